@@ -1,0 +1,321 @@
+"""Generate tests/golden/* from the REFERENCE's own functions (run in the build container only).
+
+  python oracle/make_golden.py            # needs /root/reference (read-only) + transformers
+
+Nothing here travels to the GPU box except its outputs (small .npz/.json fixtures = data: seeded
+input recipes and the reference's outputs).  The reference package cannot be imported as a whole
+(qwen_vl_utils / deepcodec / flash_attn are absent — SURVEY.md §8c), so the hot-path modules
+lvu/lvu_config.py, lvu/lvu_cache.py, lvu/utils.py are loaded individually through a 5-line shim,
+and the end-to-end vector comes from the *composite oracle*: installed transformers' Qwen2-VL text
+model (random weights, CPU) whose attention modules call the reference's post_process_kv_cache from
+a forward hook — the same point the reference calls it (qwen25_lvu.py:183-192).
+
+Two index columns are stored for every select case:
+  ref_idx        — raw output of the reference function on torch-CPU (argsort stable=False = introsort)
+  ref_idx_stable — the same reference function with torch.Tensor.argsort forced stable, which is how
+                   the reference behaves on its deployment device (torch CUDA sort = stable radix sort).
+"""
+from __future__ import annotations
+
+import hashlib
+import importlib.util
+import json
+import os
+import sys
+import types
+import typing
+
+import numpy as np
+import torch
+
+REF = "/root/reference"
+HERE = os.path.dirname(os.path.abspath(__file__))
+OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+sys.path.insert(0, os.path.dirname(HERE))
+
+from oracle import qp_oracle as O  # noqa: E402
+
+
+def load_reference():
+    import transformers.cache_utils as cu
+    for n in ("List", "Dict", "Optional", "Any", "Tuple"):
+        if not hasattr(cu, n):
+            setattr(cu, n, getattr(typing, n))
+    pkg = types.ModuleType("lvu"); pkg.__path__ = [os.path.join(REF, "lvu")]
+    sys.modules["lvu"] = pkg
+    mods = {}
+    for name in ("lvu_config", "lvu_cache", "utils"):
+        spec = importlib.util.spec_from_file_location(f"lvu.{name}", os.path.join(REF, "lvu", f"{name}.py"))
+        m = importlib.util.module_from_spec(spec); sys.modules[f"lvu.{name}"] = m
+        spec.loader.exec_module(m); mods[name] = m
+    return mods
+
+
+class force_stable_argsort:
+    """Emulates the reference's CUDA deployment where Tensor.argsort is a stable radix sort."""
+
+    def __enter__(self):
+        self.orig = torch.Tensor.argsort
+        orig = self.orig
+
+        def stable(t, *a, **kw):
+            kw["stable"] = True
+            return orig(t, *a, **kw)
+        torch.Tensor.argsort = stable
+
+    def __exit__(self, *exc):
+        torch.Tensor.argsort = self.orig
+
+
+# ---------------------------------------------------------------- seeded input recipes (shared with tests)
+
+def make_keys(dist: str, hkv: int, n: int, seed: int, d: int = 128) -> torch.Tensor:
+    """bf16 [1, Hkv, n, D] new-key block.  Recipes documented in tests/golden/README.md."""
+    rs = np.random.RandomState(seed)
+    if dist == "normal":
+        x = rs.standard_normal((hkv, n, d))
+    elif dist == "heavy":          # per-channel scales with a few RoPE-style outlier channels + per-token scale
+        ch = np.exp(rs.standard_normal((hkv, 1, d)) * 0.7)
+        ch[:, :, rs.randint(0, d, size=3)] *= 12.0
+        tok = np.exp(rs.standard_normal((1, n, 1)) * 0.5)
+        x = rs.standard_normal((hkv, n, d)) * ch * tok
+    elif dist == "all_equal":      # every token identical -> one tie class
+        x = np.tile(rs.standard_normal((hkv, 1, d)), (1, n, 1))
+    elif dist == "distinct":       # token t = e0 * (1 + t/256) scaled so every bf16 norm is distinct
+        assert n <= 120
+        x = np.zeros((hkv, n, d))
+        x[0, :, 0] = 1.0 + rs.permutation(n) / 128.0
+    elif dist == "few_levels":     # norms drawn from 5 exact levels -> massive ties
+        x = np.zeros((hkv, n, d))
+        x[0, :, 0] = rs.randint(1, 6, size=n).astype(np.float64)
+    else:
+        raise ValueError(dist)
+    return torch.from_numpy(x.astype(np.float32)).to(torch.bfloat16)[None]
+
+
+def sha(*arrays) -> str:
+    h = hashlib.sha256()
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+SELECT_CASES = [  # (dist, Hkv, n, k)
+    ("normal", 4, 64, 32), ("normal", 2, 720, 180), ("normal", 4, 2880, 720), ("normal", 4, 5775, 2887),
+    ("normal", 8, 960, 480), ("heavy", 4, 5760, 2880), ("heavy", 2, 2880, 1440), ("heavy", 8, 720, 360),
+    ("heavy", 4, 2240, 1120), ("all_equal", 4, 257, 100), ("distinct", 4, 100, 37), ("distinct", 2, 64, 63),
+    ("few_levels", 4, 1000, 333), ("few_levels", 4, 2880, 720), ("normal", 4, 35, 7), ("normal", 4, 100, 28),
+    ("normal", 4, 2, 1), ("heavy", 4, 4097, 1),
+]
+
+
+def gen_select(ref):
+    U = ref["utils"]
+    out = {}
+    meta = []
+    for ci, (dist, hkv, n, k) in enumerate(SELECT_CASES):
+        seed = 1000 + ci
+        keys = make_keys(dist, hkv, n, seed)
+        vals = torch.zeros_like(keys)
+        hid = torch.zeros(1, n, 8)
+        mask = U.get_top_k_mask_to_predict(None, keys, vals, hid, top_k=k, predict_type="key_norms_small")
+        ref_idx = torch.nonzero(mask[0], as_tuple=True)[0].numpy().astype(np.int32)
+        with force_stable_argsort():
+            mask_s = U.get_top_k_mask_to_predict(None, keys, vals, hid, top_k=k, predict_type="key_norms_small")
+        ref_idx_s = torch.nonzero(mask_s[0], as_tuple=True)[0].numpy().astype(np.int32)
+        tnorm = keys[0].transpose(0, 1).flatten(1, 2).norm(2, dim=-1)          # utils.py:134-135 verbatim semantics
+        tbits = O.torch_bf16_to_bits(tnorm)
+        obits = O.key_norms_bf16(O.key_sumsq_heads(O.torch_bf16_to_bits(keys[0])))
+        tau, n_lt, n_eq = O.select_threshold(tbits, k)
+        out[f"c{ci}_ref_idx"] = ref_idx
+        out[f"c{ci}_ref_idx_stable"] = ref_idx_s
+        out[f"c{ci}_torch_norm_bits"] = tbits
+        meta.append(dict(case=ci, dist=dist, hkv=hkv, n=n, k=k, seed=seed, tau=tau, n_less=n_lt, n_equal=n_eq,
+                         boundary_tied=bool(n_lt + n_eq != k), norm_rows_differ=int((tbits != obits).sum()),
+                         sym_diff_cpu_vs_stable=int(len(set(ref_idx) ^ set(ref_idx_s)))))
+        print(meta[-1])
+    np.savez_compressed(os.path.join(OUT, "gv1_select.npz"), **out)
+    json.dump(meta, open(os.path.join(OUT, "gv1_select.json"), "w"), indent=1)
+
+
+def gen_effective_k(ref):
+    U, C = ref["utils"], ref["lvu_config"]
+    rows = []
+    L = 28
+    for q_len in (1, 2, 15, 35, 100, 960, 2240, 2880, 5760, 5775):
+        for top_k in (None, 1, 64, 5760):
+            for top_p in (None, 0.0, 0.1, 0.2, 0.25, 0.29, 0.5, 0.75, 1.0):
+                for decay, factor in ((None, None), ("linear", 0.5), ("exponential", 0.9), ("exponential", 0.33)):
+                    for layer in (0, 1, 14, 27):
+                        for enable in (True, False):
+                            cfg = C.LVUConfig(model_name_or_path="x", top_k=top_k, top_p=top_p, top_k_decay_type=decay,
+                                              top_k_decay_factor=factor, enable=enable)
+                            lc = C.LVULayerConfig(layer_idx=layer, total_layers=L, lvu_config=cfg)
+                            hkv, d = 1, 8
+                            keys = torch.arange(q_len, dtype=torch.float32).add(1).view(1, 1, q_len, 1).repeat(1, hkv, 1, d).to(torch.bfloat16)
+                            hid = torch.zeros(1, q_len, 4)
+                            try:
+                                res = U.post_process_kv_cache(hid, None, None, None, None, None, (keys, keys.clone()), lc)
+                                kept = res[5][0].shape[2]
+                                eff = None if kept == q_len else kept
+                            except Exception as ex:   # e.g. top_k None with decay -> TypeError in the reference
+                                eff = f"raise:{type(ex).__name__}"
+                            rows.append([q_len, top_k, top_p, decay, factor, layer, L, enable, eff])
+    json.dump(rows, open(os.path.join(OUT, "gv3_effective_k.json"), "w"))
+    print("effective_k rows", len(rows))
+
+
+COMPACT_CASES = [(0, 15, 7, 4), (2887, 5760, 2880, 4), (8640, 2880, 720, 4), (100, 960, 480, 8), (5, 64, 63, 2), (0, 2240, 1120, 4)]
+
+
+def gen_compaction(ref):
+    U, C = ref["utils"], ref["lvu_config"]
+    meta = []
+    for ci, (past, n, k, hkv) in enumerate(COMPACT_CASES):
+        rs = np.random.RandomState(2000 + ci)
+        keys = torch.from_numpy(rs.standard_normal((1, hkv, past + n, 128)).astype(np.float32)).to(torch.bfloat16)
+        vals = torch.from_numpy(rs.standard_normal((1, hkv, past + n, 128)).astype(np.float32)).to(torch.bfloat16)
+        hid = torch.from_numpy(rs.standard_normal((1, n, 16)).astype(np.float32))
+        cfg = C.LVUConfig(model_name_or_path="x", top_k=k, prefill_prune_starting_layer=0)
+        lc = C.LVULayerConfig(layer_idx=0, total_layers=4, lvu_config=cfg)
+        pos_ids = torch.arange(n)[None, None].repeat(3, 1, 1) + 7
+        cache_pos = torch.arange(n) + past
+        pe = (torch.from_numpy(rs.standard_normal((3, 1, n, 8)).astype(np.float32)), torch.from_numpy(rs.standard_normal((3, 1, n, 8)).astype(np.float32)))
+        with force_stable_argsort():
+            h2, am2, pi2, cp2, pe2, (k2, v2) = U.post_process_kv_cache(hid, None, pos_ids, cache_pos, pe, None, (keys, vals), lc)
+        meta.append(dict(case=ci, past=past, n=n, k=k, hkv=hkv, seed=2000 + ci,
+                         k_sha=sha(O.torch_bf16_to_bits(k2[0])), v_sha=sha(O.torch_bf16_to_bits(v2[0])),
+                         out_len=int(k2.shape[2]), hidden_sha=sha(h2.numpy()), pos_sha=sha(pi2.numpy()),
+                         cache_pos_sha=sha(cp2.numpy()), pe_sha=sha(pe2[0].numpy(), pe2[1].numpy()),
+                         hidden_shape=list(h2.shape), pos_shape=list(pi2.shape)))
+        print(meta[-1]["case"], meta[-1]["out_len"], meta[-1]["hidden_shape"])
+    json.dump(meta, open(os.path.join(OUT, "gv2_compaction.json"), "w"), indent=1)
+
+
+# ---------------------------------------------------------------- composite end-to-end oracle (GV5) + rope index (GV6)
+
+TINY = dict(hidden=256, n_heads=2, n_kv_heads=1, head_dim=128, intermediate=512, n_layers=3, vocab=320)
+
+E2E_CASES = [
+    # name, dtype, frames, grid_h, grid_w, group_size, prefix, tail, top_p, top_k
+    ("fp32_rho1", "float32", 8, 4, 6, 4, 5, 7, None, None),
+    ("fp32_rho05", "float32", 8, 4, 6, 4, 5, 7, 0.5, None),
+    ("fp32_rho025_g2", "float32", 12, 8, 4, 2, 15, 9, 0.25, None),
+    ("fp32_topk5", "float32", 8, 4, 6, 4, 3, 4, None, 5),
+    ("bf16_rho05", "bfloat16", 8, 4, 6, 4, 5, 7, 0.5, None),
+    ("bf16_rho025_g2", "bfloat16", 12, 8, 4, 2, 15, 9, 0.25, None),
+]
+
+
+def build_hf_tiny(dtype):
+    from transformers import Qwen2VLConfig, Qwen2VLForConditionalGeneration
+    t = TINY
+    cfg = Qwen2VLConfig(
+        text_config=dict(hidden_size=t["hidden"], num_attention_heads=t["n_heads"], num_key_value_heads=t["n_kv_heads"],
+                         intermediate_size=t["intermediate"], num_hidden_layers=t["n_layers"], vocab_size=t["vocab"],
+                         rms_norm_eps=1e-6, max_position_embeddings=32768, tie_word_embeddings=False,
+                         rope_parameters=dict(rope_type="default", mrope_section=[16, 24, 24], rope_theta=1_000_000.0)),
+        vision_config=dict(depth=1, embed_dim=32, hidden_size=t["hidden"], num_heads=2, mlp_ratio=2, patch_size=14,
+                           spatial_merge_size=2, temporal_patch_size=2),
+    )
+    cfg._attn_implementation = "eager"
+    torch.manual_seed(0)
+    model = Qwen2VLForConditionalGeneration(cfg).eval()
+    spec = O.TextSpec(**t)
+    w = O.synthetic_text_weights(spec, seed=7, dtype=torch.float32, norm_jitter=0.1)
+    lm = model.model.language_model
+    sd = {}
+    for k, v in w.items():
+        if k == "lm_head.weight":
+            continue
+        sd[k.replace("layers.", "layers.").replace("q_proj", "self_attn.q_proj").replace("k_proj", "self_attn.k_proj")
+           .replace("v_proj", "self_attn.v_proj").replace("o_proj", "self_attn.o_proj")] = v
+    missing, unexpected = lm.load_state_dict(sd, strict=False)
+    assert not unexpected and all("rotary" in m for m in missing), (missing, unexpected)
+    model.lm_head.weight.data.copy_(w["lm_head.weight"])
+    return model.to(dtype), spec, w
+
+
+def gen_e2e(ref):
+    from transformers import DynamicCache
+    U, C = ref["utils"], ref["lvu_config"]
+    out, meta = {}, []
+    for (name, dtn, frames, gh, gw, gs, prefix, tail, top_p, top_k) in E2E_CASES:
+        dtype = getattr(torch, dtn)
+        model, spec, w = build_hf_tiny(dtype)
+        lm = model.model.language_model
+        n_video = (frames // 2) * (gh // 2) * (gw // 2)
+        T = prefix + n_video + tail
+        plan = O.plan_groups(frames, gs, gh, gw, prefix, T)
+        pos, delta = O.mrope_positions(prefix, (frames // 2, gh, gw), tail)
+        rs = np.random.RandomState(4242)
+        embeds = torch.from_numpy(rs.standard_normal((T, spec.hidden)).astype(np.float32) * 0.5).to(dtype)
+        cfg = C.LVUConfig(model_name_or_path="x", top_k=top_k, top_p=top_p)
+        layer_cfgs = [C.LVULayerConfig(layer_idx=i, total_layers=spec.n_layers, lvu_config=cfg) for i in range(spec.n_layers)]
+        cache = DynamicCache(config=model.config.get_text_config())
+        kept_trace = []
+
+        def make_hook(i):
+            def hook(mod, args, kwargs, output):
+                hs = kwargs["hidden_states"]
+                lay = cache.layers[i]
+                before = lay.keys.shape[2]
+                with force_stable_argsort():
+                    res = U.post_process_kv_cache(hs, None, None, None, None, None, (lay.keys, lay.values), layer_cfgs[i])
+                lay.keys, lay.values = res[5]
+                kept_trace.append((i, before, lay.keys.shape[2]))
+                return output
+            return hook
+        hooks = [l.self_attn.register_forward_hook(make_hook(i), with_kwargs=True) for i, l in enumerate(lm.layers)]
+        start = 0
+        segs = plan.tokens + [plan.tail_len]
+        post = torch.from_numpy(pos)
+        with torch.no_grad():
+            for gi, n in enumerate(segs):
+                if gi == len(segs) - 1:
+                    cfg.enable = False        # qwen25_lvu.py:737-738: no pruning for the prompt tail
+                pid = post[:, None, start:start + n]
+                past_seen = start
+                o = lm(inputs_embeds=embeds[None, start:start + n], position_ids=pid, past_key_values=cache, use_cache=True,
+                       cache_position=torch.arange(n) + past_seen)
+                start += n
+            logits = model.lm_head(o.last_hidden_state[:, -1]).float()[0]
+        for h in hooks:
+            h.remove()
+        out[f"{name}_logits"] = logits.numpy()
+        out[f"{name}_cache_len"] = np.array([cache.layers[i].keys.shape[2] for i in range(spec.n_layers)], dtype=np.int32)
+        meta.append(dict(name=name, dtype=dtn, frames=frames, grid_h=gh, grid_w=gw, group_size=gs, prefix=prefix, tail=tail,
+                         top_p=top_p, top_k=top_k, group_tokens=plan.tokens, tail_len=plan.tail_len, embed_seed=4242,
+                         weight_seed=7, trace=kept_trace))
+        print(name, plan.tokens, out[f"{name}_cache_len"], float(logits.abs().max()))
+    np.savez_compressed(os.path.join(OUT, "gv5_e2e.npz"), **out)
+    json.dump(meta, open(os.path.join(OUT, "gv5_e2e.json"), "w"), indent=1)
+
+
+def gen_rope_index():
+    """GV6: installed transformers' Qwen2-VL get_rope_index (5.15) on grids where it agrees with the
+    4.50.0 rule (text after the video resumes at max(position)+1; 5.15 uses max(h,w)//merge, equal
+    when t <= max(h,w)//merge)."""
+    model, spec, _ = build_hf_tiny(torch.float32)
+    vid, vs = model.config.video_token_id, model.config.vision_start_token_id
+    rows = []
+    for (prefix, t, gh, gw, tail) in [(5, 3, 4, 6, 7), (15, 2, 8, 4, 9), (16, 8, 40, 72, 30), (3, 3, 6, 6, 1), (0, 1, 2, 2, 2)]:
+        n_video = t * (gh // 2) * (gw // 2)
+        ids = torch.cat([torch.arange(prefix) + 10, torch.full((n_video,), vid), torch.arange(tail) + 10])[None]
+        mm = (ids == vid).long() * 2
+        pos, delta = model.model.get_rope_index(ids, mm, None, torch.tensor([[t, gh, gw]]), torch.ones_like(ids))
+        rows.append(dict(prefix=prefix, t=t, gh=gh, gw=gw, tail=tail, pos_sha=sha(pos[:, 0].numpy().astype(np.int64)),
+                         delta=int(delta[0, 0]), last=[int(x) for x in pos[:, 0, -1]]))
+        print(rows[-1])
+    json.dump(rows, open(os.path.join(OUT, "gv6_rope_index.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    ref = load_reference()
+    which = sys.argv[1:] or ["select", "effk", "compact", "e2e", "rope"]
+    if "select" in which: gen_select(ref)
+    if "effk" in which: gen_effective_k(ref)
+    if "compact" in which: gen_compaction(ref)
+    if "e2e" in which: gen_e2e(ref)
+    if "rope" in which: gen_rope_index()
