@@ -1,0 +1,128 @@
+/*
+ * quickprefill.h — C ABI of libquickprefill.so, the MI355X (gfx950) QuickPrefill hot path.
+ *
+ * One entry point per operator seam of the reference's group-chunked prefill with key-L2-norm
+ * KV-cache pruning (TIGER-AI-Lab/QuickVideo; citations are into /root/reference):
+ *
+ *   seam 1  prune     lvu/utils.py:197-376  post_process_kv_cache  (+ :133-136, :190-194 scoring)
+ *   seam 2  append    lvu/models/qwen25_lvu.py:51-58 (M-RoPE + cache.update) -> lvu/lvu_cache.py:90-98
+ *   seam 3  attention lvu/models/qwen25_lvu.py:61-62,102-112 (repeat_kv + flash_attn causal)
+ *   glue    RMSNorm / SwiGLU of the patched decoder layer, qwen25_lvu.py:169,196-198 [transformers]
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless it says "host".
+ *   - bf16 tensors are passed as void* (16-bit patterns); the caller owns every buffer, including the
+ *     workspace sized with qp_select_workspace_bytes(); the library allocates nothing on the device
+ *     and never synchronises: all work is enqueued on the hipStream_t given (passed as void*).
+ *   - every function returns QP_OK (0) or a negative qp_status; qp_last_error() gives a thread-local
+ *     message.  Invalid arguments are rejected before anything is launched.
+ *   - KV arena layout per layer: K and V are [n_kv_heads][capacity][head_dim] bf16; "head stride"
+ *     arguments are in ELEMENTS (capacity*head_dim for the arena).  head_dim must be 128.
+ *   - "new" K/V of the group being prefilled may live either in the arena tail
+ *     (k_new = k_cache + prefix_len*head_dim, same head stride) or in a separate staging block
+ *     [n_kv_heads][n][head_dim]; attention takes (prefix, new) as two segments so the pruning step is a
+ *     pure gather staging -> arena with no in-place hazard.
+ */
+#ifndef QUICKPREFILL_H_
+#define QUICKPREFILL_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct qp_ctx qp_ctx;
+
+typedef enum qp_status {
+  QP_OK = 0,
+  QP_ERR_INVALID = -1,     /* bad argument (maps to ValueError / AssertionError in the Python mirror) */
+  QP_ERR_UNSUPPORTED = -2, /* shape outside what the kernels implement                               */
+  QP_ERR_HIP = -3,         /* a HIP runtime call failed                                              */
+  QP_ERR_WORKSPACE = -4    /* workspace too small                                                    */
+} qp_status;
+
+/* ---- context ------------------------------------------------------------------------------ */
+/* device: HIP ordinal.  One context per device/process (one process per GPU under tensor parallel). */
+int qp_create(qp_ctx** out, int device);
+void qp_destroy(qp_ctx* ctx);
+const char* qp_last_error(void);
+const char* qp_version(void);
+int qp_device_cus(const qp_ctx* ctx);
+
+/* ---- seam 2: M-RoPE + KV append  (qwen25_lvu.py:46-58) -------------------------------------- */
+/* cos/sin tables for one group: pos int64 [3][n] (temporal, height, width streams of get_rope_index,
+ * qwen25_lvu.py:613-619, 689); sections = mrope_section (e.g. {16,24,24}, sum = head_dim/2);
+ * out cos/sin bf16 [n][head_dim/2] (second half of the head repeats the first). */
+int qp_mrope_table(qp_ctx* ctx, const int64_t* pos, int64_t n, const int32_t sections[3], float theta,
+                   int head_dim, void* cos_out, void* sin_out, void* stream);
+
+/* qkv bf16 [n][(n_q+2*n_kv)*head_dim] (q heads, then k heads, then v heads — the fused q/k/v
+ * projection incl. bias).  Rotates q and k (rotate-half, bf16 rounding after each op like the
+ * reference's bf16 tensors), writes q to q_out [n][n_q][head_dim] (must not overlap qkv), k/v to
+ * k_dst/v_dst[h*dst_head_stride + (dst_row0+t)*head_dim ...], and — when head_sumsq != NULL — the
+ * canonical per-head fp32 sum of squares of the STORED (bf16) key row to head_sumsq[h*n + t]. */
+int qp_rope_append(qp_ctx* ctx, const void* qkv, const void* cos, const void* sin, int64_t n, int n_q_heads,
+                   int n_kv_heads, int head_dim, void* q_out, void* k_dst, void* v_dst, int64_t dst_head_stride,
+                   int64_t dst_row0, float* head_sumsq, void* stream);
+
+/* ---- seam 3: prefill attention over (pruned prefix, new group)  (qwen25_lvu.py:61-62,102-112) - */
+/* q bf16 [n][n_q][128]; prefix K/V rows [0,prefix_len) with head stride prefix_head_stride; new K/V rows
+ * [0,n) with head stride new_head_stride.  Query i attends every prefix key and new keys j <= i
+ * (flash-attn's bottom-right aligned causal mask); GQA native (q head h uses kv head h/(n_q/n_kv)).
+ * out bf16 [n][n_q][128].  softmax(scale * q.k) in fp32, P rounded to bf16 before P.V. */
+int qp_prefill_attn(qp_ctx* ctx, const void* q, const void* k_prefix, const void* v_prefix,
+                    int64_t prefix_head_stride, int64_t prefix_len, const void* k_new, const void* v_new,
+                    int64_t new_head_stride, int64_t n, int n_q_heads, int n_kv_heads, int head_dim, float scale,
+                    void* out, void* stream);
+
+/* ---- seam 1: key-norm scoring, k-smallest select, compaction  (utils.py:133-136, 266-342) ---- */
+/* Canonical per-head sum of squares of key rows k[h*head_stride + (row0+t)*head_dim ...], t<n ->
+ * head_sumsq[h*n+t] fp32.  (Unfused variant of what qp_rope_append emits.) */
+int qp_key_sumsq(qp_ctx* ctx, const void* k, int64_t head_stride, int64_t row0, int64_t n, int n_kv_heads,
+                 int head_dim, float* head_sumsq, void* stream);
+
+size_t qp_select_workspace_bytes(int64_t n);
+
+/* head_sumsq fp32 [n_heads_total][n] (all KV heads of the layer, ascending head order; under tensor
+ * parallelism the all-gathered per-rank partials).  norm[t] = bf16(sqrt(((s0+s1)+s2)+...)).
+ * kept_idx_out int32 [k]: the k smallest norms, ties -> lowest index, listed in ascending index order
+ * (utils.py:136,191-194,284).  norm_bits_out (uint16 [n], may be NULL) receives the bf16 norms.
+ * Requires 0 < k <= n <= 65536. */
+int qp_select_k_smallest(qp_ctx* ctx, const float* head_sumsq, int n_heads_total, int64_t n, int64_t k,
+                         int32_t* kept_idx_out, uint16_t* norm_bits_out, void* workspace, size_t workspace_bytes,
+                         void* stream);
+
+/* dst[h*dst_head_stride + (dst_row0+j)*head_dim ...] = src[h*src_head_stride + idx[j]*head_dim ...]
+ * for j<k, for K and V (utils.py:287-288, 333-336).  src and dst must not overlap. */
+int qp_gather_kv(qp_ctx* ctx, const void* k_src, const void* v_src, int64_t src_head_stride, const int32_t* idx,
+                 int64_t k, int n_kv_heads, int head_dim, void* k_dst, void* v_dst, int64_t dst_head_stride,
+                 int64_t dst_row0, void* stream);
+
+/* In-place drop-in for post_process_kv_cache's KV part on the arena (utils.py:266-342):
+ * rows [past_len, past_len+n) are the group's new tokens; on return rows [past_len, past_len+k) hold the
+ * kept ones in original order and kept_idx_out[k] lists them.  workspace >= qp_prune_workspace_bytes(). */
+size_t qp_prune_workspace_bytes(int64_t n, int64_t k, int n_kv_heads, int head_dim);
+int qp_prune_tail(qp_ctx* ctx, void* k_cache, void* v_cache, int64_t head_stride, int64_t past_len, int64_t n,
+                  int64_t k, int n_kv_heads, int head_dim, int32_t* kept_idx_out, void* workspace,
+                  size_t workspace_bytes, void* stream);
+
+/* Row gather for the hidden-state pruning hand-off (prune_for_next_layer; utils.py:292-331):
+ * dst[j][:] = src[idx[j]][:], rows of row_bytes (multiple of 16). */
+int qp_gather_rows(qp_ctx* ctx, const void* src, const int32_t* idx, int64_t k, int64_t row_bytes, void* dst,
+                   void* stream);
+
+/* ---- glue of the patched decoder layer (qwen25_lvu.py:166-198) [transformers Qwen2RMSNorm/MLP] -- */
+/* if delta != NULL: h = bf16(h + delta) (written back);  out = w * bf16(h * rsqrt(mean(h^2) + eps)). */
+int qp_add_rmsnorm(qp_ctx* ctx, void* h, const void* delta, const void* w, void* out, int64_t n, int hidden,
+                   float eps, void* stream);
+/* h = bf16(h + delta) only (last residual of the layer). */
+int qp_add_inplace(qp_ctx* ctx, void* h, const void* delta, int64_t n_elems, void* stream);
+/* gate_up bf16 [n][2*inter] (gate columns then up columns) -> out[n][inter] = bf16(bf16(silu(g)) * u). */
+int qp_swiglu(qp_ctx* ctx, const void* gate_up, int64_t n, int inter, void* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QUICKPREFILL_H_ */

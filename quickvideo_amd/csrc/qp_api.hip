@@ -1,0 +1,214 @@
+// C ABI of libquickprefill.so (include/quickprefill.h): argument validation + launches.  No torch types,
+// no device allocation, no synchronisation: everything is enqueued on the caller's stream.
+#include "qp_common.h"
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+static thread_local char g_err[512] = "";
+
+int qp_fail(int status, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return status;
+}
+
+int qp_check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return qp_fail(QP_ERR_HIP, "%s launch failed: %s", what, hipGetErrorString(e));
+  return QP_OK;
+}
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+extern "C" {
+
+const char* qp_last_error(void) { return g_err; }
+const char* qp_version(void) { return "quickprefill-mi355x 0.1 (gfx950)"; }
+
+int qp_create(qp_ctx** out, int device) {
+  QP_REQUIRE(out != nullptr, QP_ERR_INVALID, "qp_create: out is NULL");
+  int count = 0;
+  hipError_t e = hipGetDeviceCount(&count);
+  if (e != hipSuccess || count <= 0) return qp_fail(QP_ERR_HIP, "qp_create: no HIP device (%s)", hipGetErrorString(e));
+  QP_REQUIRE(device >= 0 && device < count, QP_ERR_INVALID, "qp_create: device %d out of range [0,%d)", device, count);
+  hipDeviceProp_t prop;
+  e = hipGetDeviceProperties(&prop, device);
+  if (e != hipSuccess) return qp_fail(QP_ERR_HIP, "qp_create: hipGetDeviceProperties: %s", hipGetErrorString(e));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return qp_fail(QP_ERR_UNSUPPORTED, "qp_create: device %d is %s; this library is built for gfx950 (MI355X) only", device,
+                   prop.gcnArchName);
+  qp_ctx* c = new (std::nothrow) qp_ctx;
+  QP_REQUIRE(c != nullptr, QP_ERR_INVALID, "qp_create: out of host memory");
+  c->device = device;
+  c->cus = prop.multiProcessorCount;
+  c->lds_per_cu = (int)prop.sharedMemPerBlock;
+  *out = c;
+  return QP_OK;
+}
+
+void qp_destroy(qp_ctx* ctx) { delete ctx; }
+int qp_device_cus(const qp_ctx* ctx) { return ctx ? ctx->cus : 0; }
+
+int qp_mrope_table(qp_ctx* ctx, const int64_t* pos, int64_t n, const int32_t sections[3], float theta, int head_dim,
+                   void* cos_out, void* sin_out, void* stream) {
+  QP_REQUIRE(ctx && pos && sections && cos_out && sin_out, QP_ERR_INVALID, "qp_mrope_table: NULL argument");
+  QP_REQUIRE(n >= 0, QP_ERR_INVALID, "qp_mrope_table: n=%lld", (long long)n);
+  QP_REQUIRE(head_dim > 0 && head_dim % 2 == 0 && sections[0] + sections[1] + sections[2] == head_dim / 2, QP_ERR_INVALID,
+             "qp_mrope_table: mrope sections %d+%d+%d must sum to head_dim/2=%d", sections[0], sections[1], sections[2],
+             head_dim / 2);
+  if (n == 0) return QP_OK;
+  return qp_launch_mrope_table(pos, n, sections, theta, head_dim, cos_out, sin_out, (hipStream_t)stream);
+}
+
+int qp_rope_append(qp_ctx* ctx, const void* qkv, const void* cos, const void* sin, int64_t n, int n_q_heads, int n_kv_heads,
+                   int head_dim, void* q_out, void* k_dst, void* v_dst, int64_t dst_head_stride, int64_t dst_row0,
+                   float* head_sumsq, void* stream) {
+  QP_REQUIRE(ctx && qkv && cos && sin && q_out && k_dst && v_dst, QP_ERR_INVALID, "qp_rope_append: NULL argument");
+  QP_REQUIRE(head_dim == 128, QP_ERR_UNSUPPORTED, "qp_rope_append: head_dim=%d (only 128)", head_dim);
+  QP_REQUIRE(n >= 0 && n_q_heads > 0 && n_kv_heads > 0 && dst_row0 >= 0, QP_ERR_INVALID, "qp_rope_append: bad sizes");
+  QP_REQUIRE(dst_head_stride % 8 == 0 && dst_head_stride >= (dst_row0 + n) * head_dim, QP_ERR_INVALID,
+             "qp_rope_append: head stride %lld too small for rows [%lld,%lld)", (long long)dst_head_stride, (long long)dst_row0,
+             (long long)(dst_row0 + n));
+  QP_REQUIRE(aligned16(qkv) && aligned16(cos) && aligned16(sin) && aligned16(q_out) && aligned16(k_dst) && aligned16(v_dst),
+             QP_ERR_INVALID, "qp_rope_append: pointers must be 16-byte aligned");
+  if (n == 0) return QP_OK;
+  return qp_launch_rope_append(qkv, cos, sin, n, n_q_heads, n_kv_heads, q_out, k_dst, v_dst, dst_head_stride, dst_row0,
+                               head_sumsq, (hipStream_t)stream);
+}
+
+int qp_prefill_attn(qp_ctx* ctx, const void* q, const void* k_prefix, const void* v_prefix, int64_t prefix_head_stride,
+                    int64_t prefix_len, const void* k_new, const void* v_new, int64_t new_head_stride, int64_t n,
+                    int n_q_heads, int n_kv_heads, int head_dim, float scale, void* out, void* stream) {
+  QP_REQUIRE(ctx && q && k_new && v_new && out, QP_ERR_INVALID, "qp_prefill_attn: NULL argument");
+  QP_REQUIRE(head_dim == 128, QP_ERR_UNSUPPORTED, "qp_prefill_attn: head_dim=%d (only 128)", head_dim);
+  QP_REQUIRE(n >= 0 && prefix_len >= 0, QP_ERR_INVALID, "qp_prefill_attn: negative length");
+  QP_REQUIRE(n_q_heads > 0 && n_kv_heads > 0 && n_q_heads % n_kv_heads == 0, QP_ERR_INVALID,
+             "qp_prefill_attn: n_q_heads=%d not a multiple of n_kv_heads=%d", n_q_heads, n_kv_heads);
+  QP_REQUIRE(prefix_len == 0 || (k_prefix && v_prefix && prefix_head_stride >= prefix_len * head_dim), QP_ERR_INVALID,
+             "qp_prefill_attn: prefix pointers/stride invalid for prefix_len=%lld", (long long)prefix_len);
+  QP_REQUIRE(new_head_stride >= n * head_dim && new_head_stride % 8 == 0 && prefix_head_stride % 8 == 0, QP_ERR_INVALID,
+             "qp_prefill_attn: bad head strides");
+  QP_REQUIRE(aligned16(q) && aligned16(k_new) && aligned16(v_new) && aligned16(out) && aligned16(k_prefix) && aligned16(v_prefix),
+             QP_ERR_INVALID, "qp_prefill_attn: pointers must be 16-byte aligned");
+  QP_REQUIRE(n_q_heads <= 65535, QP_ERR_UNSUPPORTED, "qp_prefill_attn: too many heads");
+  if (n == 0) return QP_OK;
+  return qp_launch_prefill_attn(ctx, q, k_prefix, v_prefix, prefix_head_stride, prefix_len, k_new, v_new, new_head_stride, n,
+                                n_q_heads, n_kv_heads, scale, out, (hipStream_t)stream);
+}
+
+int qp_key_sumsq(qp_ctx* ctx, const void* k, int64_t head_stride, int64_t row0, int64_t n, int n_kv_heads, int head_dim,
+                 float* head_sumsq, void* stream) {
+  QP_REQUIRE(ctx && k && head_sumsq, QP_ERR_INVALID, "qp_key_sumsq: NULL argument");
+  QP_REQUIRE(head_dim == 128, QP_ERR_UNSUPPORTED, "qp_key_sumsq: head_dim=%d (only 128)", head_dim);
+  QP_REQUIRE(n >= 0 && row0 >= 0 && n_kv_heads > 0 && head_stride % 8 == 0 && head_stride >= (row0 + n) * head_dim,
+             QP_ERR_INVALID, "qp_key_sumsq: bad sizes");
+  QP_REQUIRE(aligned16(k), QP_ERR_INVALID, "qp_key_sumsq: k must be 16-byte aligned");
+  if (n == 0) return QP_OK;
+  return qp_launch_key_sumsq(k, head_stride, row0, n, n_kv_heads, head_sumsq, (hipStream_t)stream);
+}
+
+size_t qp_select_workspace_bytes(int64_t n) { (void)n; return 256; }
+
+int qp_select_k_smallest(qp_ctx* ctx, const float* head_sumsq, int n_heads_total, int64_t n, int64_t k,
+                         int32_t* kept_idx_out, uint16_t* norm_bits_out, void* workspace, size_t workspace_bytes,
+                         void* stream) {
+  QP_REQUIRE(ctx && head_sumsq && kept_idx_out, QP_ERR_INVALID, "qp_select_k_smallest: NULL argument");
+  QP_REQUIRE(n_heads_total > 0, QP_ERR_INVALID, "qp_select_k_smallest: n_heads_total=%d", n_heads_total);
+  QP_REQUIRE(k > 0 && k <= n, QP_ERR_INVALID, "qp_select_k_smallest: need 0 < k <= n, got k=%lld n=%lld", (long long)k,
+             (long long)n);
+  QP_REQUIRE(n <= 65536, QP_ERR_UNSUPPORTED, "qp_select_k_smallest: n=%lld > 65536", (long long)n);
+  QP_REQUIRE(workspace_bytes >= qp_select_workspace_bytes(n) || workspace == nullptr, QP_ERR_WORKSPACE,
+             "qp_select_k_smallest: workspace too small");
+  return qp_launch_select(head_sumsq, n_heads_total, n, k, kept_idx_out, norm_bits_out, workspace, (hipStream_t)stream);
+}
+
+int qp_gather_kv(qp_ctx* ctx, const void* k_src, const void* v_src, int64_t src_head_stride, const int32_t* idx, int64_t k,
+                 int n_kv_heads, int head_dim, void* k_dst, void* v_dst, int64_t dst_head_stride, int64_t dst_row0,
+                 void* stream) {
+  QP_REQUIRE(ctx && k_src && v_src && idx && k_dst && v_dst, QP_ERR_INVALID, "qp_gather_kv: NULL argument");
+  QP_REQUIRE(head_dim == 128, QP_ERR_UNSUPPORTED, "qp_gather_kv: head_dim=%d (only 128)", head_dim);
+  QP_REQUIRE(k >= 0 && n_kv_heads > 0 && dst_row0 >= 0 && src_head_stride % 8 == 0 && dst_head_stride % 8 == 0 &&
+                 dst_head_stride >= (dst_row0 + k) * head_dim,
+             QP_ERR_INVALID, "qp_gather_kv: bad sizes");
+  QP_REQUIRE(aligned16(k_src) && aligned16(v_src) && aligned16(k_dst) && aligned16(v_dst), QP_ERR_INVALID,
+             "qp_gather_kv: pointers must be 16-byte aligned");
+  if (k == 0) return QP_OK;
+  return qp_launch_gather_kv(k_src, v_src, src_head_stride, idx, k, n_kv_heads, k_dst, v_dst, dst_head_stride, dst_row0,
+                             (hipStream_t)stream);
+}
+
+// workspace layout of qp_prune_tail: [head_sumsq fp32 Hkv*n][pad to 256][K rows Hkv*k*D bf16][V rows Hkv*k*D bf16]
+static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+size_t qp_prune_workspace_bytes(int64_t n, int64_t k, int n_kv_heads, int head_dim) {
+  return align256((size_t)n_kv_heads * n * 4) + 2 * align256((size_t)n_kv_heads * k * head_dim * 2) + 256;
+}
+
+int qp_prune_tail(qp_ctx* ctx, void* k_cache, void* v_cache, int64_t head_stride, int64_t past_len, int64_t n, int64_t k,
+                  int n_kv_heads, int head_dim, int32_t* kept_idx_out, void* workspace, size_t workspace_bytes, void* stream) {
+  QP_REQUIRE(ctx && k_cache && v_cache && kept_idx_out && workspace, QP_ERR_INVALID, "qp_prune_tail: NULL argument");
+  QP_REQUIRE(head_dim == 128, QP_ERR_UNSUPPORTED, "qp_prune_tail: head_dim=%d (only 128)", head_dim);
+  QP_REQUIRE(past_len >= 0 && k > 0 && k <= n && n_kv_heads > 0, QP_ERR_INVALID,
+             "qp_prune_tail: need past_len >= 0 and 0 < k <= n (k=%lld n=%lld)", (long long)k, (long long)n);
+  QP_REQUIRE(n <= 65536, QP_ERR_UNSUPPORTED, "qp_prune_tail: n=%lld > 65536", (long long)n);
+  QP_REQUIRE(head_stride % 8 == 0 && head_stride >= (past_len + n) * head_dim, QP_ERR_INVALID, "qp_prune_tail: head stride too small");
+  QP_REQUIRE(workspace_bytes >= qp_prune_workspace_bytes(n, k, n_kv_heads, head_dim), QP_ERR_WORKSPACE,
+             "qp_prune_tail: workspace %zu < %zu bytes", workspace_bytes, qp_prune_workspace_bytes(n, k, n_kv_heads, head_dim));
+  QP_REQUIRE(aligned16(k_cache) && aligned16(v_cache) && aligned16(workspace), QP_ERR_INVALID, "qp_prune_tail: alignment");
+  hipStream_t s = (hipStream_t)stream;
+  unsigned char* ws = (unsigned char*)workspace;
+  float* sumsq = (float*)ws;
+  unsigned char* kt = ws + align256((size_t)n_kv_heads * n * 4);
+  unsigned char* vt = kt + align256((size_t)n_kv_heads * k * head_dim * 2);
+  int rc = qp_launch_key_sumsq(k_cache, head_stride, past_len, n, n_kv_heads, sumsq, s);
+  if (rc) return rc;
+  rc = qp_launch_select(sumsq, n_kv_heads, n, k, kept_idx_out, nullptr, nullptr, s);
+  if (rc) return rc;
+  // gather the kept tail rows into the workspace, then copy them back contiguously (dst <= src row-wise, but
+  // workgroups run in no defined order, so the in-place move goes through the scratch block)
+  const unsigned short* kc = (const unsigned short*)k_cache;
+  const unsigned short* vc = (const unsigned short*)v_cache;
+  rc = qp_launch_gather_kv(kc + past_len * head_dim, vc + past_len * head_dim, head_stride, kept_idx_out, k, n_kv_heads, kt, vt,
+                           k * head_dim, 0, s);
+  if (rc) return rc;
+  return qp_launch_copy_rows_kv(kt, vt, k * head_dim, k, n_kv_heads, k_cache, v_cache, head_stride, past_len, s);
+}
+
+int qp_gather_rows(qp_ctx* ctx, const void* src, const int32_t* idx, int64_t k, int64_t row_bytes, void* dst, void* stream) {
+  QP_REQUIRE(ctx && src && idx && dst, QP_ERR_INVALID, "qp_gather_rows: NULL argument");
+  QP_REQUIRE(k >= 0 && row_bytes > 0 && row_bytes % 16 == 0, QP_ERR_INVALID, "qp_gather_rows: row_bytes=%lld must be a multiple of 16",
+             (long long)row_bytes);
+  QP_REQUIRE(aligned16(src) && aligned16(dst), QP_ERR_INVALID, "qp_gather_rows: alignment");
+  if (k == 0) return QP_OK;
+  return qp_launch_gather_rows(src, idx, k, row_bytes, dst, (hipStream_t)stream);
+}
+
+int qp_add_rmsnorm(qp_ctx* ctx, void* h, const void* delta, const void* w, void* out, int64_t n, int hidden, float eps,
+                   void* stream) {
+  QP_REQUIRE(ctx && h && w && out, QP_ERR_INVALID, "qp_add_rmsnorm: NULL argument");
+  QP_REQUIRE(n >= 0 && hidden > 0 && hidden % 8 == 0 && hidden <= 32768, QP_ERR_INVALID, "qp_add_rmsnorm: hidden=%d", hidden);
+  QP_REQUIRE(aligned16(h) && aligned16(delta) && aligned16(w) && aligned16(out), QP_ERR_INVALID, "qp_add_rmsnorm: alignment");
+  return qp_launch_add_rmsnorm(h, delta, w, out, n, hidden, eps, (hipStream_t)stream);
+}
+
+int qp_add_inplace(qp_ctx* ctx, void* h, const void* delta, int64_t n_elems, void* stream) {
+  QP_REQUIRE(ctx && h && delta, QP_ERR_INVALID, "qp_add_inplace: NULL argument");
+  QP_REQUIRE(n_elems >= 0 && n_elems % 8 == 0, QP_ERR_INVALID, "qp_add_inplace: n_elems must be a multiple of 8");
+  QP_REQUIRE(aligned16(h) && aligned16(delta), QP_ERR_INVALID, "qp_add_inplace: alignment");
+  if (n_elems == 0) return QP_OK;
+  return qp_launch_add_inplace(h, delta, n_elems, (hipStream_t)stream);
+}
+
+int qp_swiglu(qp_ctx* ctx, const void* gate_up, int64_t n, int inter, void* out, void* stream) {
+  QP_REQUIRE(ctx && gate_up && out, QP_ERR_INVALID, "qp_swiglu: NULL argument");
+  QP_REQUIRE(n >= 0 && inter > 0 && inter % 8 == 0, QP_ERR_INVALID, "qp_swiglu: inter=%d must be a multiple of 8", inter);
+  QP_REQUIRE(aligned16(gate_up) && aligned16(out), QP_ERR_INVALID, "qp_swiglu: alignment");
+  if (n == 0) return QP_OK;
+  return qp_launch_swiglu(gate_up, n, inter, out, (hipStream_t)stream);
+}
+
+}  // extern "C"

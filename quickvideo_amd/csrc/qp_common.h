@@ -1,0 +1,59 @@
+// Shared declarations of libquickprefill (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/quickprefill.h"
+
+struct qp_ctx {
+  int device;
+  int cus;
+  int lds_per_cu;
+};
+
+// thread-local error message (qp_api.cpp)
+int qp_fail(int status, const char* fmt, ...);
+int qp_check_launch(const char* what);
+
+#define QP_REQUIRE(cond, status, ...) do { if (!(cond)) return qp_fail((status), __VA_ARGS__); } while (0)
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef float f32x8_t __attribute__((ext_vector_type(8)));
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x8_t __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
+// round-to-nearest-even fp32 -> bf16 bits (NaN kept quiet)
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x0040u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float round_bf16(float f) { return bf16_bits_to_f32(f32_to_bf16_bits(f)); }
+
+// kernel launchers (one per .hip file)
+int qp_launch_mrope_table(const int64_t* pos, int64_t n, const int32_t* sections, float theta, int head_dim, void* cos_out,
+                          void* sin_out, hipStream_t s);
+int qp_launch_rope_append(const void* qkv, const void* cos, const void* sin, int64_t n, int hq, int hkv, void* q_out,
+                          void* k_dst, void* v_dst, int64_t dst_head_stride, int64_t dst_row0, float* head_sumsq,
+                          hipStream_t s);
+int qp_launch_key_sumsq(const void* k, int64_t head_stride, int64_t row0, int64_t n, int hkv, float* head_sumsq,
+                        hipStream_t s);
+int qp_launch_select(const float* head_sumsq, int n_heads, int64_t n, int64_t k, int32_t* kept, uint16_t* norm_bits,
+                     void* ws, hipStream_t s);
+int qp_launch_gather_kv(const void* k_src, const void* v_src, int64_t src_head_stride, const int32_t* idx, int64_t k,
+                        int hkv, void* k_dst, void* v_dst, int64_t dst_head_stride, int64_t dst_row0, hipStream_t s);
+int qp_launch_gather_rows(const void* src, const int32_t* idx, int64_t k, int64_t row_bytes, void* dst, hipStream_t s);
+int qp_launch_copy_rows_kv(const void* k_src, const void* v_src, int64_t src_head_stride, int64_t k, int hkv, void* k_dst,
+                           void* v_dst, int64_t dst_head_stride, int64_t dst_row0, hipStream_t s);
+int qp_launch_add_rmsnorm(void* h, const void* delta, const void* w, void* out, int64_t n, int hidden, float eps,
+                          hipStream_t s);
+int qp_launch_add_inplace(void* h, const void* delta, int64_t n_elems, hipStream_t s);
+int qp_launch_swiglu(const void* gate_up, int64_t n, int inter, void* out, hipStream_t s);
+int qp_launch_prefill_attn(const qp_ctx* ctx, const void* q, const void* k_prefix, const void* v_prefix,
+                           int64_t prefix_head_stride, int64_t prefix_len, const void* k_new, const void* v_new,
+                           int64_t new_head_stride, int64_t n, int hq, int hkv, float scale, void* out, hipStream_t s);

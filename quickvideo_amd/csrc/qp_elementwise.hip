@@ -1,0 +1,116 @@
+// Glue kernels of the patched decoder layer (qwen25_lvu.py:166-198): residual add + RMSNorm, SwiGLU.
+// HBM-bound, 16-B vector accesses; math mirrors transformers' Qwen2RMSNorm / Qwen2MLP on bf16 tensors
+// (fp32 inside, one bf16 rounding per torch op).
+#include "qp_common.h"
+
+__global__ __launch_bounds__(256) void add_rmsnorm_kernel(uint4* __restrict__ h, const uint4* __restrict__ delta,
+                                                          const uint4* __restrict__ w, uint4* __restrict__ out, int hidden16,
+                                                          float inv_hidden, float eps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint4* row = (uint4*)smem;                       // hidden16 chunks of the (updated) row
+  __shared__ float red[4];
+  const int64_t base = (int64_t)blockIdx.x * hidden16;
+  float ss = 0.f;
+  for (int c = threadIdx.x; c < hidden16; c += 256) {
+    uint4 x = h[base + c];
+    if (delta) {
+      uint4 d = delta[base + c];
+      unsigned xw[4] = {x.x, x.y, x.z, x.w}, dw[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float lo = __uint_as_float(xw[i] << 16) + __uint_as_float(dw[i] << 16);
+        float hi = __uint_as_float(xw[i] & 0xffff0000u) + __uint_as_float(dw[i] & 0xffff0000u);
+        xw[i] = (unsigned)f32_to_bf16_bits(lo) | ((unsigned)f32_to_bf16_bits(hi) << 16);
+      }
+      x = make_uint4(xw[0], xw[1], xw[2], xw[3]);
+      h[base + c] = x;
+    }
+    row[c] = x;
+    unsigned xw[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float lo = __uint_as_float(xw[i] << 16), hi = __uint_as_float(xw[i] & 0xffff0000u);
+      ss = __builtin_fmaf(lo, lo, ss);
+      ss = __builtin_fmaf(hi, hi, ss);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ss;
+  __syncthreads();
+  const float tot = (red[0] + red[1]) + (red[2] + red[3]);
+  const float rs = 1.0f / __fsqrt_rn(tot * inv_hidden + eps);
+  for (int c = threadIdx.x; c < hidden16; c += 256) {
+    uint4 x = row[c], ww = w[c];
+    unsigned xw[4] = {x.x, x.y, x.z, x.w}, wv[4] = {ww.x, ww.y, ww.z, ww.w}, o[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float lo = round_bf16(__uint_as_float(xw[i] << 16) * rs) * __uint_as_float(wv[i] << 16);
+      float hi = round_bf16(__uint_as_float(xw[i] & 0xffff0000u) * rs) * __uint_as_float(wv[i] & 0xffff0000u);
+      o[i] = (unsigned)f32_to_bf16_bits(lo) | ((unsigned)f32_to_bf16_bits(hi) << 16);
+    }
+    out[base + c] = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+int qp_launch_add_rmsnorm(void* h, const void* delta, const void* w, void* out, int64_t n, int hidden, float eps,
+                          hipStream_t s) {
+  if (n == 0) return QP_OK;
+  add_rmsnorm_kernel<<<(int)n, 256, (size_t)hidden * 2, s>>>((uint4*)h, (const uint4*)delta, (const uint4*)w, (uint4*)out,
+                                                              hidden / 8, 1.0f / (float)hidden, eps);
+  return qp_check_launch("add_rmsnorm");
+}
+
+__global__ __launch_bounds__(256) void add_inplace_kernel(uint4* __restrict__ h, const uint4* __restrict__ delta, int64_t n16) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) {
+    uint4 x = h[i], d = delta[i];
+    unsigned xw[4] = {x.x, x.y, x.z, x.w}, dw[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float lo = __uint_as_float(xw[k] << 16) + __uint_as_float(dw[k] << 16);
+      float hi = __uint_as_float(xw[k] & 0xffff0000u) + __uint_as_float(dw[k] & 0xffff0000u);
+      xw[k] = (unsigned)f32_to_bf16_bits(lo) | ((unsigned)f32_to_bf16_bits(hi) << 16);
+    }
+    h[i] = make_uint4(xw[0], xw[1], xw[2], xw[3]);
+  }
+}
+
+int qp_launch_add_inplace(void* h, const void* delta, int64_t n_elems, hipStream_t s) {
+  int64_t n16 = n_elems / 8;
+  int64_t blocks = (n16 + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  add_inplace_kernel<<<(int)blocks, 256, 0, s>>>((uint4*)h, (const uint4*)delta, n16);
+  return qp_check_launch("add_inplace");
+}
+
+__device__ __forceinline__ float silu_mul_bf16(float g, float u) {
+  float a = round_bf16(g / (1.0f + __expf(-g)));
+  return a * u;
+}
+
+__global__ __launch_bounds__(256) void swiglu_kernel(const uint4* __restrict__ gate_up, int64_t n, int inter16,
+                                                     uint4* __restrict__ out) {
+  const int64_t total = n * inter16;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t t = i / inter16, c = i - t * inter16;
+    uint4 g = gate_up[t * 2 * inter16 + c], u = gate_up[t * 2 * inter16 + inter16 + c];
+    unsigned gw[4] = {g.x, g.y, g.z, g.w}, uw[4] = {u.x, u.y, u.z, u.w}, o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float lo = silu_mul_bf16(__uint_as_float(gw[k] << 16), __uint_as_float(uw[k] << 16));
+      float hi = silu_mul_bf16(__uint_as_float(gw[k] & 0xffff0000u), __uint_as_float(uw[k] & 0xffff0000u));
+      o[k] = (unsigned)f32_to_bf16_bits(lo) | ((unsigned)f32_to_bf16_bits(hi) << 16);
+    }
+    out[i] = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+int qp_launch_swiglu(const void* gate_up, int64_t n, int inter, void* out, hipStream_t s) {
+  int64_t total = n * (inter / 8);
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (blocks < 1) blocks = 1;
+  swiglu_kernel<<<(int)blocks, 256, 0, s>>>((const uint4*)gate_up, n, inter / 8, (uint4*)out);
+  return qp_check_launch("swiglu");
+}

@@ -1,0 +1,244 @@
+// Seam 1 kernels: canonical key sum-of-squares, k-smallest select, KV gather / compaction.
+// Reference semantics: lvu/utils.py:133-136 (key_norms_small), :190-194 (mask), :266-342 (gather + cat).
+// All HBM-bound byte/integer work: coalesced 16-B accesses, 16 lanes per 256-B head row.
+#include "qp_common.h"
+
+// ------------------------------------------------------------------------------------------------
+// K4: per-head sum of squares in the canonical order (oracle: key_sumsq_heads).
+//   16 lanes per head row (D=128): lane c owns elements 8c..8c+7, accumulates them left to right
+//   (x*x is exact in fp32), then an xor butterfly 1,2,4,8 over the 16 lanes.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float chunk_sumsq(uint4 v) {
+  unsigned w[4] = {v.x, v.y, v.z, v.w};
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float lo = __uint_as_float(w[i] << 16), hi = __uint_as_float(w[i] & 0xffff0000u);
+    s = __builtin_fmaf(lo, lo, s);
+    s = __builtin_fmaf(hi, hi, s);
+  }
+  return s;
+}
+
+__device__ __forceinline__ float row16_butterfly(float s) {
+#pragma unroll
+  for (int m = 1; m < 16; m <<= 1) s = s + __shfl_xor(s, m, 16);
+  return s;
+}
+
+__global__ __launch_bounds__(256) void key_sumsq_kernel(const uint4* __restrict__ k, int64_t head_stride16, int64_t row0,
+                                                        int64_t n, int hkv, float* __restrict__ head_sumsq) {
+  const int c = threadIdx.x & 15;
+  const int64_t rows = n * hkv;
+  for (int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4); r < rows; r += (int64_t)gridDim.x * 16) {
+    const int64_t h = r / n, t = r - h * n;
+    uint4 v = k[h * head_stride16 + (row0 + t) * 16 + c];
+    float s = row16_butterfly(chunk_sumsq(v));
+    if (c == 0) head_sumsq[h * n + t] = s;
+  }
+}
+
+int qp_launch_key_sumsq(const void* k, int64_t head_stride, int64_t row0, int64_t n, int hkv, float* head_sumsq,
+                        hipStream_t s) {
+  int64_t rows = n * hkv;
+  int grid = (int)((rows + 15) / 16 < 4096 ? (rows + 15) / 16 : 4096);
+  if (grid < 1) grid = 1;
+  key_sumsq_kernel<<<grid, 256, 0, s>>>((const uint4*)k, head_stride / 8, row0, n, hkv, head_sumsq);
+  return qp_check_launch("key_sumsq");
+}
+
+// ------------------------------------------------------------------------------------------------
+// K5: k-smallest select on bf16 norms, ties -> lowest index, ascending index list out.
+//   One 1024-thread workgroup (n <= 65536): norms (16-bit patterns) live in LDS;
+//   two 256-bin histogram passes find the threshold pattern tau, then an ordered two-scan compaction
+//   emits  {t : key<tau}  U  {first r ties of key==tau}.  No host round trip (the reference does
+//   .tolist() + torch.tensor + nonzero().cpu(): utils.py:136,191,284).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned block_excl_scan_1024(unsigned v, unsigned* wave_tot, unsigned* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    unsigned t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  if (wave == 0) {
+    unsigned w = lane < 16 ? wave_tot[lane] : 0u, wi = w;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) {
+      unsigned t = __shfl_up(wi, o, 64);
+      if (lane >= o) wi += t;
+    }
+    if (lane < 16) wave_tot[lane] = wi - w;   // exclusive wave offsets
+    if (lane == 15) *total = wi;
+  }
+  __syncthreads();
+  unsigned r = wave_tot[wave] + incl - v;
+  __syncthreads();
+  return r;
+}
+
+// finds bucket b with cum_before(b) < kk <= cum_before(b)+hist[b]; result in res[0]=b, res[1]=cum_before(b)
+__device__ __forceinline__ void find_bucket_256(unsigned* hist, unsigned* scan, unsigned kk, unsigned* res) {
+  const int t = threadIdx.x;
+  if (t < 256) scan[t] = hist[t];
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    unsigned a = 0;
+    if (t < 256 && t >= o) a = scan[t - o];
+    __syncthreads();
+    if (t < 256) scan[t] += a;
+    __syncthreads();
+  }
+  if (t < 256) {
+    unsigned incl = scan[t], before = incl - hist[t];
+    if (before < kk && kk <= incl) { res[0] = (unsigned)t; res[1] = before; }
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void select_kernel(const float* __restrict__ head_sumsq, int n_heads, int n, int k,
+                                                      int32_t* __restrict__ kept, uint16_t* __restrict__ norm_bits_out) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned* hist = (unsigned*)smem;            // 256
+  unsigned* scan = hist + 256;                 // 256
+  unsigned* wave_tot = scan + 256;             // 16
+  unsigned* res = wave_tot + 16;               // 4
+  unsigned* tot = res + 4;                     // 4
+  uint16_t* keys = (uint16_t*)(tot + 4);       // n
+  const int tid = threadIdx.x;
+
+  for (int t = tid; t < n; t += 1024) {
+    float s = head_sumsq[t];
+    for (int h = 1; h < n_heads; ++h) s = s + head_sumsq[(int64_t)h * n + t];
+    uint16_t b = f32_to_bf16_bits(__fsqrt_rn(s));
+    keys[t] = b;
+    if (norm_bits_out) norm_bits_out[t] = b;
+  }
+  if (tid < 256) hist[tid] = 0;
+  __syncthreads();
+  for (int t = tid; t < n; t += 1024) atomicAdd(&hist[keys[t] >> 8], 1u);
+  __syncthreads();
+  find_bucket_256(hist, scan, (unsigned)k, res);
+  const unsigned b1 = res[0], c1 = res[1];
+  __syncthreads();
+  if (tid < 256) hist[tid] = 0;
+  __syncthreads();
+  for (int t = tid; t < n; t += 1024) { unsigned key = keys[t]; if ((key >> 8) == b1) atomicAdd(&hist[key & 255u], 1u); }
+  __syncthreads();
+  find_bucket_256(hist, scan, (unsigned)k - c1, res);
+  const unsigned tau = (b1 << 8) | res[0];
+  const unsigned n_less = c1 + res[1];
+  const unsigned r_ties = (unsigned)k - n_less;      // >= 1 ties (key == tau) to take, lowest index first
+  __syncthreads();
+
+  const int chunk = (n + 1023) / 1024;
+  const int t0 = tid * chunk, t1 = min(n, t0 + chunk);
+  unsigned lt = 0, eq = 0;
+  for (int t = t0; t < t1; ++t) { unsigned key = keys[t]; lt += key < tau; eq += key == tau; }
+  const unsigned eq_before = block_excl_scan_1024(eq, wave_tot, tot);
+  unsigned take = 0;
+  if (eq_before < r_ties) take = min(eq, r_ties - eq_before);
+  const unsigned pos0 = block_excl_scan_1024(lt + take, wave_tot, tot);
+  unsigned pos = pos0, taken = 0;
+  for (int t = t0; t < t1; ++t) {
+    unsigned key = keys[t];
+    bool keep = key < tau;
+    if (key == tau && taken < take) { keep = true; ++taken; }
+    if (keep) kept[pos++] = t;
+  }
+}
+
+static size_t select_smem_bytes(int64_t n) { return (256 + 256 + 16 + 4 + 4) * 4 + (size_t)((n + 7) / 8 * 8) * 2; }
+
+int qp_launch_select(const float* head_sumsq, int n_heads, int64_t n, int64_t k, int32_t* kept, uint16_t* norm_bits,
+                     void* ws, hipStream_t s) {
+  (void)ws;
+  size_t smem = select_smem_bytes(n);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+    if (e != hipSuccess) return qp_fail(QP_ERR_HIP, "hipFuncSetAttribute(select): %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  select_kernel<<<1, 1024, smem, s>>>(head_sumsq, n_heads, (int)n, (int)k, kept, norm_bits);
+  return qp_check_launch("select");
+}
+
+// ------------------------------------------------------------------------------------------------
+// K6: gather kept rows (staging or arena tail -> arena), K and V in one launch.
+//   256-B rows, 16 lanes x 16 B per row, 4 independent rows in flight per thread.
+// ------------------------------------------------------------------------------------------------
+template <bool kIndexed>
+__global__ __launch_bounds__(256) void gather_kv_kernel(const uint4* __restrict__ k_src, const uint4* __restrict__ v_src,
+                                                        int64_t src_hs16, const int32_t* __restrict__ idx, int64_t k,
+                                                        int hkv, uint4* __restrict__ k_dst, uint4* __restrict__ v_dst,
+                                                        int64_t dst_hs16, int64_t dst_row0) {
+  const int c = threadIdx.x & 15;
+  const int64_t rows = 2 * (int64_t)hkv * k;          // (kv, head, j)
+  const int64_t stride = (int64_t)gridDim.x * 16;
+  int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  for (; r < rows; r += 4 * stride) {
+    uint4 v[4];
+    int64_t dsto[4];
+    bool ok[4], isv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      int64_t rr = r + u * stride;
+      ok[u] = rr < rows;
+      if (!ok[u]) rr = rows - 1;
+      int64_t j = rr % k, hh = (rr / k) % hkv;
+      isv[u] = rr >= (int64_t)hkv * k;
+      int64_t srow = kIndexed ? (int64_t)idx[j] : j;
+      const uint4* src = isv[u] ? v_src : k_src;
+      v[u] = src[hh * src_hs16 + srow * 16 + c];
+      dsto[u] = hh * dst_hs16 + (dst_row0 + j) * 16 + c;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (ok[u]) (isv[u] ? v_dst : k_dst)[dsto[u]] = v[u];
+  }
+}
+
+static int gather_grid(int64_t rows) {
+  int64_t blocks = (rows + 63) / 64;   // 16 rows per block pass x 4 unrolled
+  if (blocks > 2048) blocks = 2048;
+  if (blocks < 1) blocks = 1;
+  return (int)blocks;
+}
+
+int qp_launch_gather_kv(const void* k_src, const void* v_src, int64_t src_head_stride, const int32_t* idx, int64_t k,
+                        int hkv, void* k_dst, void* v_dst, int64_t dst_head_stride, int64_t dst_row0, hipStream_t s) {
+  gather_kv_kernel<true><<<gather_grid(2 * hkv * k), 256, 0, s>>>((const uint4*)k_src, (const uint4*)v_src, src_head_stride / 8,
+                                                                   idx, k, hkv, (uint4*)k_dst, (uint4*)v_dst,
+                                                                   dst_head_stride / 8, dst_row0);
+  return qp_check_launch("gather_kv");
+}
+
+int qp_launch_copy_rows_kv(const void* k_src, const void* v_src, int64_t src_head_stride, int64_t k, int hkv, void* k_dst,
+                           void* v_dst, int64_t dst_head_stride, int64_t dst_row0, hipStream_t s) {
+  gather_kv_kernel<false><<<gather_grid(2 * hkv * k), 256, 0, s>>>((const uint4*)k_src, (const uint4*)v_src, src_head_stride / 8,
+                                                                    nullptr, k, hkv, (uint4*)k_dst, (uint4*)v_dst,
+                                                                    dst_head_stride / 8, dst_row0);
+  return qp_check_launch("copy_rows_kv");
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const uint4* __restrict__ src, const int32_t* __restrict__ idx, int64_t k,
+                                                          int64_t row16, uint4* __restrict__ dst) {
+  const int64_t total = k * row16;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    int64_t j = i / row16, c = i - j * row16;
+    dst[i] = src[(int64_t)idx[j] * row16 + c];
+  }
+}
+
+int qp_launch_gather_rows(const void* src, const int32_t* idx, int64_t k, int64_t row_bytes, void* dst, hipStream_t s) {
+  int64_t total = k * (row_bytes / 16);
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  gather_rows_kernel<<<(int)blocks, 256, 0, s>>>((const uint4*)src, idx, k, row_bytes / 16, (uint4*)dst);
+  return qp_check_launch("gather_rows");
+}

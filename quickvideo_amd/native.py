@@ -1,0 +1,173 @@
+"""ctypes binding of libquickprefill.so (include/quickprefill.h) for torch tensors.
+
+PyTorch is plumbing here: it owns device memory and the current HIP stream; every operator of the hot
+path is a hand-written gfx950 kernel behind the C ABI.  There is NO fallback: if the library is
+missing, or no MI355X is visible, importing the ops fails loudly (``QuickPrefillUnavailable``).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libquickprefill.so")
+
+QP_OK, QP_ERR_INVALID, QP_ERR_UNSUPPORTED, QP_ERR_HIP, QP_ERR_WORKSPACE = 0, -1, -2, -3, -4
+
+
+class QuickPrefillUnavailable(RuntimeError):
+    pass
+
+
+class QuickPrefillError(RuntimeError):
+    def __init__(self, status: int, msg: str):
+        super().__init__(f"libquickprefill status {status}: {msg}")
+        self.status = status
+
+
+_c = ctypes
+_vp, _i64, _i32, _f32, _sz = _c.c_void_p, _c.c_int64, _c.c_int, _c.c_float, _c.c_size_t
+
+# name -> (restype, argtypes): exactly the declarations of include/quickprefill.h
+SIGNATURES = {
+    "qp_create": (_i32, [_c.POINTER(_vp), _i32]),
+    "qp_destroy": (None, [_vp]),
+    "qp_last_error": (_c.c_char_p, []),
+    "qp_version": (_c.c_char_p, []),
+    "qp_device_cus": (_i32, [_vp]),
+    "qp_mrope_table": (_i32, [_vp, _vp, _i64, _c.POINTER(_c.c_int32), _f32, _i32, _vp, _vp, _vp]),
+    "qp_rope_append": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _vp, _vp]),
+    "qp_prefill_attn": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _f32, _vp, _vp]),
+    "qp_key_sumsq": (_i32, [_vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _vp]),
+    "qp_select_workspace_bytes": (_sz, [_i64]),
+    "qp_select_k_smallest": (_i32, [_vp, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "qp_gather_kv": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _i64, _vp]),
+    "qp_prune_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32]),
+    "qp_prune_tail": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _vp, _vp, _sz, _vp]),
+    "qp_gather_rows": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _vp]),
+    "qp_add_rmsnorm": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
+    "qp_add_inplace": (_i32, [_vp, _vp, _vp, _i64, _vp]),
+    "qp_swiglu": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp]),
+}
+
+
+def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
+    """dlopen the C-ABI library and bind every symbol the header declares (no compute, no GPU needed)."""
+    if not os.path.exists(path):
+        raise QuickPrefillUnavailable(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"(or `make -C quickvideo_amd/csrc`). There is no CPU fallback for the QuickPrefill hot path.")
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)            # AttributeError if the .so does not export a declared symbol
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+class QuickPrefillOps:
+    """Stream-ordered operators on torch CUDA(HIP) tensors.  One instance per device."""
+
+    def __init__(self, device: Optional[torch.device] = None):
+        if not torch.cuda.is_available():
+            raise QuickPrefillUnavailable("no HIP device visible to torch: the QuickPrefill engine needs an MI355X (gfx950); "
+                                          "there is no CPU fallback")
+        self.lib = load_library()
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        h = _vp()
+        self._check(self.lib.qp_create(ctypes.byref(h), self.device.index or 0))
+        self.ctx = h
+        self._select_ws = torch.empty(int(self.lib.qp_select_workspace_bytes(65536)), dtype=torch.uint8, device=self.device)
+
+    def __del__(self):
+        try:
+            if getattr(self, "ctx", None):
+                self.lib.qp_destroy(self.ctx)
+        except Exception:
+            pass
+
+    # -- helpers
+    def _check(self, status: int):
+        if status != QP_OK:
+            msg = self.lib.qp_last_error().decode()
+            if status == QP_ERR_INVALID:
+                raise ValueError(f"libquickprefill: {msg}")
+            raise QuickPrefillError(status, msg)
+
+    @staticmethod
+    def _stream():
+        return torch.cuda.current_stream().cuda_stream
+
+    @property
+    def cus(self) -> int:
+        return int(self.lib.qp_device_cus(self.ctx))
+
+    # -- seam 2
+    def mrope_table(self, pos: torch.Tensor, sections, theta: float, head_dim: int):
+        """pos int64 [3, n] (device) -> cos, sin bf16 [n, head_dim//2]."""
+        assert pos.dtype == torch.int64 and pos.dim() == 2 and pos.shape[0] == 3 and pos.is_contiguous()
+        n = pos.shape[1]
+        cos = torch.empty(n, head_dim // 2, dtype=torch.bfloat16, device=pos.device)
+        sin = torch.empty_like(cos)
+        sec = (ctypes.c_int32 * 3)(*sections)
+        self._check(self.lib.qp_mrope_table(self.ctx, pos.data_ptr(), n, sec, float(theta), head_dim, cos.data_ptr(),
+                                            sin.data_ptr(), self._stream()))
+        return cos, sin
+
+    def rope_append(self, qkv, cos, sin, n_q, n_kv, head_dim, q_out, k_dst, v_dst, dst_head_stride, dst_row0, head_sumsq):
+        n = qkv.shape[0]
+        self._check(self.lib.qp_rope_append(self.ctx, qkv.data_ptr(), cos.data_ptr(), sin.data_ptr(), n, n_q, n_kv, head_dim,
+                                            q_out.data_ptr(), k_dst.data_ptr(), v_dst.data_ptr(), dst_head_stride, dst_row0,
+                                            _ptr(head_sumsq), self._stream()))
+
+    # -- seam 3
+    def prefill_attn(self, q, k_prefix, v_prefix, prefix_head_stride, prefix_len, k_new, v_new, new_head_stride, n, n_q, n_kv,
+                     head_dim, scale, out):
+        self._check(self.lib.qp_prefill_attn(self.ctx, q.data_ptr(), _ptr(k_prefix), _ptr(v_prefix), prefix_head_stride,
+                                             prefix_len, k_new.data_ptr(), v_new.data_ptr(), new_head_stride, n, n_q, n_kv,
+                                             head_dim, float(scale), out.data_ptr(), self._stream()))
+
+    # -- seam 1
+    def key_sumsq(self, k, head_stride, row0, n, n_kv, head_dim, head_sumsq):
+        self._check(self.lib.qp_key_sumsq(self.ctx, k.data_ptr(), head_stride, row0, n, n_kv, head_dim, head_sumsq.data_ptr(),
+                                          self._stream()))
+
+    def select_k_smallest(self, head_sumsq, n_heads_total, n, k, kept_idx, norm_bits=None):
+        self._check(self.lib.qp_select_k_smallest(self.ctx, head_sumsq.data_ptr(), n_heads_total, n, k, kept_idx.data_ptr(),
+                                                  _ptr(norm_bits), self._select_ws.data_ptr(), self._select_ws.numel(),
+                                                  self._stream()))
+
+    def gather_kv(self, k_src, v_src, src_head_stride, idx, k, n_kv, head_dim, k_dst, v_dst, dst_head_stride, dst_row0):
+        self._check(self.lib.qp_gather_kv(self.ctx, k_src.data_ptr(), v_src.data_ptr(), src_head_stride, idx.data_ptr(), k, n_kv,
+                                          head_dim, k_dst.data_ptr(), v_dst.data_ptr(), dst_head_stride, dst_row0,
+                                          self._stream()))
+
+    def prune_workspace_bytes(self, n, k, n_kv, head_dim) -> int:
+        return int(self.lib.qp_prune_workspace_bytes(n, k, n_kv, head_dim))
+
+    def prune_tail(self, k_cache, v_cache, head_stride, past_len, n, k, n_kv, head_dim, kept_idx, workspace):
+        self._check(self.lib.qp_prune_tail(self.ctx, k_cache.data_ptr(), v_cache.data_ptr(), head_stride, past_len, n, k, n_kv,
+                                           head_dim, kept_idx.data_ptr(), workspace.data_ptr(), workspace.numel() * workspace.element_size(),
+                                           self._stream()))
+
+    def gather_rows(self, src, idx, k, row_bytes, dst):
+        self._check(self.lib.qp_gather_rows(self.ctx, src.data_ptr(), idx.data_ptr(), k, row_bytes, dst.data_ptr(), self._stream()))
+
+    # -- glue
+    def add_rmsnorm(self, h, delta, w, out, eps):
+        n, hidden = h.shape
+        self._check(self.lib.qp_add_rmsnorm(self.ctx, h.data_ptr(), _ptr(delta), w.data_ptr(), out.data_ptr(), n, hidden, float(eps),
+                                            self._stream()))
+
+    def add_inplace(self, h, delta):
+        self._check(self.lib.qp_add_inplace(self.ctx, h.data_ptr(), delta.data_ptr(), h.numel(), self._stream()))
+
+    def swiglu(self, gate_up, out):
+        n, two_i = gate_up.shape
+        self._check(self.lib.qp_swiglu(self.ctx, gate_up.data_ptr(), n, two_i // 2, out.data_ptr(), self._stream()))

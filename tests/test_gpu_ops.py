@@ -1,0 +1,264 @@
+"""GPU parity tests: every operator behind the C ABI (libquickprefill.so via ctypes) vs the CPU oracle on the
+same seeded inputs.  Integer / byte results are bit-exact; floating-point results carry a stated tolerance."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import qp_oracle as O
+from oracle.make_golden import COMPACT_CASES, SELECT_CASES, make_keys
+
+pytestmark = pytest.mark.gpu
+
+D = 128
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from quickvideo_amd.native import QuickPrefillOps
+    return QuickPrefillOps(torch.device("cuda:0"))
+
+
+def sha(*arrays):
+    h = hashlib.sha256()
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()
+
+
+def dev_bits(t):
+    return O.torch_bf16_to_bits(t.cpu())
+
+
+def gpu_select(ops, keys_bf16, k):
+    """keys_bf16: torch bf16 [Hkv, n, D] (cpu). Returns (idx, norm_bits, head_sumsq) from the HIP path."""
+    hkv, n, _ = keys_bf16.shape
+    kd = keys_bf16.cuda().contiguous()
+    ss = torch.empty(hkv, n, dtype=torch.float32, device="cuda")
+    ops.key_sumsq(kd, n * D, 0, n, hkv, D, ss)
+    idx = torch.full((k,), -1, dtype=torch.int32, device="cuda")
+    nb = torch.zeros(n, dtype=torch.int16, device="cuda")
+    ops.select_k_smallest(ss, hkv, n, k, idx, nb)
+    torch.cuda.synchronize()
+    return idx.cpu().numpy(), nb.cpu().numpy().view(np.uint16), ss.cpu().numpy()
+
+
+@pytest.mark.parametrize("ci", range(len(SELECT_CASES)))
+def test_sumsq_select_bit_exact(ops, golden_dir, ci):
+    data = np.load(os.path.join(golden_dir, "gv1_select.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "gv1_select.json")))[ci]
+    dist, hkv, n, k = SELECT_CASES[ci]
+    keys = make_keys(dist, hkv, n, meta["seed"])[0]
+    idx, nb, ss = gpu_select(ops, keys, k)
+    bits = O.torch_bf16_to_bits(keys)
+    ss_ref = O.key_sumsq_heads(bits)
+    assert np.array_equal(ss.view(np.uint32), ss_ref.view(np.uint32)), "per-head fp32 sums must be bit-identical"
+    nb_ref = O.key_norms_bf16(ss_ref)
+    assert np.array_equal(nb, nb_ref)
+    assert np.array_equal(idx, O.select_k_smallest(nb_ref, k))
+    if meta["norm_rows_differ"] == 0:     # same norms as the reference -> same kept set as the reference (stable sort)
+        assert np.array_equal(idx, data[f"c{ci}_ref_idx_stable"])
+
+
+@pytest.mark.parametrize("n,k,hkv", [(1, 1, 4), (2, 1, 2), (64, 64, 4), (1025, 1, 4), (5775, 2887, 4), (65536, 32768, 1), (40000, 39999, 2)])
+def test_select_edge_sizes(ops, n, k, hkv):
+    rs = np.random.RandomState(n + k)
+    keys = torch.from_numpy(rs.standard_normal((hkv, n, D)).astype(np.float32)).to(torch.bfloat16)
+    idx, nb, _ = gpu_select(ops, keys, k)
+    nb_ref = O.key_norms_bf16(O.key_sumsq_heads(O.torch_bf16_to_bits(keys)))
+    assert np.array_equal(nb, nb_ref) and np.array_equal(idx, O.select_k_smallest(nb_ref, k))
+
+
+def test_select_special_values(ops):
+    n, hkv = 300, 4
+    keys = torch.zeros(hkv, n, D, dtype=torch.bfloat16)
+    keys[0, 10:20, 0] = float("inf"); keys[1, 30, 5] = float("nan"); keys[:, 50:60] = 3.0e38   # overflow -> inf norm
+    keys[2, 100:, 3] = 1.0
+    idx, nb, _ = gpu_select(ops, keys, 150)
+    nb_ref = O.key_norms_bf16(O.key_sumsq_heads(O.torch_bf16_to_bits(keys)))
+    assert np.array_equal(nb, nb_ref) and np.array_equal(idx, O.select_k_smallest(nb_ref, 150))
+
+
+@pytest.mark.parametrize("ci", range(len(COMPACT_CASES)))
+def test_prune_tail_inplace_and_staged(ops, golden_dir, ci):
+    meta = json.load(open(os.path.join(golden_dir, "gv2_compaction.json")))[ci]
+    past, n, k, hkv = COMPACT_CASES[ci]
+    rs = np.random.RandomState(meta["seed"])
+    keys = torch.from_numpy(rs.standard_normal((1, hkv, past + n, D)).astype(np.float32)).to(torch.bfloat16)[0]
+    vals = torch.from_numpy(rs.standard_normal((1, hkv, past + n, D)).astype(np.float32)).to(torch.bfloat16)[0]
+    cap = past + n + 37
+    # (a) in-place drop-in seam on the arena
+    kc = torch.zeros(hkv, cap, D, dtype=torch.bfloat16, device="cuda"); vc = torch.zeros_like(kc)
+    kc[:, :past + n] = keys.cuda(); vc[:, :past + n] = vals.cuda()
+    idx = torch.empty(k, dtype=torch.int32, device="cuda")
+    ws = torch.empty(ops.prune_workspace_bytes(n, k, hkv, D), dtype=torch.uint8, device="cuda")
+    ops.prune_tail(kc, vc, cap * D, past, n, k, hkv, D, idx, ws)
+    torch.cuda.synchronize()
+    ko, vo = O.torch_bf16_to_bits(keys).copy(), O.torch_bf16_to_bits(vals).copy()
+    ref_idx, _ = O.prune_tail(ko, vo, past, n, k)
+    assert np.array_equal(idx.cpu().numpy(), ref_idx)
+    assert np.array_equal(dev_bits(kc[:, :past + k]), ko[:, :past + k]) and np.array_equal(dev_bits(vc[:, :past + k]), vo[:, :past + k])
+    assert sha(dev_bits(kc[:, :past + k])) == meta["k_sha"] and sha(dev_bits(vc[:, :past + k])) == meta["v_sha"]   # == the reference's output
+    # (b) engine path: new rows in a staging block, gather into the arena
+    kc2 = torch.zeros(hkv, cap, D, dtype=torch.bfloat16, device="cuda"); vc2 = torch.zeros_like(kc2)
+    kc2[:, :past] = keys[:, :past].cuda(); vc2[:, :past] = vals[:, :past].cuda()
+    ks = keys[:, past:].contiguous().cuda(); vs = vals[:, past:].contiguous().cuda()
+    ss = torch.empty(hkv, n, dtype=torch.float32, device="cuda")
+    ops.key_sumsq(ks, n * D, 0, n, hkv, D, ss)
+    idx2 = torch.empty(k, dtype=torch.int32, device="cuda")
+    ops.select_k_smallest(ss, hkv, n, k, idx2)
+    ops.gather_kv(ks, vs, n * D, idx2, k, hkv, D, kc2, vc2, cap * D, past)
+    torch.cuda.synchronize()
+    assert sha(dev_bits(kc2[:, :past + k])) == meta["k_sha"] and sha(dev_bits(vc2[:, :past + k])) == meta["v_sha"]
+    assert torch.count_nonzero(kc2[:, past + k:]).item() == 0      # nothing written past the kept rows
+    # hidden-state pruning hand-off uses the same index list (utils.py:292-331)
+    hid = torch.from_numpy(rs.standard_normal((1, n, 16)).astype(np.float32))[0]
+    out = torch.empty(k, 16, dtype=torch.float32, device="cuda")
+    ops.gather_rows(hid.cuda(), idx2, k, 64, out)
+    assert sha(out.cpu().numpy()[None]) == meta["hidden_sha"]
+
+
+@pytest.mark.parametrize("n,hq,hkv,row0", [(1, 2, 1, 0), (77, 28, 4, 13), (960, 8, 1, 0), (5775, 28, 4, 2887), (300, 12, 2, 5)])
+def test_rope_append_bit_exact(ops, n, hq, hkv, row0):
+    rs = np.random.RandomState(n * 7 + hq)
+    spec = O.TextSpec(hidden=hq * D, n_heads=hq, n_kv_heads=hkv, head_dim=D, intermediate=8, n_layers=1, vocab=8)
+    qkv = torch.from_numpy(rs.standard_normal((n, (hq + 2 * hkv) * D)).astype(np.float32) * 2).to(torch.bfloat16)
+    pos = np.stack([rs.randint(0, 4000, n), rs.randint(0, 60, n), rs.randint(0, 80, n)]).astype(np.int64)
+    cos, sin = O.mrope_cos_sin(torch.from_numpy(pos), spec, torch.bfloat16)           # [n, D] oracle tables
+    q = qkv[:, :hq * D].view(n, hq, D).transpose(0, 1)
+    k = qkv[:, hq * D:(hq + hkv) * D].view(n, hkv, D).transpose(0, 1)
+    v = qkv[:, (hq + hkv) * D:].view(n, hkv, D).transpose(0, 1)
+    q_ref, k_ref = O.apply_rope(q, cos, sin), O.apply_rope(k, cos, sin)
+    cap = row0 + n + 3
+    kc = torch.zeros(hkv, cap, D, dtype=torch.bfloat16, device="cuda"); vc = torch.zeros_like(kc)
+    q_out = torch.empty(n, hq, D, dtype=torch.bfloat16, device="cuda")
+    ss = torch.empty(hkv, n, dtype=torch.float32, device="cuda")
+    ops.rope_append(qkv.cuda(), cos[:, :D // 2].contiguous().cuda(), sin[:, :D // 2].contiguous().cuda(), hq, hkv, D, q_out, kc, vc,
+                    cap * D, row0, ss)
+    torch.cuda.synchronize()
+    assert np.array_equal(dev_bits(q_out.transpose(0, 1).contiguous()), O.torch_bf16_to_bits(q_ref.contiguous()))
+    assert np.array_equal(dev_bits(kc[:, row0:row0 + n]), O.torch_bf16_to_bits(k_ref.contiguous()))
+    assert np.array_equal(dev_bits(vc[:, row0:row0 + n]), O.torch_bf16_to_bits(v.contiguous()))
+    ss_ref = O.key_sumsq_heads(O.torch_bf16_to_bits(k_ref.contiguous()))
+    assert np.array_equal(ss.cpu().numpy().view(np.uint32), ss_ref.view(np.uint32))
+    assert torch.count_nonzero(kc[:, :row0]).item() == 0 and torch.count_nonzero(kc[:, row0 + n:]).item() == 0
+
+
+def test_mrope_table(ops):
+    spec = O.TextSpec(hidden=256, n_heads=2, n_kv_heads=1, head_dim=D, intermediate=8, n_layers=1, vocab=8)
+    pos, _ = O.mrope_positions(15, (32, 40, 72), 30)
+    pos = pos[:, :4000]
+    cos_ref, sin_ref = O.mrope_cos_sin(torch.from_numpy(pos), spec, torch.bfloat16)
+    cos, sin = ops.mrope_table(torch.from_numpy(pos).cuda(), spec.mrope_section, spec.rope_theta, D)
+    torch.cuda.synchronize()
+    for got, ref in ((cos, cos_ref), (sin, sin_ref)):
+        g, r = got.float().cpu(), ref[:, :D // 2].float()
+        # device cosf/sinf/powf vs torch CPU: angles up to ~4e3 rad in fp32 -> allow a few bf16 ulps near zero crossings
+        assert torch.max(torch.abs(g - r)).item() <= 2e-2 and (g != r).float().mean().item() < 0.02
+
+
+def attn_case(ops, n, P, hq, hkv, staged, seed, scale=None, spike=False):
+    rs = np.random.RandomState(seed)
+    q = torch.from_numpy(rs.standard_normal((n, hq, D)).astype(np.float32)).to(torch.bfloat16)
+    k = torch.from_numpy(rs.standard_normal((hkv, P + n, D)).astype(np.float32)).to(torch.bfloat16)
+    v = torch.from_numpy(rs.standard_normal((hkv, P + n, D)).astype(np.float32)).to(torch.bfloat16)
+    if spike:   # force online-softmax rescales: a few keys with huge scores late in the sequence
+        k[:, P + n // 2] = q[n // 2, 0] * 4
+        k[:, max(P - 3, 0)] = q[min(5, n - 1), hq - 1] * 3
+    scale = D ** -0.5 if scale is None else scale
+    ref = O.attention_bottom_right(q.transpose(0, 1), k, v, scale).float()
+    cap = P + n + 11
+    kc = torch.full((hkv, cap, D), float("nan"), dtype=torch.bfloat16, device="cuda"); vc = torch.full_like(kc, float("nan"))
+    kc[:, :P] = k[:, :P].cuda(); vc[:, :P] = v[:, :P].cuda()
+    out = torch.empty(n, hq, D, dtype=torch.bfloat16, device="cuda")
+    if staged:
+        kn, vn = k[:, P:].contiguous().cuda(), v[:, P:].contiguous().cuda()
+        ops.prefill_attn(q.cuda(), kc, vc, cap * D, P, kn, vn, n * D, n, hq, hkv, D, scale, out)
+    else:
+        kc[:, P:P + n] = k[:, P:].cuda(); vc[:, P:P + n] = v[:, P:].cuda()
+        ops.prefill_attn(q.cuda(), kc, vc, cap * D, P, kc[:, P:], vc[:, P:], cap * D, n, hq, hkv, D, scale, out)
+    torch.cuda.synchronize()
+    got = out.float().cpu()
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs()
+    # tolerance (bf16 P and bf16 output, fp32 accumulate): |err| <= 1.5e-2 + 1.5e-2*|ref|
+    assert (err <= 1.5e-2 + 1.5e-2 * ref.abs()).all(), (err.max().item(), n, P)
+    assert err.mean().item() < 2e-3
+    return got
+
+
+@pytest.mark.parametrize("n,P,hq,hkv,staged", [
+    (1, 0, 2, 1, True), (1, 77, 2, 1, False), (15, 0, 4, 2, True), (64, 64, 2, 1, True), (128, 0, 2, 1, False),
+    (129, 63, 7, 1, True), (200, 300, 8, 4, False), (333, 1000, 6, 1, True), (512, 0, 12, 2, False), (257, 129, 28, 4, True),
+])
+def test_prefill_attn_small(ops, n, P, hq, hkv, staged):
+    attn_case(ops, n, P, hq, hkv, staged, seed=n * 31 + P)
+
+
+def test_prefill_attn_rescale_branch(ops):
+    attn_case(ops, 300, 500, 4, 2, True, seed=5, spike=True)
+    attn_case(ops, 192, 0, 2, 1, False, seed=6, spike=True, scale=0.5)
+
+
+def test_prefill_attn_transpose_detecting(ops):
+    """Asymmetric probe (cdna guide rule 16): q = e_a rows, k/v structured so a swapped layout cannot pass."""
+    n, P, hq, hkv = 96, 40, 2, 1
+    q = torch.zeros(n, hq, D); k = torch.zeros(hkv, P + n, D); v = torch.zeros(hkv, P + n, D)
+    for i in range(n):
+        q[i, 0, i % D] = 6.0; q[i, 1, (3 * i + 1) % D] = 5.0
+    for j in range(P + n):
+        k[0, j, (5 * j + 2) % D] = 4.0; k[0, j, j % D] += 2.0
+        v[0, j] = torch.arange(D) * 0.01 + j * 0.1
+    q, k, v = q.to(torch.bfloat16), k.to(torch.bfloat16), v.to(torch.bfloat16)
+    ref = O.attention_bottom_right(q.transpose(0, 1), k, v, D ** -0.5).float()
+    out = torch.empty(n, hq, D, dtype=torch.bfloat16, device="cuda")
+    kc, vc = k.cuda(), v.cuda()
+    ops.prefill_attn(q.cuda(), kc, vc, (P + n) * D, P, kc[:, P:], vc[:, P:], (P + n) * D, n, hq, hkv, D, D ** -0.5, out)
+    torch.cuda.synchronize()
+    err = (out.float().cpu() - ref).abs()
+    assert (err <= 3e-2 + 1.5e-2 * ref.abs()).all(), err.max().item()
+
+
+def test_glue_kernels(ops):
+    rs = np.random.RandomState(3)
+    for n, hidden, inter in ((5, 256, 512), (33, 3584, 18944), (2, 8192, 29568)):
+        h = torch.from_numpy(rs.standard_normal((n, hidden)).astype(np.float32)).to(torch.bfloat16)
+        d = torch.from_numpy(rs.standard_normal((n, hidden)).astype(np.float32) * 0.3).to(torch.bfloat16)
+        w = torch.from_numpy(1 + 0.1 * rs.standard_normal(hidden).astype(np.float32)).to(torch.bfloat16)
+        h2 = h + d
+        ref = O.rmsnorm(h2, w, 1e-6)
+        hd, out = h.cuda(), torch.empty(n, hidden, dtype=torch.bfloat16, device="cuda")
+        ops.add_rmsnorm(hd, d.cuda(), w.cuda(), out, 1e-6)
+        assert np.array_equal(dev_bits(hd), O.torch_bf16_to_bits(h2))                   # residual add: bit-exact
+        # RMSNorm: fp32 mean order differs from torch -> at most 1 bf16 ulp on the normalised value (rel 2^-7) twice
+        assert torch.allclose(out.float().cpu(), ref.float(), rtol=1.6e-2, atol=1e-3)
+        out2 = torch.empty_like(out)
+        ops.add_rmsnorm(hd, None, w.cuda(), out2, 1e-6)
+        assert torch.equal(out2, out)
+        gu = torch.from_numpy(rs.standard_normal((n, 2 * inter)).astype(np.float32) * 2).to(torch.bfloat16)
+        ref = torch.nn.functional.silu(gu[:, :inter]) * gu[:, inter:]
+        so = torch.empty(n, inter, dtype=torch.bfloat16, device="cuda")
+        ops.swiglu(gu.cuda(), so)
+        assert torch.allclose(so.float().cpu(), ref.float(), rtol=1.6e-2, atol=1e-3)
+        hd2 = h.cuda(); ops.add_inplace(hd2, d.cuda())
+        assert np.array_equal(dev_bits(hd2), O.torch_bf16_to_bits(h2))
+
+
+def test_error_behaviour(ops):
+    """C status -> Python exception mapping: invalid arguments raise ValueError before any launch."""
+    from quickvideo_amd.native import QuickPrefillError
+    ss = torch.zeros(4, 10, dtype=torch.float32, device="cuda"); idx = torch.zeros(10, dtype=torch.int32, device="cuda")
+    with pytest.raises(ValueError):
+        ops.select_k_smallest(ss, 4, 10, 0, idx)           # k must be > 0  (reference: "no prune" handled by the caller)
+    with pytest.raises(ValueError):
+        ops.select_k_smallest(ss, 4, 10, 11, idx)          # k > n
+    with pytest.raises(QuickPrefillError):
+        ops.select_k_smallest(ss, 4, 70000, 5, idx)        # unsupported size
+    q = torch.zeros(4, 3, D, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(ValueError):
+        ops.prefill_attn(q, None, None, 0, 0, q, q, 4 * D, 4, 3, 2, D, 1.0, q)     # 3 q heads over 2 kv heads
+    with pytest.raises(QuickPrefillError):
+        ops.prefill_attn(q, None, None, 0, 0, q, q, 4 * 64, 4, 2, 1, 64, 1.0, q)   # head_dim 64 unsupported
