@@ -1,0 +1,209 @@
+"""QuickPrefill engine: group-chunked prefill with per-group key-norm KV pruning on one MI355X
+(or one tensor-parallel rank).
+
+Mirrors, per group, the reference's patched decoder layer (lvu/models/qwen25_lvu.py:122-212) and attention
+(:29-120) with the pruning hook of lvu/utils.py:197-376 — but laid out for the hardware:
+
+  * one pre-allocated KV arena [L][2][Hkv][capacity][D] bf16 for the whole video (the reference re-allocates
+    and copies the whole past twice per layer per group: torch.cat in cache.update and in utils.py:335-336);
+  * the group's new K/V are written by the fused RoPE kernel into a small staging block, attention reads
+    (arena prefix, staging) as two segments, and pruning is a pure gather staging -> arena tail;
+    layers that do not prune append straight into the arena;
+  * no host round trip inside the loop (the reference syncs 2x per layer: utils.py:136, :284);
+  * GQA is native in the attention kernel (no repeat_kv materialisation, :61-62);
+  * lm_head only for the last position of the prompt tail (HF 4.50 computes it for every video token).
+
+GEMMs go through torch (hipBLASLt); everything else is libquickprefill.so via quickvideo_amd.native.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+
+from .lvu_config import LVUConfig, effective_k
+from .spec import TextSpec
+from .weights import DecoderWeights
+
+
+class KVArena:
+    """Pre-allocated per-layer KV store.  k(l)/v(l): [Hkv_local, capacity, D]; len[l] = rows in use."""
+
+    def __init__(self, n_layers: int, n_kv_heads: int, capacity: int, head_dim: int, device, dtype=torch.bfloat16):
+        self.capacity, self.head_dim, self.n_kv = capacity, head_dim, n_kv_heads
+        self.buf = torch.empty(n_layers, 2, n_kv_heads, capacity, head_dim, dtype=dtype, device=device)
+        self.len: List[int] = [0] * n_layers
+
+    def k(self, l): return self.buf[l, 0]
+    def v(self, l): return self.buf[l, 1]
+
+    @property
+    def head_stride(self) -> int:
+        return self.capacity * self.head_dim
+
+    def reset(self):
+        self.len = [0] * len(self.len)
+
+
+class QuickPrefillEngine:
+    def __init__(self, weights: DecoderWeights, cfg: LVUConfig, capacity: int, max_group_tokens: int, device=None, ops=None,
+                 tp_group=None):
+        self.w, self.spec, self.cfg = weights, weights.spec, cfg
+        self.device = torch.device(device if device is not None else weights.embed.device)
+        if ops is None:
+            from .native import QuickPrefillOps      # raises QuickPrefillUnavailable without a GPU / library: no fallback
+            ops = QuickPrefillOps(self.device)
+        self.ops = ops
+        self.tp_group = tp_group
+        self.tp_size = weights.tp_size
+        self.tp_rank = weights.tp_rank
+        s = self.spec
+        self.hq, self.hkv, self.li = weights.local_q_heads, weights.local_kv_heads, weights.local_inter
+        self.D = s.head_dim
+        self.dtype = weights.embed.dtype
+        self.n_max = max_group_tokens
+        self.arena = KVArena(len(weights.layers), self.hkv, capacity, self.D, self.device, self.dtype)
+        n, d, dev, dt = self.n_max, s.hidden, self.device, self.dtype
+        e = lambda *shape, dtype=dt: torch.empty(*shape, dtype=dtype, device=dev)
+        self.b_h, self.b_x, self.b_o, self.b_dn = e(n, d), e(n, d), e(n, d), e(n, d)
+        self.b_qkv = e(n, (self.hq + 2 * self.hkv) * self.D)
+        self.b_q, self.b_att = e(n, self.hq, self.D), e(n, self.hq, self.D)
+        self.b_gu, self.b_act = e(n, 2 * self.li), e(n, self.li)
+        self.b_stage = e(2, self.hkv, n, self.D)
+        self.b_ss = e(self.hkv, n, dtype=torch.float32)
+        self.b_ss_all = e(self.tp_size, self.hkv, n, dtype=torch.float32) if self.tp_size > 1 else None
+        self.b_idx = e(n, dtype=torch.int32)
+        self.b_h2 = e(n, d)
+        self.kept_trace: Optional[list] = None      # tests: set to [] to record kept indices per (group, layer)
+        self.seq_pos = 0                            # tokens of the original sequence consumed so far
+
+    # ------------------------------------------------------------------ helpers
+    def reset(self):
+        self.arena.reset()
+        self.seq_pos = 0
+
+    def _all_reduce(self, t: torch.Tensor):
+        if self.tp_size > 1:
+            torch.distributed.all_reduce(t, group=self.tp_group)
+
+    def _global_sumsq(self, n: int) -> (torch.Tensor, int):
+        """[Hkv_total, n] per-head sums in ascending head order, identical on every rank (partials are
+        all-gathered and added in fixed head order so the norm is bit-stable across TP degrees)."""
+        if self.tp_size == 1:
+            return self.b_ss.view(-1)[: self.hkv * n].view(self.hkv, n), self.hkv
+        local = self.b_ss.view(-1)[: self.hkv * n].view(self.hkv, n)
+        allb = self.b_ss_all.view(-1)[: self.tp_size * self.hkv * n].view(self.tp_size, self.hkv, n)
+        torch.distributed.all_gather_into_tensor(allb, local, group=self.tp_group)
+        total = self.spec.n_kv_heads
+        if total % self.tp_size == 0:
+            return allb.view(total, n), total
+        rep = self.tp_size // total                 # each KV head replicated on `rep` consecutive ranks
+        return allb[::rep].reshape(total, n).contiguous(), total
+
+    # ------------------------------------------------------------------ one segment through all layers
+    def forward_segment(self, embeds: torch.Tensor, pos: torch.Tensor, prune: bool) -> torch.Tensor:
+        """embeds [n, d] (device, engine dtype), pos int64 [3, n].  Returns the final hidden rows [n', d] (pre-norm)."""
+        s, ops, cfg, D = self.spec, self.ops, self.cfg, self.D
+        n = embeds.shape[0]
+        assert n <= self.n_max, f"group of {n} tokens exceeds max_group_tokens={self.n_max}"
+        L = len(self.w.layers)
+        cos, sin = ops.mrope_table(pos.contiguous(), s.mrope_section, s.rope_theta, D)
+        hbufs, hsel = (self.b_h, self.b_h2), 0
+        h = hbufs[0][:n]
+        h.copy_(embeds)
+        delta = None                                 # pending residual (MLP output of the previous layer)
+        scale = D ** -0.5
+        for l, lw in enumerate(self.w.layers):
+            n = h.shape[0]
+            x = self.b_x[:n]
+            ops.add_rmsnorm(h, delta, lw.ln1, x, s.rms_eps)                  # h += delta; x = RMSNorm(h)   (qwen25_lvu.py:167-169)
+            qkv = self.b_qkv[:n]
+            torch.addmm(lw.b_qkv, x, lw.w_qkv.t(), out=qkv)                  # q/k/v proj + bias             (:42-44)
+            k_keep = effective_k(n, cfg, l, L) if prune else None            # utils.py:231-255
+            past = self.arena.len[l]
+            assert past + n <= self.arena.capacity, "KV arena overflow"
+            q = self.b_q[:n]
+            if k_keep is not None:                                           # prune layer: new K/V go to staging
+                kn = self.b_stage[0].view(-1)[: self.hkv * n * D].view(self.hkv, n, D)
+                vn = self.b_stage[1].view(-1)[: self.hkv * n * D].view(self.hkv, n, D)
+                ops.rope_append(qkv, cos, sin, self.hq, self.hkv, D, q, kn, vn, n * D, 0, self.b_ss)
+                new_stride = n * D
+            else:                                                            # append in place                (:56-58)
+                kc, vc = self.arena.k(l), self.arena.v(l)
+                ops.rope_append(qkv, cos, sin, self.hq, self.hkv, D, q, kc, vc, self.arena.head_stride, past, None)
+                kn, vn, new_stride = kc[:, past:], vc[:, past:], self.arena.head_stride
+            att = self.b_att[:n]
+            ops.prefill_attn(q, self.arena.k(l), self.arena.v(l), self.arena.head_stride, past, kn, vn, new_stride, n, self.hq,
+                             self.hkv, D, scale, att)                        # :61-62, :102-112
+            o = self.b_o[:n]
+            torch.mm(att.view(n, self.hq * D), lw.w_o.t(), out=o)            # o_proj                        (:114-115)
+            self._all_reduce(o)
+            if k_keep is not None:                                           # post_process_kv_cache         (:183-192)
+                ss_all, heads_total = self._global_sumsq(n)
+                idx = self.b_idx[:k_keep]
+                ops.select_k_smallest(ss_all, heads_total, n, k_keep, idx)
+                ops.gather_kv(kn, vn, n * D, idx, k_keep, self.hkv, D, self.arena.k(l), self.arena.v(l), self.arena.head_stride, past)
+                self.arena.len[l] = past + k_keep
+                if self.kept_trace is not None:
+                    self.kept_trace.append((l, idx.clone()))
+            else:
+                self.arena.len[l] = past + n
+                if self.kept_trace is not None:
+                    self.kept_trace.append((l, None))
+            prune_hidden = (k_keep is not None and cfg.enable and isinstance(cfg.prefill_prune_starting_layer, int)
+                            and cfg.prefill_prune_starting_layer >= 0 and l >= cfg.prefill_prune_starting_layer)
+            if prune_hidden:                                                 # utils.py:292-331, 344-372
+                ops.add_inplace(h, o)
+                hsel ^= 1
+                hk = hbufs[hsel][:k_keep]
+                ops.gather_rows(h, idx, k_keep, s.hidden * h.element_size(), hk)
+                c2, s2 = torch.empty_like(cos[:k_keep]), torch.empty_like(sin[:k_keep])
+                ops.gather_rows(cos, idx, k_keep, cos.shape[1] * cos.element_size(), c2)
+                ops.gather_rows(sin, idx, k_keep, sin.shape[1] * sin.element_size(), s2)
+                h, cos, sin, n = hk, c2, s2, k_keep
+                x2 = self.b_x[:n]
+                ops.add_rmsnorm(h, None, lw.ln2, x2, s.rms_eps)
+            else:
+                x2 = self.b_x[:n]
+                ops.add_rmsnorm(h, o, lw.ln2, x2, s.rms_eps)                 # h += attn; x2 = RMSNorm(h)     (:182, :195-196)
+            gu = self.b_gu[:n]
+            torch.mm(x2, lw.w_gate_up.t(), out=gu)                           # gate & up                      (:197)
+            act = self.b_act[:n]
+            ops.swiglu(gu, act)
+            dn = self.b_dn[:n]
+            torch.mm(act, lw.w_down.t(), out=dn)
+            self._all_reduce(dn)
+            delta = dn
+        ops.add_inplace(h, delta)                                            # last residual                  (:198)
+        return h
+
+    # ------------------------------------------------------------------ public steps of the group loop
+    def prefill_group(self, embeds: torch.Tensor, pos: torch.Tensor):
+        """One video group (qwen25_lvu.py:671-717): KV appended + pruned; hidden output is discarded like the
+        reference discards the group's logits (:697-699)."""
+        self.forward_segment(embeds, pos, prune=True)
+        self.seq_pos += embeds.shape[0]
+
+    def prefill_tail(self, embeds: torch.Tensor, pos: torch.Tensor) -> torch.Tensor:
+        """Prompt tail over the pruned cache, no pruning (qwen25_lvu.py:724-742, enable = do_top_k_for_query).
+        Returns fp32 logits [V] of the last position = distribution of the first generated token (TTFT point)."""
+        h = self.forward_segment(embeds, pos, prune=bool(self.cfg.do_top_k_for_query))
+        self.seq_pos += embeds.shape[0]
+        return self.logits_last(h)
+
+    def logits_last(self, h: torch.Tensor) -> torch.Tensor:
+        x = torch.empty(1, self.spec.hidden, dtype=self.dtype, device=self.device)
+        self.ops.add_rmsnorm(h[-1:].contiguous(), None, self.w.norm, x, self.spec.rms_eps)
+        return torch.mm(x, self.w.lm_head.t())[0].float()
+
+    def decode_step(self, token_embed: torch.Tensor, rope_delta: int) -> torch.Tensor:
+        """One greedy decode step: position = original sequence position + rope_delta on all three streams
+        (HF generate with the caller-supplied cache_position, qwen25_lvu.py:445-464, 740)."""
+        p = self.seq_pos + rope_delta
+        pos = torch.full((3, 1), p, dtype=torch.int64, device=self.device)
+        h = self.forward_segment(token_embed.view(1, -1), pos, prune=bool(self.cfg.do_top_k_for_query))
+        self.seq_pos += 1
+        return self.logits_last(h)
+
+    def embed_tokens(self, ids: torch.Tensor) -> torch.Tensor:
+        return self.w.embed.index_select(0, ids.to(self.device))

@@ -1,0 +1,76 @@
+"""Test double with the interface of quickvideo_amd.native.QuickPrefillOps, computing on CPU tensors with the
+oracle.  It lets the engine's HOST logic (planner, layer loop, KV arena bookkeeping, tensor-parallel sharding and
+collectives over gloo) run in the CPU test suite.  It lives under tests/ — product code never imports it."""
+import numpy as np
+import torch
+
+from oracle import qp_oracle as O
+
+
+class OracleOps:
+    cus = 0
+
+    def mrope_table(self, pos, sections, theta, head_dim):
+        spec = O.TextSpec(hidden=head_dim, n_heads=1, n_kv_heads=1, head_dim=head_dim, intermediate=8, n_layers=1, vocab=8,
+                          rope_theta=theta, mrope_section=tuple(sections))
+        cos, sin = O.mrope_cos_sin(pos.cpu(), spec, torch.bfloat16)
+        return cos[:, :head_dim // 2].contiguous(), sin[:, :head_dim // 2].contiguous()
+
+    def rope_append(self, qkv, cos, sin, n_q, n_kv, D, q_out, k_dst, v_dst, dst_head_stride, dst_row0, head_sumsq):
+        n = qkv.shape[0]
+        c, s = torch.cat([cos, cos], -1), torch.cat([sin, sin], -1)
+        q = qkv[:, :n_q * D].view(n, n_q, D).transpose(0, 1)
+        k = qkv[:, n_q * D:(n_q + n_kv) * D].view(n, n_kv, D).transpose(0, 1)
+        v = qkv[:, (n_q + n_kv) * D:].view(n, n_kv, D).transpose(0, 1)
+        q_out[:n].copy_(O.apply_rope(q, c, s).transpose(0, 1))
+        kr = O.apply_rope(k, c, s)
+        kd = k_dst.reshape(-1) if k_dst.is_contiguous() else None
+        for h in range(n_kv):
+            self._rows(k_dst, h, dst_head_stride, dst_row0, n, D).copy_(kr[h])
+            self._rows(v_dst, h, dst_head_stride, dst_row0, n, D).copy_(v[h])
+        if head_sumsq is not None:
+            ss = O.key_sumsq_heads(O.torch_bf16_to_bits(kr.contiguous()))
+            head_sumsq.view(-1)[: n_kv * n].copy_(torch.from_numpy(ss).view(-1))
+
+    @staticmethod
+    def _rows(t, h, head_stride, row0, n, D):
+        """view of rows [row0,row0+n) of head h given a base tensor whose storage starts at element 0 of head 0"""
+        base = t.as_strided((t.untyped_storage().nbytes() // t.element_size() - t.storage_offset(),), (1,), t.storage_offset())
+        return base[h * head_stride + row0 * D: h * head_stride + (row0 + n) * D].view(n, D)
+
+    def prefill_attn(self, q, k_prefix, v_prefix, prefix_head_stride, P, k_new, v_new, new_head_stride, n, n_q, n_kv, D, scale, out):
+        ks, vs = [], []
+        for h in range(n_kv):
+            parts_k, parts_v = [], []
+            if P > 0:
+                parts_k.append(self._rows(k_prefix, h, prefix_head_stride, 0, P, D)); parts_v.append(self._rows(v_prefix, h, prefix_head_stride, 0, P, D))
+            parts_k.append(self._rows(k_new, h, new_head_stride, 0, n, D)); parts_v.append(self._rows(v_new, h, new_head_stride, 0, n, D))
+            ks.append(torch.cat(parts_k)); vs.append(torch.cat(parts_v))
+        out[:n].copy_(O.attention_bottom_right(q[:n].transpose(0, 1), torch.stack(ks), torch.stack(vs), scale))
+
+    def select_k_smallest(self, head_sumsq, n_heads_total, n, k, kept_idx, norm_bits=None):
+        ss = head_sumsq.reshape(-1)[: n_heads_total * n].view(n_heads_total, n).numpy()
+        nb = O.key_norms_bf16(ss)
+        kept_idx[:k].copy_(torch.from_numpy(O.select_k_smallest(nb, k)))
+
+    def gather_kv(self, k_src, v_src, src_head_stride, idx, k, n_kv, D, k_dst, v_dst, dst_head_stride, dst_row0):
+        ii = idx[:k].long()
+        n_src = int(ii.max()) + 1
+        for h in range(n_kv):
+            self._rows(k_dst, h, dst_head_stride, dst_row0, k, D).copy_(self._rows(k_src, h, src_head_stride, 0, n_src, D)[ii])
+            self._rows(v_dst, h, dst_head_stride, dst_row0, k, D).copy_(self._rows(v_src, h, src_head_stride, 0, n_src, D)[ii])
+
+    def gather_rows(self, src, idx, k, row_bytes, dst):
+        dst[:k].copy_(src[idx[:k].long()])
+
+    def add_rmsnorm(self, h, delta, w, out, eps):
+        if delta is not None:
+            h.copy_(h + delta)
+        out.copy_(O.rmsnorm(h, w, eps))
+
+    def add_inplace(self, h, delta):
+        h.copy_(h + delta)
+
+    def swiglu(self, gate_up, out):
+        i = gate_up.shape[1] // 2
+        out.copy_(torch.nn.functional.silu(gate_up[:, :i]) * gate_up[:, i:])

@@ -1,0 +1,121 @@
+"""CPU tests of the engine's host logic with the oracle-backed ops double (tests/oracle_ops.py): group loop,
+arena bookkeeping, hidden-state pruning hand-off, prompt tail, decode positions — compared with the oracle's own
+end-to-end restatement and with the golden vectors from the reference (GV5)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import qp_oracle as O
+from oracle.make_golden import E2E_CASES, TINY as TINY_DICT
+from quickvideo_amd import planner
+from quickvideo_amd.engine import QuickPrefillEngine
+from quickvideo_amd.lvu_config import LVUConfig, LVULayerConfig, effective_k
+from quickvideo_amd.spec import TINY
+from quickvideo_amd.weights import DecoderWeights
+from tests.oracle_ops import OracleOps
+
+
+def make_case(frames, gh, gw, gs, prefix, tail, seed=4242):
+    spec_o = O.TextSpec(**TINY_DICT)
+    w = {k: v.to(torch.bfloat16) for k, v in O.synthetic_text_weights(spec_o, seed=7, norm_jitter=0.1).items()}
+    n_video = (frames // 2) * (gh // 2) * (gw // 2)
+    T = prefix + n_video + tail
+    plan = planner.plan_groups(frames, gs, gh, gw, prefix, T)
+    pos, delta = planner.mrope_positions(prefix, (frames // 2, gh, gw), tail)
+    rs = np.random.RandomState(seed)
+    embeds = torch.from_numpy(rs.standard_normal((T, spec_o.hidden)).astype(np.float32) * 0.5).to(torch.bfloat16)
+    return spec_o, w, plan, pos, delta, embeds
+
+
+def run_engine(w, plan, pos, embeds, cfg, ops, tp_rank=0, tp_size=1, tp_group=None):
+    dw = DecoderWeights.from_named(TINY, w, "cpu", tp_rank=tp_rank, tp_size=tp_size)
+    eng = QuickPrefillEngine(dw, cfg, capacity=embeds.shape[0] + 8, max_group_tokens=max(plan.tokens + [plan.tail_len]), device="cpu",
+                             ops=ops, tp_group=tp_group)
+    eng.kept_trace = []
+    start = 0
+    post = torch.from_numpy(pos)
+    for n in plan.tokens:
+        eng.prefill_group(embeds[start:start + n], post[:, start:start + n])
+        start += n
+    logits = eng.prefill_tail(embeds[start:], post[:, start:])
+    return eng, logits
+
+
+@pytest.mark.parametrize("top_p,top_k,pps,decay", [(0.5, None, None, None), (None, 5, None, None), (0.5, None, 1, None),
+                                                    (0.6, None, 0, "linear"), (None, None, None, None), (0.3, None, None, "exponential")])
+def test_engine_equals_oracle_e2e(top_p, top_k, pps, decay):
+    spec_o, w, plan, pos, delta, embeds = make_case(12, 8, 4, 4, 9, 6)
+    cfg = LVUConfig("x", top_p=top_p, top_k=top_k, prefill_prune_starting_layer=pps, top_k_decay_type=decay,
+                    top_k_decay_factor=0.8 if decay == "exponential" else None, video_group_size=4)
+    eng, logits = run_engine(w, plan, pos, embeds, cfg, OracleOps())
+    ref = O.group_prefill(w, spec_o, embeds, pos, plan.tokens,
+                          O.PruneCfg(top_k=top_k, top_p=top_p, top_k_decay_type=decay, top_k_decay_factor=cfg.top_k_decay_factor,
+                                     prefill_prune_starting_layer=pps))
+    assert eng.arena.len == ref["cache_len"]
+    flat_ref = [k for g in ref["kept"] for k in g]
+    assert len(flat_ref) == len(eng.kept_trace)
+    for (l, got), want in zip(eng.kept_trace, flat_ref):
+        assert (got is None) == (want is None)
+        if want is not None:
+            assert np.array_equal(got.numpy(), want)
+    assert torch.equal(logits, ref["logits"])          # same ops in the same order -> identical
+    for l in range(spec_o.n_layers):                   # arena content == oracle cache
+        assert torch.equal(eng.arena.k(l)[:, :eng.arena.len[l]], ref["cache"].k[l])
+        assert torch.equal(eng.arena.v(l)[:, :eng.arena.len[l]], ref["cache"].v[l])
+
+
+@pytest.mark.parametrize("ci", [i for i, c in enumerate(E2E_CASES) if c[1] == "bfloat16"])
+def test_engine_vs_reference_golden(golden_dir, ci):
+    """Engine host logic (with oracle math) against the composite REFERENCE run (GV5)."""
+    data = np.load(os.path.join(golden_dir, "gv5_e2e.npz"))
+    name, dtn, frames, gh, gw, gs, prefix, tail, top_p, top_k = E2E_CASES[ci]
+    spec_o, w, plan, pos, delta, embeds = make_case(frames, gh, gw, gs, prefix, tail)
+    eng, logits = run_engine(w, plan, pos, embeds, LVUConfig("x", top_p=top_p, top_k=top_k, video_group_size=gs), OracleOps())
+    assert eng.arena.len == list(data[f"{name}_cache_len"])
+    ref = data[f"{name}_logits"]
+    got = logits.numpy()
+    assert np.max(np.abs(got - ref)) <= 3e-2
+    assert float(np.dot(got, ref) / (np.linalg.norm(got) * np.linalg.norm(ref))) >= 0.999
+
+
+def test_effective_k_matches_golden_table(golden_dir):
+    rows = json.load(open(os.path.join(golden_dir, "gv3_effective_k.json")))
+    for q_len, top_k, top_p, decay, factor, layer, L, enable, want in rows:
+        cfg = LVUConfig("x", top_k=top_k, top_p=top_p, top_k_decay_type=decay, top_k_decay_factor=factor, enable=enable)
+        if isinstance(want, str):
+            with pytest.raises(TypeError):
+                effective_k(q_len, cfg, layer, L)
+        else:
+            assert effective_k(q_len, cfg, layer, L) == want
+
+
+def test_config_surface():
+    """Field names/defaults of lvu/lvu_config.py:3-33 stay drop-in."""
+    c = LVUConfig("Qwen/Qwen2-VL-7B-Instruct")
+    assert (c.top_k_predict_type, c.top_k, c.top_p, c.do_top_k_for_query, c.adaptive_local_attention, c.num_frames, c.enable,
+            c.query_based) == ("key_norms_small", None, None, False, True, 32, True, False)
+    assert LVUConfig("x", top_k_decay_type="linear").top_k_decay_factor == 0.5
+    assert LVUConfig("x", top_k_predict_type="query_attention_weights").query_based is True
+    lc = LVULayerConfig(layer_idx=27, total_layers=28, lvu_config=LVUConfig("x", prefill_prune_starting_layer=20))
+    assert lc.is_last_layer and lc.prune_for_next_layer
+    assert not LVULayerConfig(layer_idx=3, total_layers=28, lvu_config=LVUConfig("x", prefill_prune_starting_layer=20)).prune_for_next_layer
+    # intended top_k_starting_layer semantics (reference crashes there: utils.py:253)
+    assert effective_k(100, LVUConfig("x", top_p=0.5, top_k_starting_layer=4), 2, 28) is None
+    assert effective_k(100, LVUConfig("x", top_p=0.5, top_k_starting_layer=4), 4, 28) == 50
+
+
+def test_planner_matches_oracle():
+    for args in [(64, 16, 40, 72, 15, 15 + 23040 + 30), (8, 3, 4, 6, 5, 36), (12, 8, 4, 4, 2, 29), (8, 0, 4, 6, 5, 40), (7200 // 2 * 2, 16, 28, 40, 15, 15 + 1008000 + 29)]:
+        a, b = planner.plan_groups(*args), O.plan_groups(*args)
+        assert (a.tokens, a.grid_thw, a.pixel_rows, a.frames, a.past_len_after, a.tail_len) == (b.tokens, b.grid_thw, b.pixel_rows, b.frames, b.past_len_after, b.tail_len)
+    with pytest.raises(TypeError):
+        planner.plan_groups(8, None, 4, 6, 5, 40)
+    with pytest.raises(AssertionError):
+        planner.plan_groups(8, 4, 4, 6, 5, 29)          # no prompt tail left
+    for p, g, t, sc in [(5, (3, 4, 6), 7, 1.0), (15, (32, 40, 72), 30, 1.0), (3, (6, 4, 4), 2, 2.0)]:
+        pa, da = planner.mrope_positions(p, g, t, temporal_scale=sc); pb, db = O.mrope_positions(p, g, t, temporal_scale=sc)
+        assert np.array_equal(pa, pb) and da == db
+    assert planner.video_frame_size(64, 1080, 1920) == O.video_frame_size(64, 1080, 1920) == (560, 1008)
