@@ -121,7 +121,7 @@ class QuickPrefillEngine:
             torch.addmm(lw.b_qkv, x, lw.w_qkv.t(), out=qkv)                  # q/k/v proj + bias             (:42-44)
             k_keep = effective_k(n, cfg, l, L) if prune else None            # utils.py:231-255
             past = self.arena.len[l]
-            assert past + n <= self.arena.capacity, "KV arena overflow"
+            assert past + (k_keep if k_keep is not None else n) <= self.arena.capacity, "KV arena overflow"
             q = self.b_q[:n]
             if k_keep is not None:                                           # prune layer: new K/V go to staging
                 kn = self.b_stage[0].view(-1)[: self.hkv * n * D].view(self.hkv, n, D)
