@@ -1,0 +1,46 @@
+"""Attention micro-benchmark / large-shape check: qp_prefill_attn variants vs torch SDPA on the GPU.
+usage: python tools/bench_attn.py [variants...]   e.g.  python tools/bench_attn.py 1 2"""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from quickvideo_amd.native import QuickPrefillOps
+
+D = 128
+ops = QuickPrefillOps(torch.device("cuda:0"))
+variants = sys.argv[1:] or ["1", "2"]
+shapes = [(5760, 0, 28, 4), (5760, 2887, 28, 4), (5760, 8647, 28, 4), (2240, 100000, 28, 4), (960, 15000, 8, 1)]
+if os.environ.get("QP_SHAPES") == "small":
+    shapes = shapes[:3]
+if os.environ.get("QP_SHAPES") == "one":
+    shapes = shapes[2:3]
+
+def bench(f, it=10):
+    for _ in range(2): f()
+    torch.cuda.synchronize(); s = torch.cuda.Event(True); e = torch.cuda.Event(True)
+    s.record()
+    for _ in range(it): f()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / it
+
+for (n, P, hq, hkv) in shapes:
+    g = torch.Generator(device="cuda"); g.manual_seed(n + P)
+    q = torch.randn(n, hq, D, generator=g, device="cuda").to(torch.bfloat16)
+    k = torch.randn(hkv, P + n, D, generator=g, device="cuda").to(torch.bfloat16)
+    v = torch.randn(hkv, P + n, D, generator=g, device="cuda").to(torch.bfloat16)
+    out = torch.empty(n, hq, D, dtype=torch.bfloat16, device="cuda")
+    fl = 4 * hq * D * (n * P + n * (n + 1) / 2)
+    # reference: torch SDPA with an explicit bottom-right causal mask (fp32 math on a slice to bound memory)
+    rows = slice(max(0, n - 512), n)
+    qs = q[rows].transpose(0, 1).float()                                    # [hq, r, D]
+    kk = k.repeat_interleave(hq // hkv, 0).float(); vv = v.repeat_interleave(hq // hkv, 0).float()
+    sc = torch.einsum("hrd,hkd->hrk", qs, kk) * D ** -0.5
+    ii = torch.arange(rows.start, n, device="cuda")[:, None] + P
+    sc = sc.masked_fill(torch.arange(P + n, device="cuda")[None, :] > ii, float("-inf"))
+    ref = torch.einsum("hrk,hkd->rhd", torch.softmax(sc, -1), vv)
+    del sc, kk, vv
+    for var in variants:
+        os.environ["QP_ATTN_VARIANT"] = var
+        f = lambda: ops.prefill_attn(q, k, v, (P + n) * D, P, k[:, P:], v[:, P:], (P + n) * D, n, hq, hkv, D, D ** -0.5, out)
+        out.zero_(); f(); torch.cuda.synchronize()
+        err = (out[rows].float() - ref).abs().max().item()
+        ms = bench(f)
+        print(f"n={n} P={P} hq={hq} hkv={hkv} variant={var}: {ms:.3f} ms  {fl/ms/1e9:.1f} TF  maxerr(last 512 rows)={err:.4f}", flush=True)
