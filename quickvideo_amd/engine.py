@@ -92,13 +92,13 @@ class QuickPrefillEngine:
         if self.tp_size == 1:
             return self.b_ss.view(-1)[: self.hkv * n].view(self.hkv, n), self.hkv
         local = self.b_ss.view(-1)[: self.hkv * n].view(self.hkv, n)
-        allb = self.b_ss_all.view(-1)[: self.tp_size * self.hkv * n].view(self.tp_size, self.hkv, n)
-        torch.distributed.all_gather_into_tensor(allb, local, group=self.tp_group)
+        allb = self.b_ss_all.view(-1)[: self.tp_size * self.hkv * n].view(self.tp_size * self.hkv, n)
+        torch.distributed.all_gather_into_tensor(allb, local, group=self.tp_group)      # rank-major == ascending head order
         total = self.spec.n_kv_heads
         if total % self.tp_size == 0:
-            return allb.view(total, n), total
-        rep = self.tp_size // total                 # each KV head replicated on `rep` consecutive ranks
-        return allb[::rep].reshape(total, n).contiguous(), total
+            return allb, total
+        rep = self.tp_size // total                 # each KV head replicated on `rep` consecutive ranks (hkv_local == 1)
+        return allb[::rep].contiguous(), total
 
     # ------------------------------------------------------------------ one segment through all layers
     def forward_segment(self, embeds: torch.Tensor, pos: torch.Tensor, prune: bool) -> torch.Tensor:
@@ -133,7 +133,10 @@ class QuickPrefillEngine:
                 ops.rope_append(qkv, cos, sin, self.hq, self.hkv, D, q, kc, vc, self.arena.head_stride, past, None)
                 kn, vn, new_stride = kc[:, past:], vc[:, past:], self.arena.head_stride
             att = self.b_att[:n]
-            ops.prefill_attn(q, self.arena.k(l), self.arena.v(l), self.arena.head_stride, past, kn, vn, new_stride, n, self.hq,
+            # adaptive_local_attention=False: video groups are prefilled independently (no cross-group attention,
+            # qwen25_lvu.py:700-714); their pruned K/V still accumulate in the arena for the prompt tail.
+            past_attn = past if (cfg.adaptive_local_attention or not prune) else 0
+            ops.prefill_attn(q, self.arena.k(l), self.arena.v(l), self.arena.head_stride, past_attn, kn, vn, new_stride, n, self.hq,
                              self.hkv, D, scale, att)                        # :61-62, :102-112
             o = self.b_o[:n]
             torch.mm(att.view(n, self.hq * D), lw.w_o.t(), out=o)            # o_proj                        (:114-115)

@@ -1,0 +1,135 @@
+"""Frame sources with the reader contract the reference's overlap pipeline consumes (deepcodec
+InterleavedVideoReader [3P] as used in qwen25_lvu_interleaved.py:385-410, 438-442, 513-515):
+
+    vr = Reader(path, num_threads=.., num_intervals=..); len(vr); vr.get_fps()
+    vr.height, vr.width, vr.interpolation = H, W, "LANCZOS"     # settable
+    vr.process(idx)            # start producing the frames with these indices
+    vr.frame_iter = g          # frames per __next__
+    next(vr) -> uint8 [g, 3, H, W]   (StopIteration at the end)
+
+There is no FFmpeg / codec in this image, so real containers cannot be decoded; the sources here are
+  * synthetic://?frames=F&h=H&w=W&fps=R&seed=S[&pattern=noise|gradient]   seeded frames generated on the fly
+  * *.npy / *.pt files holding uint8 [F, 3, H, W] (pre-decoded video)
+A real decoder plugs in by implementing the same five members.  Environment knobs QUICKCODEC_CORES /
+QUICKCODEC_INTERVALS are read like the reference does (interleaved:391-392) and passed to the reader."""
+from __future__ import annotations
+
+import os
+import urllib.parse
+from typing import Optional
+
+import numpy as np
+import torch
+
+
+class VideoReaderBase:
+    height: Optional[int] = None
+    width: Optional[int] = None
+    interpolation: str = "LANCZOS"
+    frame_iter: int = 16
+
+    def __init__(self, path: str, num_threads: int = 8, num_intervals: int = 64):
+        self.path, self.num_threads, self.num_intervals = path, num_threads, num_intervals
+        self._idx = None
+        self._cursor = 0
+
+    def __len__(self) -> int: raise NotImplementedError
+    def get_fps(self) -> float: raise NotImplementedError
+    def _frames(self, idx: np.ndarray) -> np.ndarray: raise NotImplementedError   # uint8 [len(idx), 3, H, W]
+
+    def process(self, idx):
+        self._idx = np.asarray(idx, dtype=np.int64)
+        self._cursor = 0
+
+    def __iter__(self):
+        return self
+
+    def __next__(self) -> torch.Tensor:
+        if self._idx is None:
+            raise RuntimeError("call process(indices) before iterating")
+        if self._cursor >= len(self._idx):
+            raise StopIteration
+        sel = self._idx[self._cursor:self._cursor + self.frame_iter]
+        self._cursor += len(sel)
+        return torch.from_numpy(self._frames(sel))
+
+
+class SyntheticVideoReader(VideoReaderBase):
+    """Seeded synthetic video: frame i depends only on (seed, i, H, W, pattern) — any access order gives the same pixels."""
+
+    def __init__(self, path: str, num_threads: int = 8, num_intervals: int = 64):
+        super().__init__(path, num_threads, num_intervals)
+        q = dict(urllib.parse.parse_qsl(urllib.parse.urlparse(path).query))
+        self.total = int(q.get("frames", 64))
+        self.src_h, self.src_w = int(q.get("h", 1080)), int(q.get("w", 1920))
+        self.fps, self.seed, self.pattern = float(q.get("fps", 2.0)), int(q.get("seed", 1)), q.get("pattern", "noise")
+
+    def __len__(self): return self.total
+    def get_fps(self): return self.fps
+
+    def _frames(self, idx):
+        H, W = self.height or self.src_h, self.width or self.src_w
+        out = np.empty((len(idx), 3, H, W), dtype=np.uint8)
+        for j, i in enumerate(idx):
+            if self.pattern == "gradient":
+                yy = (np.arange(H, dtype=np.uint32)[:, None] * 255 // max(H - 1, 1))
+                xx = (np.arange(W, dtype=np.uint32)[None, :] * 255 // max(W - 1, 1))
+                base = (yy + xx + 7 * int(i)) % 256
+                out[j] = np.stack([base, (base * 3 + 40) % 256, (255 - base)]).astype(np.uint8)
+            else:
+                out[j] = np.random.RandomState((self.seed * 1_000_003 + int(i)) % (2 ** 31)).randint(0, 256, (3, H, W), dtype=np.uint8)
+        return out
+
+
+class ArrayVideoReader(VideoReaderBase):
+    """Pre-decoded video in a .npy / .pt file: uint8 [F, 3, H, W].  Frames are served at their stored size
+    (vr.height/width must match: resizing belongs to a decoder, which this image does not have)."""
+
+    def __init__(self, path: str, num_threads: int = 8, num_intervals: int = 64):
+        super().__init__(path, num_threads, num_intervals)
+        arr = torch.load(path).numpy() if path.endswith(".pt") else np.load(path, mmap_mode="r")
+        assert arr.ndim == 4 and arr.shape[1] == 3 and arr.dtype == np.uint8, "expected uint8 [F, 3, H, W]"
+        self.arr = arr
+        self.fps = 2.0
+
+    def __len__(self): return self.arr.shape[0]
+    def get_fps(self): return self.fps
+
+    def _frames(self, idx):
+        if self.height and self.width and (self.height, self.width) != tuple(self.arr.shape[2:]):
+            raise ValueError(f"stored frames are {tuple(self.arr.shape[2:])}, requested {(self.height, self.width)}: no resizer without a codec")
+        return np.ascontiguousarray(self.arr[idx])
+
+
+def open_video(path, num_threads: Optional[int] = None, num_intervals: Optional[int] = None) -> VideoReaderBase:
+    if isinstance(path, VideoReaderBase):
+        return path
+    nt = num_threads if num_threads is not None else int(os.environ.get("QUICKCODEC_CORES", "8"))
+    ni = num_intervals if num_intervals is not None else int(os.environ.get("QUICKCODEC_INTERVALS", "64"))
+    p = str(path)
+    if p.startswith("synthetic://"):
+        return SyntheticVideoReader(p, nt, ni)
+    if p.endswith((".npy", ".pt")):
+        return ArrayVideoReader(p, nt, ni)
+    raise ValueError(f"cannot open {p!r}: this build has no video codec (no FFmpeg in the image); use synthetic://... or a "
+                     f".npy/.pt file of uint8 [F,3,H,W] frames, or pass a reader object with the InterleavedVideoReader contract")
+
+
+def smart_nframes(total_frames: int, video_fps: float, nframes: Optional[int] = None, fps: Optional[float] = None,
+                  frame_factor: int = 2, fps_min_frames: int = 4, fps_max_frames: int = 100_000) -> int:
+    """qwen-vl-utils smart_nframes with the reference's FPS_MAX_FRAMES override (qwen25_lvu.py:27, 402-442)."""
+    if nframes is not None and fps is not None:
+        raise ValueError("Only accept either `fps` or `nframes`")
+    rnd = lambda x: round(x / frame_factor) * frame_factor
+    if nframes is not None:
+        n = rnd(nframes)
+    else:
+        fps = 2.0 if fps is None else fps
+        mn = -(-fps_min_frames // frame_factor) * frame_factor
+        mx = (min(fps_max_frames, total_frames) // frame_factor) * frame_factor
+        n = total_frames / video_fps * fps
+        n = min(min(max(n, mn), mx), total_frames)
+        n = (int(n) // frame_factor) * frame_factor
+    if not (frame_factor <= n <= total_frames):
+        raise ValueError(f"nframes should in interval [{frame_factor}, {total_frames}], but got {n}.")
+    return int(n)

@@ -1,0 +1,229 @@
+"""Video -> first token pipeline: CPU frame production overlapped with GPU ViT + group prefill.
+
+Reference shape (lvu/models/qwen25_lvu_interleaved.py:237-342, 733-942): a daemon thread pulls frame groups from
+the reader, runs the HF processor on the CPU and feeds a bounded Queue(3); the main thread polls it every 10 ms and
+runs the group loop.  Here the producer thread only moves uint8 frames into a pinned host ring and enqueues an
+async H2D copy on a dedicated HIP stream (event-signalled, no polling); normalise + patchify + ViT run on the GPU on a
+second stream, one group ahead of the LLM prefill that runs on the main stream.  Token ids and M-RoPE positions are
+built before any pixel exists from (nframes, H, W) alone, like the reference's dummy_call (interleaved:522-638, 786-810).
+"""
+from __future__ import annotations
+
+import queue
+import threading
+import time
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import planner
+from .engine import QuickPrefillEngine
+from .frames import open_video, smart_nframes
+from .lvu_config import LVUConfig, effective_k
+from .spec import TextSpec
+from .vit import VisionTower, VisionWeights, patchify_frames
+from .weights import DecoderWeights
+
+
+@dataclass
+class QwenVLNative:
+    """The `model` object of the native plugin: decoder + vision weights resident on one device."""
+    text: DecoderWeights
+    vision: VisionWeights
+    device: torch.device
+    name: str = "synthetic"
+    rope_deltas: Optional[int] = None
+    engine: Optional[QuickPrefillEngine] = None
+    config: Optional[LVUConfig] = None
+
+    @property
+    def spec(self) -> TextSpec:
+        return self.text.spec
+
+
+@dataclass
+class Timings:
+    fetch: float = 0.0          # time the consumer waited for frames (video_processing_time analogue)
+    vit: float = 0.0            # device time of patchify + ViT (events)
+    prefill: float = 0.0        # group loop wall time, device-synchronised at the end (total_prefill)
+    decode: float = 0.0
+    e2e: float = 0.0
+    ttft: float = 0.0           # first frame requested -> first token id on the host
+    tokens: int = 0
+    groups: int = 0
+
+
+class _Producer(threading.Thread):
+    """Frame groups -> pinned ring -> async H2D on `copy_stream`; bounded like the reference's Queue(maxsize=3)."""
+
+    def __init__(self, reader, n_groups, frames_per_group, device, depth=3):
+        super().__init__(daemon=True)
+        self.reader, self.n_groups, self.device, self.depth = reader, n_groups, device, depth
+        self.q: "queue.Queue" = queue.Queue(maxsize=depth)
+        self.exc = None
+        self.use_gpu = device.type == "cuda"
+        self.copy_stream = torch.cuda.Stream(device) if self.use_gpu else None
+        self.slots_free = threading.Semaphore(depth)
+        self.ring = None
+        self.fpg = frames_per_group
+
+    def run(self):
+        try:
+            for g in range(self.n_groups):
+                frames = next(self.reader)                      # uint8 [g,3,H,W] (CPU work, GIL released inside numpy)
+                self.slots_free.acquire()
+                if self.use_gpu:
+                    if self.ring is None:
+                        shape = (self.fpg,) + tuple(frames.shape[1:])
+                        self.ring = [(torch.empty(shape, dtype=torch.uint8).pin_memory(), torch.empty(shape, dtype=torch.uint8, device=self.device))
+                                     for _ in range(self.depth)]
+                    host, dev = self.ring[g % self.depth]
+                    host[: frames.shape[0]].copy_(frames)
+                    with torch.cuda.stream(self.copy_stream):
+                        dev[: frames.shape[0]].copy_(host[: frames.shape[0]], non_blocking=True)
+                        ev = torch.cuda.Event()
+                        ev.record(self.copy_stream)
+                    self.q.put((g, dev[: frames.shape[0]], ev))
+                else:
+                    self.q.put((g, frames.clone(), None))
+        except BaseException as e:   # re-raised in the consumer, like interleaved:291-292, 314-316
+            self.exc = e
+            self.q.put(None)
+
+    def get(self):
+        item = self.q.get()
+        if item is None:
+            raise self.exc
+        return item
+
+    def release(self):
+        self.slots_free.release()
+
+
+class PrefillPipeline:
+    def __init__(self, model: QwenVLNative, config: LVUConfig, processor, ops=None):
+        self.model, self.cfg, self.processor, self.ops = model, config, processor, ops
+        self.tower = VisionTower(model.vision)
+        self.use_gpu = model.device.type == "cuda"
+        self.vit_stream = torch.cuda.Stream(model.device) if self.use_gpu else None
+        self.last_timings: Optional[Timings] = None
+
+    # ------------------------------------------------------------------ planning (no pixels needed)
+    def plan(self, reader, question: str):
+        cfg, spec = self.cfg, self.model.spec
+        total, vfps = len(reader), reader.get_fps()
+        nframes = smart_nframes(total, vfps, nframes=cfg.num_frames if cfg.fps is None else None, fps=cfg.fps)
+        ek = cfg.extra_kwargs or {}
+        src_h = getattr(reader, "src_h", None) or reader.height
+        src_w = getattr(reader, "src_w", None) or reader.width
+        if src_h is None:                                            # array-backed video: frames already at model size
+            src_h, src_w = reader.arr.shape[2:]
+            H, W = src_h, src_w
+        else:
+            H, W = planner.video_frame_size(nframes, src_h, src_w, ek.get("max_pixels"), ek.get("min_pixels"))
+        idx = np.linspace(0, total - 1, nframes).round().astype(np.int64)   # interleaved:397-399
+        vs = self.model.vision.spec
+        gh, gw = H // vs.patch_size, W // vs.patch_size
+        prompt = self.processor.build_prompt(question)
+        n_video = (nframes // vs.temporal_patch_size) * (gh // 2) * (gw // 2)
+        T = len(prompt.prefix_ids) + n_video + len(prompt.tail_ids)
+        gs = cfg.video_group_size
+        plan = planner.plan_groups(nframes, gs, gh, gw, len(prompt.prefix_ids), T, vs.temporal_patch_size, vs.spatial_merge_size)
+        pos, delta = planner.mrope_positions(len(prompt.prefix_ids), (nframes // vs.temporal_patch_size, gh, gw), len(prompt.tail_ids),
+                                             vs.spatial_merge_size, spec.temporal_scale)
+        return dict(nframes=nframes, H=H, W=W, idx=idx, prompt=prompt, plan=plan, pos=pos, delta=delta, T=T, gh=gh, gw=gw)
+
+    def _engine(self, plan, T) -> QuickPrefillEngine:
+        cfg, spec = self.cfg, self.model.spec
+        kept = sum((effective_k(n, cfg, 0, spec.n_layers) or n) for n in plan.tokens)
+        need_cap = kept + plan.tail_len + 256
+        n_max = max(plan.tokens + [plan.tail_len, 1])
+        eng = self.model.engine
+        if eng is None or eng.arena.capacity < need_cap or eng.n_max < n_max or eng.cfg is not cfg:
+            eng = QuickPrefillEngine(self.model.text, cfg, capacity=need_cap, max_group_tokens=n_max, device=self.model.device, ops=self.ops)
+            self.model.engine = eng
+        eng.reset()
+        return eng
+
+    # ------------------------------------------------------------------ video -> tokens
+    @torch.no_grad()
+    def generate(self, question: str, video, max_new_tokens: int = 16, overlap: bool = True, eos_token_id: Optional[int] = None,
+                 **unused) -> List[int]:
+        if self.cfg.top_k_predict_type != "key_norms_small":
+            raise ValueError(f"Unknown predict type: {self.cfg.top_k_predict_type} (the native engine implements key_norms_small, "
+                             f"lvu/utils.py:133-136; the reference's other ablation modes are out of scope)")
+        tm = Timings()
+        dev = self.model.device
+        t_e2e = time.perf_counter()
+        reader = open_video(video)
+        P = self.plan(reader, question)
+        plan, pos = P["plan"], torch.from_numpy(P["pos"]).to(dev)
+        reader.height, reader.width, reader.interpolation = P["H"], P["W"], "LANCZOS"
+        gs = plan.frames[0]
+        reader.frame_iter = gs
+        reader.process(P["idx"])                                      # decoding starts here (interleaved:438-442)
+        eng = self._engine(plan, P["T"])
+        self.model.rope_deltas = P["delta"]                           # qwen25_lvu.py:620
+        prefix = torch.tensor(P["prompt"].prefix_ids, dtype=torch.long, device=dev)
+        tail = torch.tensor(P["prompt"].tail_ids, dtype=torch.long, device=dev)
+        prod = _Producer(reader, len(plan.tokens), gs, dev)
+        if overlap:
+            prod.start()
+        else:
+            prod.run()                                                # sequential plugin: fetch everything first
+        sync = (lambda: torch.cuda.synchronize(dev)) if self.use_gpu else (lambda: None)
+
+        def vit_group(g):
+            t0 = time.perf_counter()
+            gi, frames, ev = prod.get()
+            tm.fetch += time.perf_counter() - t0
+            if self.use_gpu:
+                s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                self.vit_stream.wait_event(ev)
+                with torch.cuda.stream(self.vit_stream):
+                    s_ev.record(self.vit_stream)
+                    rows, grid = patchify_frames(frames, self.model.vision.spec, self.model.text.embed.dtype)
+                    feats = self.tower.forward(rows, grid)
+                    e_ev.record(self.vit_stream)
+                return feats, (s_ev, e_ev)
+            rows, grid = patchify_frames(frames, self.model.vision.spec, self.model.text.embed.dtype)
+            return self.tower.forward(rows, grid), None
+
+        t_pre = time.perf_counter()
+        start, vit_events = 0, []
+        nxt = vit_group(0)
+        for g, n in enumerate(plan.tokens):
+            feats, evs = nxt
+            if self.use_gpu:
+                torch.cuda.current_stream(dev).wait_event(evs[1])
+                vit_events.append(evs)
+            emb = torch.cat([eng.embed_tokens(prefix), feats], 0) if g == 0 else feats
+            assert emb.shape[0] == n, (emb.shape, n)
+            if g + 1 < len(plan.tokens):
+                nxt = vit_group(g + 1)                                # ViT of the next group runs ahead on its own stream
+            eng.prefill_group(emb, pos[:, start:start + n])
+            prod.release()
+            start += n
+        sync()
+        tm.prefill = time.perf_counter() - t_pre
+        tm.tokens, tm.groups = start, len(plan.tokens)
+        t_dec = time.perf_counter()
+        logits = eng.prefill_tail(eng.embed_tokens(tail), pos[:, start:])     # pruning off for the tail (qwen25_lvu.py:737-742)
+        tok = int(torch.argmax(logits).item())                                # first token on the host = TTFT point
+        tm.ttft = time.perf_counter() - t_e2e
+        out = [tok]
+        for _ in range(max_new_tokens - 1):
+            if eos_token_id is not None and tok == eos_token_id:
+                break
+            logits = eng.decode_step(eng.embed_tokens(torch.tensor([tok], device=dev)), P["delta"])
+            tok = int(torch.argmax(logits).item())
+            out.append(tok)
+        sync()
+        tm.decode = time.perf_counter() - t_dec
+        tm.e2e = time.perf_counter() - t_e2e
+        if self.use_gpu:
+            tm.vit = sum(s.elapsed_time(e) for s, e in vit_events) * 1e-3
+        self.last_timings = tm
+        return out

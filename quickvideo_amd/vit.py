@@ -1,0 +1,165 @@
+"""Qwen2-VL vision front end on PyTorch-ROCm (north_star: "ViT patch-embed/attention front
+end ... rebuilt on PyTorch-ROCm").
+
+What the reference does on the CPU (HF processor under the GIL, qwen25_lvu_interleaved.py:252-271, 318-340:
+rescale + CLIP-normalise + patchify the fp32 frames, then H2D of 4n x 1176 fp32) happens here on the GPU from the
+uint8 frames: upload 1 byte/pixel instead of 4, one fused normalise+patchify pass, then the ViT
+(transformers Qwen2VisionTransformerPretrainedModel [3P], restated): Conv3d patch embed as a GEMM, `depth`
+pre-LN blocks with full attention inside each temporal patch (cu_seqlens = one sequence per grid_t), 2-D rotary
+position embedding on (h, w), quick-GELU MLP, and the 2x2 PatchMerger MLP into the LLM width.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Tuple
+
+import torch
+import torch.nn.functional as F
+
+CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
+CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+@dataclass(frozen=True)
+class VisionSpec:
+    depth: int = 32
+    embed_dim: int = 1280
+    num_heads: int = 16
+    mlp_ratio: float = 4.0
+    patch_size: int = 14
+    temporal_patch_size: int = 2
+    spatial_merge_size: int = 2
+    in_channels: int = 3
+    out_hidden: int = 3584          # LLM width
+
+    @property
+    def head_dim(self) -> int:
+        return self.embed_dim // self.num_heads
+
+    @property
+    def patch_dim(self) -> int:
+        return self.in_channels * self.temporal_patch_size * self.patch_size * self.patch_size
+
+    def flops_per_patch(self) -> float:
+        d, m = self.embed_dim, int(self.embed_dim * self.mlp_ratio)
+        return 2.0 * (self.patch_dim * d + self.depth * (4 * d * d + 2 * d * m)) + 2.0 * (4 * d * 4 * d + 4 * d * self.out_hidden) / 4
+
+
+QWEN2_VL_VIT_7B = VisionSpec(out_hidden=3584)
+QWEN2_VL_VIT_2B = VisionSpec(out_hidden=1536)
+QWEN2_VL_VIT_72B = VisionSpec(out_hidden=8192)
+TINY_VIT = VisionSpec(depth=2, embed_dim=64, num_heads=4, mlp_ratio=2.0, out_hidden=256)
+
+
+def patchify_frames(frames_u8: torch.Tensor, spec: VisionSpec, dtype=torch.bfloat16) -> Tuple[torch.Tensor, Tuple[int, int, int]]:
+    """uint8 frames [F, 3, H, W] (already at the smart_resize target size) -> (pixel rows [grid_t*grid_h*grid_w, 1176],
+    (grid_t, grid_h, grid_w)) in the HF Qwen2VLImageProcessor order (t, h/2, w/2, 2, 2 | C, T, 14, 14) [3P]."""
+    Fn, C, H, W = frames_u8.shape
+    ps, tp, mg = spec.patch_size, spec.temporal_patch_size, spec.spatial_merge_size
+    assert Fn % tp == 0 and H % (ps * mg) == 0 and W % (ps * mg) == 0, "frame count / size not aligned to the patch grid"
+    gt, gh, gw = Fn // tp, H // ps, W // ps
+    mean = torch.tensor(CLIP_MEAN, device=frames_u8.device, dtype=torch.float32).view(1, C, 1, 1)
+    std = torch.tensor(CLIP_STD, device=frames_u8.device, dtype=torch.float32).view(1, C, 1, 1)
+    x = (frames_u8.to(torch.float32) * (1.0 / 255.0) - mean) / std
+    x = x.view(gt, tp, C, gh // mg, mg, ps, gw // mg, mg, ps).permute(0, 3, 6, 4, 7, 2, 1, 5, 8)
+    return x.reshape(gt * gh * gw, C * tp * ps * ps).to(dtype), (gt, gh, gw)
+
+
+def vision_pos_ids(grid_thw: Tuple[int, int, int], merge: int, device) -> torch.Tensor:
+    """(h, w) position of every patch in the merge-grouped order [3P get_vision_position_ids / rot_pos_emb]."""
+    t, h, w = grid_thw
+    hp = torch.arange(h, device=device).unsqueeze(1).expand(-1, w)
+    wp = torch.arange(w, device=device).unsqueeze(0).expand(h, -1)
+    re = lambda p: p.reshape(h // merge, merge, w // merge, merge).permute(0, 2, 1, 3).flatten()
+    return torch.stack([re(hp), re(wp)], dim=-1).repeat(t, 1)
+
+
+@dataclass
+class VisionBlockWeights:
+    ln1_w: torch.Tensor; ln1_b: torch.Tensor
+    qkv_w: torch.Tensor; qkv_b: torch.Tensor
+    proj_w: torch.Tensor; proj_b: torch.Tensor
+    ln2_w: torch.Tensor; ln2_b: torch.Tensor
+    fc1_w: torch.Tensor; fc1_b: torch.Tensor
+    fc2_w: torch.Tensor; fc2_b: torch.Tensor
+
+
+@dataclass
+class VisionWeights:
+    spec: VisionSpec
+    patch_w: torch.Tensor                 # [embed_dim, patch_dim]  (Conv3d weight flattened)
+    blocks: List[VisionBlockWeights]
+    ln_q_w: torch.Tensor; ln_q_b: torch.Tensor
+    m1_w: torch.Tensor; m1_b: torch.Tensor
+    m2_w: torch.Tensor; m2_b: torch.Tensor
+
+    @staticmethod
+    def from_named(spec: VisionSpec, sd: Dict[str, torch.Tensor], device, dtype=torch.bfloat16, prefix: str = "") -> "VisionWeights":
+        g = lambda k: sd[prefix + k].to(device=device, dtype=dtype).contiguous()
+        blocks = []
+        for i in range(spec.depth):
+            p = f"blocks.{i}."
+            blocks.append(VisionBlockWeights(g(p + "norm1.weight"), g(p + "norm1.bias"), g(p + "attn.qkv.weight"), g(p + "attn.qkv.bias"),
+                                             g(p + "attn.proj.weight"), g(p + "attn.proj.bias"), g(p + "norm2.weight"), g(p + "norm2.bias"),
+                                             g(p + "mlp.fc1.weight"), g(p + "mlp.fc1.bias"), g(p + "mlp.fc2.weight"), g(p + "mlp.fc2.bias")))
+        return VisionWeights(spec, g("patch_embed.proj.weight").reshape(spec.embed_dim, -1).contiguous(), blocks,
+                             g("merger.ln_q.weight"), g("merger.ln_q.bias"), g("merger.mlp.0.weight"), g("merger.mlp.0.bias"),
+                             g("merger.mlp.2.weight"), g("merger.mlp.2.bias"))
+
+    @staticmethod
+    def synthetic(spec: VisionSpec, device, seed: int = 0, dtype=torch.bfloat16, std: float = 0.02) -> "VisionWeights":
+        gen = torch.Generator(device=device); gen.manual_seed(seed + 77)
+        mat = lambda *s: (torch.randn(*s, generator=gen, device=device, dtype=torch.float32) * std).to(dtype)
+        one = lambda n: torch.ones(n, device=device, dtype=dtype)
+        zero = lambda n: torch.zeros(n, device=device, dtype=dtype)
+        d, m, d4 = spec.embed_dim, int(spec.embed_dim * spec.mlp_ratio), spec.embed_dim * spec.spatial_merge_size ** 2
+        blocks = [VisionBlockWeights(one(d), zero(d), mat(3 * d, d), mat(3 * d), mat(d, d), mat(d), one(d), zero(d), mat(m, d), mat(m),
+                                     mat(d, m), mat(d)) for _ in range(spec.depth)]
+        return VisionWeights(spec, mat(d, spec.patch_dim), blocks, one(d), zero(d), mat(d4, d4), mat(d4), mat(spec.out_hidden, d4),
+                             mat(spec.out_hidden))
+
+
+def _rotate_half(x):
+    h = x.shape[-1] // 2
+    return torch.cat((-x[..., h:], x[..., :h]), dim=-1)
+
+
+class VisionTower:
+    """Stateless forward over VisionWeights; runs on whatever device the weights live on (MI355X in the product)."""
+
+    def __init__(self, weights: VisionWeights):
+        self.w, self.spec = weights, weights.spec
+
+    @torch.no_grad()
+    def forward(self, pixel_rows: torch.Tensor, grid_thw: Tuple[int, int, int]) -> torch.Tensor:
+        s, w = self.spec, self.w
+        t, h, wd = grid_thw
+        n, seq = pixel_rows.shape[0], h * wd
+        assert n == t * seq
+        x = F.linear(pixel_rows.to(w.patch_w.dtype), w.patch_w)                         # Conv3d(stride = kernel) == GEMM
+        pos = vision_pos_ids(grid_thw, s.spatial_merge_size, x.device)                  # [n, 2]
+        rd = s.head_dim // 2
+        inv_freq = 1.0 / (10000.0 ** (torch.arange(0, rd, 2, dtype=torch.float32, device=x.device) / rd))
+        rot = (pos.unsqueeze(-1).float() * inv_freq).flatten(1)                         # [n, head_dim/2]
+        emb = torch.cat((rot, rot), dim=-1)
+        cos, sin = emb.cos()[:, None, :], emb.sin()[:, None, :]                         # fp32 [n, 1, head_dim]
+        H, hd = s.num_heads, s.head_dim
+        for b in w.blocks:
+            y = F.layer_norm(x, (s.embed_dim,), b.ln1_w, b.ln1_b, 1e-6)
+            qkv = F.linear(y, b.qkv_w, b.qkv_b).view(n, 3, H, hd)
+            q, k, v = qkv[:, 0], qkv[:, 1], qkv[:, 2]
+            qf, kf = q.float(), k.float()
+            q = (qf * cos + _rotate_half(qf) * sin).to(x.dtype)
+            k = (kf * cos + _rotate_half(kf) * sin).to(x.dtype)
+            # one attention sequence per temporal patch: [t, H, seq, hd]
+            q4, k4, v4 = (z.reshape(t, seq, H, hd).transpose(1, 2) for z in (q, k, v))
+            a = F.scaled_dot_product_attention(q4, k4, v4, is_causal=False)
+            a = a.transpose(1, 2).reshape(n, H * hd)
+            x = x + F.linear(a, b.proj_w, b.proj_b)
+            y = F.layer_norm(x, (s.embed_dim,), b.ln2_w, b.ln2_b, 1e-6)
+            y = F.linear(y, b.fc1_w, b.fc1_b)
+            y = y * torch.sigmoid(1.702 * y)                                             # quick_gelu
+            x = x + F.linear(y, b.fc2_w, b.fc2_b)
+        y = F.layer_norm(x, (s.embed_dim,), w.ln_q_w, w.ln_q_b, 1e-6).view(-1, s.embed_dim * s.spatial_merge_size ** 2)
+        y = F.gelu(F.linear(y, w.m1_w, w.m1_b))
+        return F.linear(y, w.m2_w, w.m2_b)                                               # [n/4, out_hidden]

@@ -1,0 +1,63 @@
+"""CPU checks of the drop-in boundary: libquickprefill.so loads without a GPU and exports every symbol that
+include/quickprefill.h declares; the ctypes table binds exactly that set; no product module imports the oracle."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "quickprefill.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(qp_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from quickvideo_amd import native
+    if not os.path.exists(native.LIB_PATH):
+        import __graft_entry__ as g
+        g.build()
+    lib = native.load_library()
+    names = header_functions()
+    assert len(names) >= 18
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in quickprefill.h but not exported"
+    assert sorted(native.SIGNATURES) == names, "ctypes table and header disagree"
+    assert b"gfx950" in lib.qp_version()
+
+
+def test_missing_library_fails_loudly():
+    from quickvideo_amd import native
+    with pytest.raises(native.QuickPrefillUnavailable):
+        native.load_library(os.path.join(ROOT, "does_not_exist.so"))
+
+
+def test_no_gpu_means_no_engine():
+    """Without a GPU the product refuses to construct its operators (there is no CPU fallback)."""
+    import torch
+    from quickvideo_amd import native
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(native.QuickPrefillUnavailable):
+        native.QuickPrefillOps()
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "quickvideo_amd")
+    offenders = []
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dp, f), errors="ignore").read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M) or "qp_oracle" in txt:
+                    offenders.append(os.path.join(dp, f))
+    for f in ("lvu",):
+        d = os.path.join(ROOT, f)
+        if os.path.isdir(d):
+            for dp, _, files in os.walk(d):
+                for ff in files:
+                    if ff.endswith(".py") and re.search(r"^\s*(from|import)\s+oracle\b", open(os.path.join(dp, ff)).read(), flags=re.M):
+                        offenders.append(os.path.join(dp, ff))
+    assert not offenders, offenders

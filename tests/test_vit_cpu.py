@@ -1,0 +1,60 @@
+"""Pins quickvideo_amd/vit.py (pure torch, device-agnostic) against the installed transformers Qwen2-VL vision
+tower with the same weights, and the GPU-side patchify against the HF processor's layout rule.  CPU, fp32."""
+import numpy as np
+import pytest
+import torch
+
+from quickvideo_amd.vit import VisionSpec, VisionTower, VisionWeights, patchify_frames, vision_pos_ids, CLIP_MEAN, CLIP_STD
+
+
+def hf_tower(spec):
+    from transformers.models.qwen2_vl.configuration_qwen2_vl import Qwen2VLVisionConfig
+    from transformers.models.qwen2_vl.modeling_qwen2_vl import Qwen2VisionTransformerPretrainedModel
+    cfg = Qwen2VLVisionConfig(depth=spec.depth, embed_dim=spec.embed_dim, hidden_size=spec.out_hidden, num_heads=spec.num_heads,
+                              mlp_ratio=int(spec.mlp_ratio), patch_size=spec.patch_size, spatial_merge_size=spec.spatial_merge_size,
+                              temporal_patch_size=spec.temporal_patch_size, hidden_act="quick_gelu")
+    cfg._attn_implementation = "eager"
+    torch.manual_seed(3)
+    m = Qwen2VisionTransformerPretrainedModel(cfg).eval().float()
+    for p in m.parameters():
+        torch.nn.init.normal_(p, std=0.05)
+    return m
+
+
+@pytest.mark.parametrize("grid", [(2, 4, 6), (1, 8, 4), (3, 2, 2)])
+def test_vit_matches_hf(grid):
+    spec = VisionSpec(depth=2, embed_dim=64, num_heads=4, mlp_ratio=2.0, out_hidden=96)
+    m = hf_tower(spec)
+    w = VisionWeights.from_named(spec, m.state_dict(), "cpu", dtype=torch.float32)
+    t, h, wd = grid
+    rs = np.random.RandomState(0)
+    pix = torch.from_numpy(rs.standard_normal((t * h * wd, spec.patch_dim)).astype(np.float32))
+    with torch.no_grad():
+        ref = m(pix, grid_thw=torch.tensor([list(grid)])).pooler_output
+    got = VisionTower(w).forward(pix, grid)
+    assert got.shape == ref.shape == (t * h * wd // 4, 96)
+    assert torch.allclose(got, ref, atol=2e-5, rtol=1e-4), (got - ref).abs().max()
+
+
+def test_patchify_layout():
+    """Same (t, h/2, w/2, 2, 2 | C, T, 14, 14) order and CLIP normalisation as HF's Qwen2VLImageProcessor."""
+    spec = VisionSpec(depth=1, embed_dim=16, num_heads=2)
+    rs = np.random.RandomState(1)
+    F_, H, W = 4, 56, 84
+    frames = torch.from_numpy(rs.randint(0, 256, (F_, 3, H, W)).astype(np.uint8))
+    rows, grid = patchify_frames(frames, spec, dtype=torch.float32)
+    assert grid == (2, 4, 6) and rows.shape == (2 * 4 * 6, 1176)
+    x = frames.numpy().astype(np.float64) / 255.0
+    x = (x - np.array(CLIP_MEAN).reshape(1, 3, 1, 1)) / np.array(CLIP_STD).reshape(1, 3, 1, 1)
+    # reference rule written independently: patch index -> (t, hb, wb, hi, wi)
+    for idx in (0, 1, 5, 23, 24, 47):
+        t, rem = divmod(idx, 24)
+        hb, rem = divmod(rem, 12)          # 12 = (w/2 blocks = 3) * 4
+        wb, rem = divmod(rem, 4)
+        hi, wi = divmod(rem, 2)
+        ph, pw = hb * 2 + hi, wb * 2 + wi
+        patch = x[t * 2:(t + 1) * 2, :, ph * 14:(ph + 1) * 14, pw * 14:(pw + 1) * 14]     # [T, C, 14, 14]
+        want = patch.transpose(1, 0, 2, 3).reshape(-1)                                   # (C, T, 14, 14)
+        assert np.allclose(rows[idx].numpy(), want, atol=1e-5)
+    pos = vision_pos_ids(grid, 2, "cpu")
+    assert pos[:6].tolist() == [[0, 0], [0, 1], [1, 0], [1, 1], [0, 2], [0, 3]]
