@@ -168,7 +168,8 @@ class PrefillPipeline:
         self.model.rope_deltas = P["delta"]                           # qwen25_lvu.py:620
         prefix = torch.tensor(P["prompt"].prefix_ids, dtype=torch.long, device=dev)
         tail = torch.tensor(P["prompt"].tail_ids, dtype=torch.long, device=dev)
-        prod = _Producer(reader, len(plan.tokens), gs, dev)
+        # overlapped: bounded ring of 3 groups like the reference's Queue(maxsize=3); sequential: everything is fetched first
+        prod = _Producer(reader, len(plan.tokens), gs, dev, depth=3 if overlap else len(plan.tokens))
         if overlap:
             prod.start()
         else:

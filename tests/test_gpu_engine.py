@@ -98,3 +98,19 @@ def test_no_gpu_fallback_is_loud():
     from quickvideo_amd import native
     with pytest.raises(native.QuickPrefillUnavailable):
         native.load_library("/nonexistent/libquickprefill.so")
+
+
+def test_lvu_generate_on_gpu(capsys):
+    """Drop-in API on the GPU: frames -> H2D ring -> ViT -> group prefill -> tokens, overlapped and sequential agree."""
+    import lvu
+    from quickvideo_amd.lvu import load_native_model
+    m = load_native_model("synthetic:tiny", device="cuda:0", seed=3)
+    video = "synthetic://?frames=48&h=112&w=168&seed=2&pattern=gradient"
+    outs = []
+    for mt in ("qwen2vl_mi355x", "qwen2vl_mi355x_sequential"):
+        obj = lvu.LVU(lvu.LVUConfig("synthetic:tiny", model_type=mt, top_p=0.5, video_group_size=4, num_frames=16), model=m)
+        outs.append(obj.generate("What is shown?", video, max_new_tokens=4))
+        t = obj._pipeline.last_timings
+        assert t.groups == 4 and t.ttft > 0 and t.vit > 0
+    assert outs[0] == outs[1] and outs[0][0].count("<tok_") == 4
+    assert "total time spent on prefill was" in capsys.readouterr().out

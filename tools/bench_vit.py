@@ -1,0 +1,20 @@
+"""ViT front-end micro-benchmark (one cfg2 group: 16 frames 560x1008 -> 23040 patches -> 5760 tokens)."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from quickvideo_amd.vit import QWEN2_VL_VIT_7B, VisionTower, VisionWeights, patchify_frames
+dev = torch.device("cuda:0")
+w = VisionWeights.synthetic(QWEN2_VL_VIT_7B, dev)
+tower = VisionTower(w)
+frames = torch.randint(0, 256, (16, 3, 560, 1008), dtype=torch.uint8, device=dev)
+def f():
+    rows, grid = patchify_frames(frames, w.spec)
+    return tower.forward(rows, grid)
+for _ in range(2): f()
+torch.cuda.synchronize()
+s, e = torch.cuda.Event(True), torch.cuda.Event(True)
+s.record()
+for _ in range(3): f()
+e.record(); torch.cuda.synchronize()
+ms = s.elapsed_time(e) / 3
+fl = w.spec.flops_per_patch() * 23040 + 32 * 8 * 16 * 4 * 2880 * 2880 * 80
+print(f"ViT group: {ms:.2f} ms, {fl/ms/1e9:.1f} TF (linear+attn flops {fl/1e12:.2f} T)")
