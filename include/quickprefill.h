@@ -75,7 +75,11 @@ int qp_rope_append(qp_ctx* ctx, const void* qkv, const void* cos, const void* si
 int qp_prefill_attn(qp_ctx* ctx, const void* q, const void* k_prefix, const void* v_prefix,
                     int64_t prefix_head_stride, int64_t prefix_len, const void* k_new, const void* v_new,
                     int64_t new_head_stride, int64_t n, int n_q_heads, int n_kv_heads, int head_dim, float scale,
-                    void* out, void* stream);
+                    void* out, void* workspace, size_t workspace_bytes, void* stream);
+/* Scratch for the kv-split partial results (work items of a ragged last round are cut along KV and merged by a combine
+ * kernel so every CU stays busy; small grids — few heads x few query blocks — are split the same way).  workspace may
+ * be NULL: the launch then runs unsplit. */
+size_t qp_attn_workspace_bytes(const qp_ctx* ctx, int64_t n, int64_t prefix_len, int n_q_heads, int n_kv_heads);
 
 /* ---- seam 1: key-norm scoring, k-smallest select, compaction  (utils.py:133-136, 266-342) ---- */
 /* Canonical per-head sum of squares of key rows k[h*head_stride + (row0+t)*head_dim ...], t<n ->

@@ -82,7 +82,8 @@ int qp_rope_append(qp_ctx* ctx, const void* qkv, const void* cos, const void* si
 
 int qp_prefill_attn(qp_ctx* ctx, const void* q, const void* k_prefix, const void* v_prefix, int64_t prefix_head_stride,
                     int64_t prefix_len, const void* k_new, const void* v_new, int64_t new_head_stride, int64_t n,
-                    int n_q_heads, int n_kv_heads, int head_dim, float scale, void* out, void* stream) {
+                    int n_q_heads, int n_kv_heads, int head_dim, float scale, void* out, void* workspace, size_t workspace_bytes,
+                    void* stream) {
   QP_REQUIRE(ctx && q && k_new && v_new && out, QP_ERR_INVALID, "qp_prefill_attn: NULL argument");
   QP_REQUIRE(head_dim == 128, QP_ERR_UNSUPPORTED, "qp_prefill_attn: head_dim=%d (only 128)", head_dim);
   QP_REQUIRE(n >= 0 && prefix_len >= 0, QP_ERR_INVALID, "qp_prefill_attn: negative length");
@@ -96,8 +97,14 @@ int qp_prefill_attn(qp_ctx* ctx, const void* q, const void* k_prefix, const void
              QP_ERR_INVALID, "qp_prefill_attn: pointers must be 16-byte aligned");
   QP_REQUIRE(n_q_heads <= 65535, QP_ERR_UNSUPPORTED, "qp_prefill_attn: too many heads");
   if (n == 0) return QP_OK;
+  QP_REQUIRE(workspace == nullptr || aligned16(workspace), QP_ERR_INVALID, "qp_prefill_attn: workspace must be 16-byte aligned");
   return qp_launch_prefill_attn(ctx, q, k_prefix, v_prefix, prefix_head_stride, prefix_len, k_new, v_new, new_head_stride, n,
-                                n_q_heads, n_kv_heads, scale, out, (hipStream_t)stream);
+                                n_q_heads, n_kv_heads, scale, out, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+size_t qp_attn_workspace_bytes(const qp_ctx* ctx, int64_t n, int64_t prefix_len, int n_q_heads, int n_kv_heads) {
+  if (!ctx || n <= 0 || n_q_heads <= 0 || n_kv_heads <= 0 || n_q_heads % n_kv_heads) return 0;
+  return qp_attn_workspace_bytes_impl(ctx, n, prefix_len, n_q_heads, n_kv_heads);
 }
 
 int qp_key_sumsq(qp_ctx* ctx, const void* k, int64_t head_stride, int64_t row0, int64_t n, int n_kv_heads, int head_dim,

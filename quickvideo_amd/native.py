@@ -40,7 +40,8 @@ SIGNATURES = {
     "qp_device_cus": (_i32, [_vp]),
     "qp_mrope_table": (_i32, [_vp, _vp, _i64, _c.POINTER(_c.c_int32), _f32, _i32, _vp, _vp, _vp]),
     "qp_rope_append": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _vp, _vp]),
-    "qp_prefill_attn": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _f32, _vp, _vp]),
+    "qp_prefill_attn": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _f32, _vp, _vp, _sz, _vp]),
+    "qp_attn_workspace_bytes": (_sz, [_vp, _i64, _i64, _i32, _i32]),
     "qp_key_sumsq": (_i32, [_vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _vp]),
     "qp_select_workspace_bytes": (_sz, [_i64]),
     "qp_select_k_smallest": (_i32, [_vp, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
@@ -84,6 +85,7 @@ class QuickPrefillOps:
         self._check(self.lib.qp_create(ctypes.byref(h), self.device.index or 0))
         self.ctx = h
         self._select_ws = torch.empty(int(self.lib.qp_select_workspace_bytes(65536)), dtype=torch.uint8, device=self.device)
+        self._attn_ws = None
 
     def __del__(self):
         try:
@@ -129,9 +131,13 @@ class QuickPrefillOps:
     # -- seam 3
     def prefill_attn(self, q, k_prefix, v_prefix, prefix_head_stride, prefix_len, k_new, v_new, new_head_stride, n, n_q, n_kv,
                      head_dim, scale, out):
+        need = int(self.lib.qp_attn_workspace_bytes(self.ctx, n, prefix_len, n_q, n_kv))
+        if self._attn_ws is None or self._attn_ws.numel() < need:          # caller-owned scratch, grown on demand
+            self._attn_ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=self.device)
         self._check(self.lib.qp_prefill_attn(self.ctx, q.data_ptr(), _ptr(k_prefix), _ptr(v_prefix), prefix_head_stride,
                                              prefix_len, k_new.data_ptr(), v_new.data_ptr(), new_head_stride, n, n_q, n_kv,
-                                             head_dim, float(scale), out.data_ptr(), self._stream()))
+                                             head_dim, float(scale), out.data_ptr(), self._attn_ws.data_ptr(),
+                                             self._attn_ws.numel(), self._stream()))
 
     # -- seam 1
     def key_sumsq(self, k, head_stride, row0, n, n_kv, head_dim, head_sumsq):

@@ -6,7 +6,7 @@ from quickvideo_amd.native import QuickPrefillOps
 
 D = 128
 ops = QuickPrefillOps(torch.device("cuda:0"))
-variants = sys.argv[1:] or ["1", "2"]
+variants = sys.argv[1:] or ["0", "1"]
 shapes = [(5760, 0, 28, 4), (5760, 2887, 28, 4), (5760, 8647, 28, 4), (2240, 100000, 28, 4), (960, 15000, 8, 1)]
 if os.environ.get("QP_SHAPES") == "small":
     shapes = shapes[:3]
