@@ -13,6 +13,25 @@ import torch
 from .spec import TextSpec
 
 
+def tp_head_partition(hq: int, hkv: int, tp_rank: int, tp_size: int):
+    """(q head indices of this rank — -1 marks a zero pad head —, first kv head, number of local kv heads).
+
+    hkv % tp == 0: kv heads sharded, each rank takes the q heads of its kv heads.  Otherwise tp % hkv == 0: every kv
+    head is replicated on rep = tp/hkv consecutive ranks and its `group` q heads are dealt out ceil(group/rep) per
+    rank, padded with zero heads (Qwen2-VL-7B at TP=8: 28 q / 4 kv heads -> ranks get 4+3(+1 pad) q heads)."""
+    group = hq // hkv
+    if hkv % tp_size == 0:
+        lkv = hkv // tp_size
+        kv_lo = tp_rank * lkv
+        return list(range(kv_lo * group, (kv_lo + lkv) * group)), kv_lo, lkv
+    assert tp_size % hkv == 0, "n_kv_heads and tp_size must divide one another"
+    rep = tp_size // hkv
+    kvh, sub = tp_rank // rep, tp_rank % rep
+    per = -(-group // rep)
+    idx = [kvh * group + sub * per + i if sub * per + i < group else -1 for i in range(per)]
+    return idx, kvh, 1
+
+
 @dataclass
 class LayerWeights:
     ln1: torch.Tensor        # [d]
@@ -57,16 +76,17 @@ class DecoderWeights:
             raise KeyError(names[0])
 
         D, hq, hkv, I = spec.head_dim, spec.n_heads, spec.n_kv_heads, spec.intermediate
-        assert hq % tp_size == 0 and I % tp_size == 0, "tensor-parallel degree must divide heads and intermediate size"
-        # KV heads: shard when divisible, replicate otherwise (7B has 4 KV heads: TP=8 replicates each on 2 ranks)
-        lq = hq // tp_size
-        q_lo = tp_rank * lq
-        if hkv % tp_size == 0:
-            lkv = hkv // tp_size; kv_lo = tp_rank * lkv
-        else:
-            assert tp_size % hkv == 0, "n_kv_heads and tp_size must divide one another"
-            lkv = 1; kv_lo = tp_rank // (tp_size // hkv)
+        assert I % tp_size == 0, "tensor-parallel degree must divide the intermediate size"
+        q_idx, kv_lo, lkv = tp_head_partition(hq, hkv, tp_rank, tp_size)
         li = I // tp_size; i_lo = tp_rank * li
+
+        def q_rows(w):            # rows of a [hq*D, ...] matrix / vector for this rank's q heads (zero rows for pad heads)
+            parts = [w[h * D:(h + 1) * D] if h >= 0 else torch.zeros_like(w[:D]) for h in q_idx]
+            return torch.cat(parts, 0)
+
+        def q_cols(w):            # columns of o_proj [d, hq*D]
+            parts = [w[:, h * D:(h + 1) * D] if h >= 0 else torch.zeros_like(w[:, :D]) for h in q_idx]
+            return torch.cat(parts, 1)
         to = lambda t: t.to(device=device, dtype=dtype).contiguous()
         layers = []
         for l in range(spec.n_layers):
@@ -75,12 +95,12 @@ class DecoderWeights:
             qw, kw, vw = g(*a("q_proj.weight")), g(*a("k_proj.weight")), g(*a("v_proj.weight"))
             qb, kb, vb = g(*a("q_proj.bias")), g(*a("k_proj.bias")), g(*a("v_proj.bias"))
             ow = g(*a("o_proj.weight"))
-            w_qkv = torch.cat([qw[q_lo * D:(q_lo + lq) * D], kw[kv_lo * D:(kv_lo + lkv) * D], vw[kv_lo * D:(kv_lo + lkv) * D]], 0)
-            b_qkv = torch.cat([qb[q_lo * D:(q_lo + lq) * D], kb[kv_lo * D:(kv_lo + lkv) * D], vb[kv_lo * D:(kv_lo + lkv) * D]], 0)
+            w_qkv = torch.cat([q_rows(qw), kw[kv_lo * D:(kv_lo + lkv) * D], vw[kv_lo * D:(kv_lo + lkv) * D]], 0)
+            b_qkv = torch.cat([q_rows(qb), kb[kv_lo * D:(kv_lo + lkv) * D], vb[kv_lo * D:(kv_lo + lkv) * D]], 0)
             gw, uw, dw = g(p + "mlp.gate_proj.weight"), g(p + "mlp.up_proj.weight"), g(p + "mlp.down_proj.weight")
             layers.append(LayerWeights(
                 ln1=to(g(p + "input_layernorm.weight")), w_qkv=to(w_qkv), b_qkv=to(b_qkv),
-                w_o=to(ow[:, q_lo * D:(q_lo + lq) * D]), ln2=to(g(p + "post_attention_layernorm.weight")),
+                w_o=to(q_cols(ow)), ln2=to(g(p + "post_attention_layernorm.weight")),
                 w_gate_up=to(torch.cat([gw[i_lo:i_lo + li], uw[i_lo:i_lo + li]], 0)), w_down=to(dw[:, i_lo:i_lo + li])))
         embed = to(g("embed_tokens.weight"))
         lm = embed if spec.tie_embeddings and "lm_head.weight" not in sd else to(g("lm_head.weight"))
@@ -92,9 +112,9 @@ class DecoderWeights:
         """Seeded random weights at the real dims, generated on the device (no checkpoint offline).
         Under TP every rank draws only its own shard (seeded by (seed, layer, rank))."""
         D, hq, hkv, I, d = spec.head_dim, spec.n_heads, spec.n_kv_heads, spec.intermediate, spec.hidden
-        assert hq % tp_size == 0 and I % tp_size == 0
-        lq = hq // tp_size
-        lkv = hkv // tp_size if hkv % tp_size == 0 else 1
+        assert I % tp_size == 0
+        q_idx, _, lkv = tp_head_partition(hq, hkv, tp_rank, tp_size)
+        lq = len(q_idx)
         li = I // tp_size
         gen = torch.Generator(device=device)
 

@@ -112,7 +112,7 @@ def test_local_attention_off_engine():
 
 
 # ---------------------------------------------------------------- tensor parallel over gloo (world_size 2)
-def _tp_worker(rank, world, port, ret):
+def _tp_worker(rank, world, port, ret, hq=4, hkv=2):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
@@ -120,8 +120,8 @@ def _tp_worker(rank, world, port, ret):
     from quickvideo_amd.lvu_config import LVUConfig
     from quickvideo_amd.spec import TextSpec
     from quickvideo_amd.weights import DecoderWeights
-    so = O.TextSpec(hidden=512, n_heads=4, n_kv_heads=2, head_dim=128, intermediate=512, n_layers=2, vocab=128)
-    spec = TextSpec(hidden=512, n_heads=4, n_kv_heads=2, head_dim=128, intermediate=512, n_layers=2, vocab=128)
+    so = O.TextSpec(hidden=512, n_heads=hq, n_kv_heads=hkv, head_dim=128, intermediate=512, n_layers=2, vocab=128)
+    spec = TextSpec(hidden=512, n_heads=hq, n_kv_heads=hkv, head_dim=128, intermediate=512, n_layers=2, vocab=128)
     w = {k: v.to(torch.bfloat16) for k, v in O.synthetic_text_weights(so, seed=5, norm_jitter=0.1).items()}
     rs = np.random.RandomState(9)
     T, groups = 60, [24, 24]
@@ -165,3 +165,21 @@ def test_tensor_parallel_gloo_world2():
     assert np.array_equal(ret["logits0"], ret["logits1"])
     ref = ret["ref_logits"]
     assert np.max(np.abs(ret["logits0"] - ref)) <= 4e-2
+
+
+def test_tensor_parallel_gloo_world4_replicated_kv_heads():
+    """tp > n_kv_heads: every kv head replicated on 2 ranks, its 3 q heads dealt 2 + 1(+1 zero pad head) — the layout
+    Qwen2-VL-7B (28 q / 4 kv heads) needs at TP=8."""
+    from quickvideo_amd.weights import tp_head_partition
+    assert [tp_head_partition(28, 4, r, 8)[0] for r in (0, 1, 7)] == [[0, 1, 2, 3], [4, 5, 6, -1], [25, 26, 27, -1]]
+    assert tp_head_partition(64, 8, 3, 8) == (list(range(24, 32)), 3, 1)
+    port = 31500 + os.getpid() % 2000
+    ret = mp.Manager().dict()
+    mp.spawn(_tp_worker, args=(4, port, ret, 6, 2), nprocs=4, join=True)
+    assert ret["heads0"] == ret["heads3"] == (2, 1, 128)
+    assert ret["len0"] == ret["len1"] == ret["len2"] == ret["len3"] == ret["ref_len"]
+    for r in (1, 2, 3):
+        for a, b in zip(ret["kept0"], ret[f"kept{r}"]):
+            assert (a is None) == (b is None) and (a is None or np.array_equal(a, b))
+        assert np.array_equal(ret["logits0"], ret[f"logits{r}"])
+    assert np.max(np.abs(ret["logits0"] - ret["ref_logits"])) <= 4e-2
