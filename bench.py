@@ -261,9 +261,13 @@ def main():
         att_ms, att_n = tot["prefill_attn"]
         att_local = att / world                                  # heads are sharded under TP
         ach = att_local / (att_ms * 1e-3) / 1e12
-        roofline = {"kernel": "attn_fwd_kernel (MFMA prefill attention over pruned prefix + causal tail)", "bound": "mfma",
+        traffic = None            # HBM bytes per launch from the committed rocprofv3 PMC passes (tools/profile_bench.sh), same command
+        tpath = os.path.join(ROOT, "profiles", "attn_pmc_traffic_latest.json")
+        if args.config == "cfg2" and world == 1 and os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("attn_fwd_kernel_s4", {}).get("traffic_bytes_per_launch")
+        roofline = {"kernel": "attn_fwd_kernel_s4 (MFMA prefill attention over pruned prefix + causal tail)", "bound": "mfma",
                     "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                    "traffic": None, "launches": att_n, "avg_launch_ms": round(att_ms / max(att_n, 1), 4),
+                    "traffic": traffic, "launches": att_n, "avg_launch_ms": round(att_ms / max(att_n, 1), 4),
                     "algorithmic_flops_per_step": att_local}
         pr_ms = tot["select_k_smallest"][0] + tot["gather_kv"][0]
         if pr_ms > 0:
