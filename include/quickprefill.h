@@ -126,6 +126,18 @@ int qp_add_inplace(qp_ctx* ctx, void* h, const void* delta, int64_t n_elems, voi
 /* gate_up bf16 [n][2*inter] (gate columns then up columns) -> out[n][inter] = bf16(bf16(silu(g)) * u). */
 int qp_swiglu(qp_ctx* ctx, const void* gate_up, int64_t n, int inter, void* out, void* stream);
 
+/* ---- vision front end (transformers Qwen2VisionTransformerPretrainedModel [3P]) ---------------
+ * The ViT tower itself runs on PyTorch-ROCm (quickvideo_amd/vit.py); these three entry points replace its non-GEMM ops.
+ * qkv bf16 [n][3][heads][head_dim] = output of the fused qkv projection of one block (n = n_seq * S tokens).        */
+/* 2-D rotary of q and k in place (apply_rotary_pos_emb_vision: fp32 math, one rounding).  cos/sin fp32 [n][head_dim/2]. */
+int qp_vit_rope(qp_ctx* ctx, void* qkv, const float* cos, const float* sin, int64_t n, int heads, int head_dim, void* stream);
+/* Full (non-causal) attention inside each of the n_seq sequences of S tokens (one per temporal patch: cu_seqlens of the
+ * reference), head_dim 80, MFMA kernel shared with qp_prefill_attn.  out bf16 [n][heads][80]. */
+int qp_vit_attn(qp_ctx* ctx, const void* qkv, int64_t n_seq, int64_t seq_len, int heads, int head_dim, float scale, void* out,
+                void* stream);
+/* out = y * sigmoid(1.702 y) with torch's bf16 rounding steps (hidden_act = quick_gelu). */
+int qp_quick_gelu(qp_ctx* ctx, const void* x, void* out, int64_t n_elems, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

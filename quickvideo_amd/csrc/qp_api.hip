@@ -218,4 +218,30 @@ int qp_swiglu(qp_ctx* ctx, const void* gate_up, int64_t n, int inter, void* out,
   return qp_launch_swiglu(gate_up, n, inter, out, (hipStream_t)stream);
 }
 
+int qp_vit_rope(qp_ctx* ctx, void* qkv, const float* cos, const float* sin, int64_t n, int heads, int head_dim, void* stream) {
+  QP_REQUIRE(ctx && qkv && cos && sin, QP_ERR_INVALID, "qp_vit_rope: NULL argument");
+  QP_REQUIRE(n >= 0 && heads > 0 && head_dim > 0 && head_dim % 16 == 0, QP_ERR_INVALID, "qp_vit_rope: head_dim=%d must be a multiple of 16", head_dim);
+  QP_REQUIRE(aligned16(qkv), QP_ERR_INVALID, "qp_vit_rope: alignment");
+  if (n == 0) return QP_OK;
+  return qp_launch_vit_rope(qkv, cos, sin, n, heads, head_dim, (hipStream_t)stream);
+}
+
+int qp_vit_attn(qp_ctx* ctx, const void* qkv, int64_t n_seq, int64_t seq_len, int heads, int head_dim, float scale, void* out,
+                void* stream) {
+  QP_REQUIRE(ctx && qkv && out, QP_ERR_INVALID, "qp_vit_attn: NULL argument");
+  QP_REQUIRE(head_dim == 80, QP_ERR_UNSUPPORTED, "qp_vit_attn: head_dim=%d (only 80)", head_dim);
+  QP_REQUIRE(n_seq >= 0 && seq_len >= 0 && heads > 0 && n_seq * heads <= 65535, QP_ERR_INVALID, "qp_vit_attn: bad sizes");
+  QP_REQUIRE(seq_len * 3 * heads * head_dim * 2 < (1ll << 31), QP_ERR_UNSUPPORTED, "qp_vit_attn: sequence too long");
+  QP_REQUIRE(aligned16(qkv) && aligned16(out), QP_ERR_INVALID, "qp_vit_attn: alignment");
+  if (n_seq == 0 || seq_len == 0) return QP_OK;
+  return qp_launch_vit_attn(ctx, qkv, n_seq, seq_len, heads, scale, out, (hipStream_t)stream);
+}
+
+int qp_quick_gelu(qp_ctx* ctx, const void* x, void* out, int64_t n_elems, void* stream) {
+  QP_REQUIRE(ctx && x && out, QP_ERR_INVALID, "qp_quick_gelu: NULL argument");
+  QP_REQUIRE(n_elems >= 0 && n_elems % 8 == 0 && aligned16(x) && aligned16(out), QP_ERR_INVALID, "qp_quick_gelu: size/alignment");
+  if (n_elems == 0) return QP_OK;
+  return qp_launch_quick_gelu(x, out, n_elems, (hipStream_t)stream);
+}
+
 }  // extern "C"

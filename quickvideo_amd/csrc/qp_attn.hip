@@ -37,6 +37,10 @@ struct AttnParams {
   int n_whole;                  // first n_whole items of a kv head run unsplit; the rest are cut into `nsplit` kv ranges
   int nsplit;
   float* ws;                    // partial results of split items (kPartialFloats floats each)
+  // batched non-causal mode (ViT tower: D = 80, one sequence per temporal patch, q/k/v interleaved in one qkv row):
+  int heads_per_seq;            // "kv head" index = seq * heads_per_seq + head
+  int64_t seq_stride16;         // uint4 between consecutive sequences (K/V and Q)
+  int kv_row_bytes;             // byte stride between consecutive K/V (and Q) rows
 };
 
 __device__ __forceinline__ bf16x8_t lds_read_b128(const unsigned char* lds, int off) {
@@ -57,8 +61,11 @@ __device__ __forceinline__ float xhalf_sum(float x) {
 // ------------------------------------------------------------------------------------------------
 // Production kernel.  kXcd: 1-D grid with the XCD/kv-head mapping (needs 8 % Hkv == 0); otherwise grid = (items, Hkv).
 // ------------------------------------------------------------------------------------------------
-template <bool kXcd>
+template <bool kXcd, int D, bool kVit>
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel_s4(AttnParams p) {
+  constexpr int KSTEPS = D / 16;                          // 16-wide contraction steps of QK^T
+  constexpr int NDB = (D + 31) / 32;                      // 32-wide d blocks of O^T
+  constexpr int SLOTS = D / 8;                            // 16-B slots per K/V row
   __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * kKV * kD * 2];
   unsigned char* kl = lds;
   unsigned char* vl = lds + kKV * kD * 2;
@@ -88,16 +95,21 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel_s4(AttnParams p) {
 
   int blk_end = qb * kQB + kQB;
   if (blk_end > n) blk_end = n;
-  const int ntp = (P + kKV - 1) / kKV, ntt = (blk_end + kKV - 1) / kKV, nt = ntp + ntt;
+  const int ntp = (P + kKV - 1) / kKV, ntt = kVit ? 0 : (blk_end + kKV - 1) / kKV, nt = ntp + ntt;
   int ti_lo = 0, ti_hi = nt;
   if (partial) { ti_lo = (int)((int64_t)split * nt / p.nsplit); ti_hi = (int)((int64_t)(split + 1) * nt / p.nsplit); }
-  const __amdgpu_buffer_rsrc_t rkp = __builtin_amdgcn_make_buffer_rsrc((void*)(p.kp + (int64_t)kvh * p.pre_hs16), 0, P * 256, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rvp = __builtin_amdgcn_make_buffer_rsrc((void*)(p.vp + (int64_t)kvh * p.pre_hs16), 0, P * 256, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rkn = __builtin_amdgcn_make_buffer_rsrc((void*)(p.kn + (int64_t)kvh * p.new_hs16), 0, n * 256, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rvn = __builtin_amdgcn_make_buffer_rsrc((void*)(p.vn + (int64_t)kvh * p.new_hs16), 0, n * 256, 0x00020000);
+  const int row_bytes = kVit ? p.kv_row_bytes : 256;
+  const int seq = kVit ? kvh / p.heads_per_seq : 0;
+  const int64_t kv_base16 = kVit ? (int64_t)seq * p.seq_stride16 + (int64_t)(kvh % p.heads_per_seq) * SLOTS : (int64_t)kvh * p.pre_hs16;
+  const __amdgpu_buffer_rsrc_t rkp = __builtin_amdgcn_make_buffer_rsrc((void*)(p.kp + kv_base16), 0, P * row_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rvp = __builtin_amdgcn_make_buffer_rsrc((void*)(p.vp + kv_base16), 0, P * row_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rkn = __builtin_amdgcn_make_buffer_rsrc((void*)(p.kn + (int64_t)kvh * p.new_hs16), 0, kVit ? 0 : n * 256, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rvn = __builtin_amdgcn_make_buffer_rsrc((void*)(p.vn + (int64_t)kvh * p.new_hs16), 0, kVit ? 0 : n * 256, 0x00020000);
 
   const int r0 = tid >> 4, slot16 = tid & 15;            // this thread's rows r0 + 16*it, 16-B slot
-  const int src_off = r0 * 256 + slot16 * 16;
+  const int src_off = r0 * row_bytes + slot16 * 16;
+  const int it_bytes = 16 * row_bytes;                    // rows advance by 16 per `it`
+  const bool ld_on = slot16 < SLOTS;                      // D = 80: slots 10..15 of the 256-B LDS rows stay unused
   const int kdst = r0 * 256 + ((slot16 ^ (r0 & 15)) << 4);                                           // + it*4096
   const int vdst = (((r0 >> 2) * 4 + (slot16 >> 2)) << 8) + ((r0 & 3) << 6) + ((slot16 & 3) << 4);   // + it*4096
   int koff[8];                                            // LDS read addresses (tile independent)
@@ -105,31 +117,34 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel_s4(AttnParams p) {
   for (int kk = 0; kk < 8; ++kk) koff[kk] = l31 * 256 + (((kk * 2 + hi) ^ (l31 & 15)) << 4);         // + kb*8192
   const int voff = (((lane & 15) >> 2) << 6) + (((lane >> 4) & 1) << 5) + ((lane & 3) << 3) + (hi << 10);
 
-  bf16x8_t qf[8];
+  bf16x8_t qf[KSTEPS];
   {
     const int qrow = qi < n ? qi : n - 1;
-    const uint4* qp = p.q + ((int64_t)qrow * p.hq + head) * 16;
+    const uint4* qp = kVit ? p.q + (int64_t)seq * p.seq_stride16 + (int64_t)qrow * (row_bytes / 16) + (int64_t)(kvh % p.heads_per_seq) * SLOTS
+                           : p.q + ((int64_t)qrow * p.hq + head) * 16;
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) qf[kk] = __builtin_bit_cast(bf16x8_t, qp[kk * 2 + hi]);
+    for (int kk = 0; kk < KSTEPS; ++kk) qf[kk] = __builtin_bit_cast(bf16x8_t, qp[kk * 2 + hi]);
   }
-  f32x16_t o[4];
+  f32x16_t o[NDB];
 #pragma unroll
-  for (int db = 0; db < 4; ++db) o[db] = (f32x16_t){0};
+  for (int db = 0; db < NDB; ++db) o[db] = (f32x16_t){0};
   float m_run = -1e30f, l_run = 0.f;
   const float c = p.c;
 
   for (int ti = ti_lo; ti < ti_hi; ++ti) {
-    const bool pre = ti < ntp;
+    const bool pre = kVit || ti < ntp;
     const int t0 = (pre ? ti : ti - ntp) * kKV;
     const int seg_len = pre ? P : n;
     {
-      const int soff = t0 * 256;
+      const int soff = t0 * row_bytes;
       u32x4_t kv[4], vv[4];
       if (pre) {
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-          kv[it] = __builtin_amdgcn_raw_buffer_load_b128(rkp, src_off + it * 4096, soff, 0);
-          vv[it] = __builtin_amdgcn_raw_buffer_load_b128(rvp, src_off + it * 4096, soff, 0);
+          if (SLOTS == 16 || ld_on) {
+            kv[it] = __builtin_amdgcn_raw_buffer_load_b128(rkp, src_off + it * it_bytes, soff, 0);
+            vv[it] = __builtin_amdgcn_raw_buffer_load_b128(rvp, src_off + it * it_bytes, soff, 0);
+          }
         }
       } else {
 #pragma unroll
@@ -139,10 +154,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel_s4(AttnParams p) {
         }
       }
       __syncthreads();                                  // everyone is done reading the previous tile
+      if (SLOTS == 16 || ld_on) {
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        *reinterpret_cast<u32x4_t*>(kl + kdst + it * 4096) = kv[it];
-        *reinterpret_cast<u32x4_t*>(vl + vdst + it * 4096) = vv[it];
+        for (int it = 0; it < 4; ++it) {
+          *reinterpret_cast<u32x4_t*>(kl + kdst + it * 4096) = kv[it];
+          *reinterpret_cast<u32x4_t*>(vl + vdst + it * 4096) = vv[it];
+        }
       }
       __syncthreads();
     }
@@ -153,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel_s4(AttnParams p) {
     for (int kb = 0; kb < 2; ++kb) {
       s[kb] = (f32x16_t){0};
 #pragma unroll
-      for (int kk = 0; kk < 8; ++kk) {
+      for (int kk = 0; kk < KSTEPS; ++kk) {
         bf16x8_t a = lds_read_b128(kl, koff[kk] + kb * 8192);
         s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[kk], s[kb], 0, 0, 0);
       }
@@ -183,7 +200,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel_s4(AttnParams p) {
       m_run = m_new;
       l_run *= alpha;
 #pragma unroll
-      for (int db = 0; db < 4; ++db)
+      for (int db = 0; db < NDB; ++db)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
     }
@@ -207,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel_s4(AttnParams p) {
 #pragma unroll
       for (int cc = 0; cc < 2; ++cc) {
 #pragma unroll
-        for (int db = 0; db < 4; ++db) {
+        for (int db = 0; db < NDB; ++db) {
           const int off = voff + (((kb * 8 + cc * 4) * 4 + db) << 8);     // 4-key row group kq = kb*8 + cc*4 + hi
           s16x4_t v0 = lds_read_tr16(vl, off);
           s16x4_t v1 = lds_read_tr16(vl, off + (2 * 4 << 8));             // +8 keys = +2 row groups
@@ -222,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel_s4(AttnParams p) {
     float* w = p.ws + ((int64_t)(kvh * (p.items - p.n_whole) + (item - p.n_whole)) * p.nsplit + split) * kPartialFloats;
     float* wo = w + wave * 64 * 64 + lane;
 #pragma unroll
-    for (int db = 0; db < 4; ++db)
+    for (int db = 0; db < NDB; ++db)
 #pragma unroll
       for (int r = 0; r < 16; ++r) wo[(db * 16 + r) * 64] = o[db][r];
     float* wm = w + 4 * 64 * 64 + wave * 128 + lane;
@@ -231,20 +248,24 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel_s4(AttnParams p) {
   }
   if (qi < n) {
     const float inv = 1.0f / l_run;
-    uint2* op = p.out + ((int64_t)qi * p.hq + head) * 32;     // 32 x 8 B per 128-wide row
+    // LLM: out [n][hq][128]; ViT: out [seq][S][heads][D]  (D/4 x 8 B per row)
+    uint2* op = kVit ? p.out + (((int64_t)seq * n + qi) * p.heads_per_seq + (kvh % p.heads_per_seq)) * (D / 4)
+                     : p.out + ((int64_t)qi * p.hq + head) * 32;
 #pragma unroll
-    for (int db = 0; db < 4; ++db)
+    for (int db = 0; db < NDB; ++db)
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
         bf16x4_t v = {(__bf16)(o[db][r4 * 4 + 0] * inv), (__bf16)(o[db][r4 * 4 + 1] * inv), (__bf16)(o[db][r4 * 4 + 2] * inv),
                       (__bf16)(o[db][r4 * 4 + 3] * inv)};
-        op[db * 8 + r4 * 2 + hi] = __builtin_bit_cast(uint2, v);   // d = db*32 + 8*r4 + 4*hi
+        if (db * 32 + 8 * r4 + 4 * hi < D) op[db * 8 + r4 * 2 + hi] = __builtin_bit_cast(uint2, v);   // d = db*32 + 8*r4 + 4*hi
       }
   }
 }
 
 // merges the kv-split partials of one item: O = sum_s O_s 2^{(m_s-M)c} / sum_s l_s 2^{(m_s-M)c}
+template <int D, bool kVit>
 __global__ __launch_bounds__(256) void attn_combine_kernel(AttnParams p) {
+  constexpr int NDB = (D + 31) / 32;
   const int n_split_items = p.items - p.n_whole;
   const int kvh = blockIdx.x / n_split_items, it = blockIdx.x % n_split_items;
   const int item = p.n_whole + it;
@@ -256,9 +277,9 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(AttnParams p) {
   float M = -1e30f;
   for (int s = 0; s < p.nsplit; ++s) M = fmaxf(M, base[(int64_t)s * kPartialFloats + 4 * 64 * 64 + wave * 128 + lane]);
   float L = 0.f;
-  float acc[64];
+  float acc[NDB * 16];
 #pragma unroll
-  for (int r = 0; r < 64; ++r) acc[r] = 0.f;
+  for (int r = 0; r < NDB * 16; ++r) acc[r] = 0.f;
   for (int s = 0; s < p.nsplit; ++s) {
     const float* w = base + (int64_t)s * kPartialFloats;
     const float ms = w[4 * 64 * 64 + wave * 128 + lane], ls = w[4 * 64 * 64 + wave * 128 + 64 + lane];
@@ -266,18 +287,19 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(AttnParams p) {
     L += ls * f;
     const float* wo = w + wave * 64 * 64 + lane;
 #pragma unroll
-    for (int r = 0; r < 64; ++r) acc[r] = __builtin_fmaf(wo[r * 64], f, acc[r]);
+    for (int r = 0; r < NDB * 16; ++r) acc[r] = __builtin_fmaf(wo[r * 64], f, acc[r]);
   }
   if (qi < (int)p.n) {
     const float inv = 1.0f / L;
-    uint2* op = p.out + ((int64_t)qi * p.hq + head) * 32;
+    uint2* op = kVit ? p.out + (((int64_t)(kvh / p.heads_per_seq) * p.n + qi) * p.heads_per_seq + (kvh % p.heads_per_seq)) * (D / 4)
+                     : p.out + ((int64_t)qi * p.hq + head) * 32;
 #pragma unroll
-    for (int db = 0; db < 4; ++db)
+    for (int db = 0; db < NDB; ++db)
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
         bf16x4_t v = {(__bf16)(acc[db * 16 + r4 * 4 + 0] * inv), (__bf16)(acc[db * 16 + r4 * 4 + 1] * inv),
                       (__bf16)(acc[db * 16 + r4 * 4 + 2] * inv), (__bf16)(acc[db * 16 + r4 * 4 + 3] * inv)};
-        op[db * 8 + r4 * 2 + hi] = __builtin_bit_cast(uint2, v);
+        if (db * 32 + 8 * r4 + 4 * hi < D) op[db * 8 + r4 * 2 + hi] = __builtin_bit_cast(uint2, v);
       }
   }
 }
@@ -475,6 +497,7 @@ int qp_launch_prefill_attn(const qp_ctx* ctx, const void* q, const void* k_prefi
   p.hq = hq; p.group = hq / hkv; p.c = scale * 1.4426950408889634f;
   p.nqb = (int)((n + kQB - 1) / kQB); p.hkv = hkv; p.ws = (float*)workspace;
   p.items = p.nqb * p.group; p.n_whole = p.items; p.nsplit = 1;
+  p.heads_per_seq = hkv; p.seq_stride16 = 0; p.kv_row_bytes = 256;
   const char* var = getenv("QP_ATTN_VARIANT");        // developer A/B switch (tools/bench_attn.py); default = production kernel
   const int variant = var ? atoi(var) : 0;
   const bool big = prefix_len * 256 >= (1ll << 31) || n * 256 >= (1ll << 31);
@@ -493,15 +516,36 @@ int qp_launch_prefill_attn(const qp_ctx* ctx, const void* q, const void* k_prefi
   const bool xcd = (hkv <= 8 && 8 % hkv == 0 && variant != 3);
   if (xcd) {
     const int G = 8 / hkv;
-    attn_fwd_kernel_s4<true><<<dim3(8 * ((per_kvh + G - 1) / G)), 256, 0, s>>>(p);
+    attn_fwd_kernel_s4<true, 128, false><<<dim3(8 * ((per_kvh + G - 1) / G)), 256, 0, s>>>(p);
   } else {
-    attn_fwd_kernel_s4<false><<<dim3((unsigned)per_kvh, (unsigned)hkv), 256, 0, s>>>(p);
+    attn_fwd_kernel_s4<false, 128, false><<<dim3((unsigned)per_kvh, (unsigned)hkv), 256, 0, s>>>(p);
   }
   int rc = qp_check_launch("prefill_attn");
   if (rc) return rc;
   if (a.nsplit > 1) {
-    attn_combine_kernel<<<dim3((unsigned)(hkv * (a.items - a.n_whole))), 256, 0, s>>>(p);
+    attn_combine_kernel<128, false><<<dim3((unsigned)(hkv * (a.items - a.n_whole))), 256, 0, s>>>(p);
     rc = qp_check_launch("prefill_attn(combine)");
   }
   return rc;
+}
+
+// Batched non-causal attention of the ViT tower: qkv bf16 [n_seq*S][3][H][80] (after the rotary), out [n_seq*S][H][80].
+// Every (sequence, head) pair is its own "kv head" with one q head; 2-D grid, no kv split (n_seq*H*ceil(S/128) workgroups
+// is several rounds of the chip for the video shapes).
+int qp_launch_vit_attn(const qp_ctx* ctx, const void* qkv, int64_t n_seq, int64_t S, int heads, float scale, void* out,
+                       hipStream_t s) {
+  (void)ctx;
+  constexpr int D = 80;
+  AttnParams p;
+  const uint4* base = (const uint4*)qkv;
+  const int row16 = 3 * heads * D / 8;
+  p.q = base; p.kp = base + heads * D / 8; p.vp = base + 2 * heads * D / 8; p.kn = p.kp; p.vn = p.vp;
+  p.out = (uint2*)out; p.pre_hs16 = 0; p.new_hs16 = 0; p.P = S; p.n = S;
+  const int hk = (int)(n_seq * heads);
+  p.hq = hk; p.group = 1; p.c = scale * 1.4426950408889634f;
+  p.nqb = (int)((S + kQB - 1) / kQB); p.hkv = hk; p.ws = nullptr;
+  p.heads_per_seq = heads; p.seq_stride16 = S * row16; p.kv_row_bytes = row16 * 16;
+  p.items = p.nqb; p.n_whole = p.nqb; p.nsplit = 1;
+  attn_fwd_kernel_s4<false, D, true><<<dim3((unsigned)p.nqb, (unsigned)hk), 256, 0, s>>>(p);
+  return qp_check_launch("vit_attn");
 }

@@ -114,3 +114,76 @@ int qp_launch_swiglu(const void* gate_up, int64_t n, int inter, void* out, hipSt
   swiglu_kernel<<<(int)blocks, 256, 0, s>>>((const uint4*)gate_up, n, inter / 8, (uint4*)out);
   return qp_check_launch("swiglu");
 }
+
+// ------------------------------------------------------------------------------------------------
+// ViT front-end glue (transformers Qwen2-VL vision tower [3P]): 2-D rotary on q,k of the fused qkv projection and
+// quick-GELU.  qkv bf16 [n][3][H][hd]; cos/sin fp32 [n][hd/2] (the tower's rotary table; both halves of a head use
+// the same angles).  Like apply_rotary_pos_emb_vision the rotation is done in fp32 and rounded once.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void vit_rope_kernel(uint4* __restrict__ qkv, const float* __restrict__ cos_t,
+                                                       const float* __restrict__ sin_t, int64_t n, int heads, int half8) {
+  // one thread per (token, q|k, head, 8-element chunk of the first half); partner chunk = +half elements
+  const int64_t per_tok = 2ll * heads * half8;
+  const int64_t total = n * per_tok;
+  const int row16 = 3 * heads * half8 * 2;                    // uint4 per token row
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t t = i / per_tok;
+    int r = (int)(i - t * per_tok);
+    const int c = r % half8; r /= half8;
+    const int h = r % heads; const int which = r / heads;      // 0 = q, 1 = k
+    const int64_t base = t * row16 + ((int64_t)which * heads + h) * (2 * half8) + c;
+    uint4 a = qkv[base], b = qkv[base + half8];
+    unsigned aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w}, ao[4], bo[4];
+    const float* cs = cos_t + t * (half8 * 8) + c * 8;
+    const float* sn = sin_t + t * (half8 * 8) + c * 8;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      float x0 = __uint_as_float(aw[w] << 16), x1 = __uint_as_float(aw[w] & 0xffff0000u);
+      float y0 = __uint_as_float(bw[w] << 16), y1 = __uint_as_float(bw[w] & 0xffff0000u);
+      float c0 = cs[2 * w], c1 = cs[2 * w + 1], s0 = sn[2 * w], s1 = sn[2 * w + 1];
+      // first half: x*cos + (-y)*sin ; second half: y*cos + x*sin
+      // separately rounded fp32 mul / mul / add like the torch ops (no fma contraction)
+      ao[w] = (unsigned)f32_to_bf16_bits(__fadd_rn(__fmul_rn(x0, c0), __fmul_rn(-y0, s0))) |
+              ((unsigned)f32_to_bf16_bits(__fadd_rn(__fmul_rn(x1, c1), __fmul_rn(-y1, s1))) << 16);
+      bo[w] = (unsigned)f32_to_bf16_bits(__fadd_rn(__fmul_rn(y0, c0), __fmul_rn(x0, s0))) |
+              ((unsigned)f32_to_bf16_bits(__fadd_rn(__fmul_rn(y1, c1), __fmul_rn(x1, s1))) << 16);
+    }
+    qkv[base] = make_uint4(ao[0], ao[1], ao[2], ao[3]);
+    qkv[base + half8] = make_uint4(bo[0], bo[1], bo[2], bo[3]);
+  }
+}
+
+int qp_launch_vit_rope(void* qkv, const float* cos_t, const float* sin_t, int64_t n, int heads, int head_dim, hipStream_t s) {
+  const int half8 = head_dim / 16;
+  int64_t total = n * 2 * heads * half8;
+  int64_t blocks = (total + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (blocks < 1) blocks = 1;
+  vit_rope_kernel<<<(int)blocks, 256, 0, s>>>((uint4*)qkv, cos_t, sin_t, n, heads, half8);
+  return qp_check_launch("vit_rope");
+}
+
+// out = bf16( y * bf16(sigmoid(bf16(1.702*y))) )  — torch's `y * torch.sigmoid(1.702 * y)` on bf16 tensors
+__global__ __launch_bounds__(256) void quick_gelu_kernel(const uint4* __restrict__ x, uint4* __restrict__ out, int64_t n16) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) {
+    uint4 v = x[i];
+    unsigned w[4] = {v.x, v.y, v.z, v.w}, o[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      float lo = __uint_as_float(w[k] << 16), hi = __uint_as_float(w[k] & 0xffff0000u);
+      float tl = round_bf16(1.702f * lo), th = round_bf16(1.702f * hi);
+      float sl = round_bf16(1.0f / (1.0f + __expf(-tl))), sh = round_bf16(1.0f / (1.0f + __expf(-th)));
+      o[k] = (unsigned)f32_to_bf16_bits(lo * sl) | ((unsigned)f32_to_bf16_bits(hi * sh) << 16);
+    }
+    out[i] = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+
+int qp_launch_quick_gelu(const void* x, void* out, int64_t n_elems, hipStream_t s) {
+  int64_t n16 = n_elems / 8;
+  int64_t blocks = (n16 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (blocks < 1) blocks = 1;
+  quick_gelu_kernel<<<(int)blocks, 256, 0, s>>>((const uint4*)x, (uint4*)out, n16);
+  return qp_check_launch("quick_gelu");
+}

@@ -52,6 +52,9 @@ SIGNATURES = {
     "qp_add_rmsnorm": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
     "qp_add_inplace": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "qp_swiglu": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp]),
+    "qp_vit_rope": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "qp_vit_attn": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _f32, _vp, _vp]),
+    "qp_quick_gelu": (_i32, [_vp, _vp, _vp, _i64, _vp]),
 }
 
 
@@ -177,3 +180,13 @@ class QuickPrefillOps:
     def swiglu(self, gate_up, out):
         n, two_i = gate_up.shape
         self._check(self.lib.qp_swiglu(self.ctx, gate_up.data_ptr(), n, two_i // 2, out.data_ptr(), self._stream()))
+
+    # -- vision front end
+    def vit_rope(self, qkv, cos, sin, heads, head_dim):
+        self._check(self.lib.qp_vit_rope(self.ctx, qkv.data_ptr(), cos.data_ptr(), sin.data_ptr(), qkv.shape[0], heads, head_dim, self._stream()))
+
+    def vit_attn(self, qkv, n_seq, seq_len, heads, head_dim, scale, out):
+        self._check(self.lib.qp_vit_attn(self.ctx, qkv.data_ptr(), n_seq, seq_len, heads, head_dim, float(scale), out.data_ptr(), self._stream()))
+
+    def quick_gelu(self, x, out):
+        self._check(self.lib.qp_quick_gelu(self.ctx, x.data_ptr(), out.data_ptr(), x.numel(), self._stream()))

@@ -105,10 +105,20 @@ class _Producer(threading.Thread):
 class PrefillPipeline:
     def __init__(self, model: QwenVLNative, config: LVUConfig, processor, ops=None):
         self.model, self.cfg, self.processor, self.ops = model, config, processor, ops
-        self.tower = VisionTower(model.vision)
         self.use_gpu = model.device.type == "cuda"
+        self._tower = None
         self.vit_stream = torch.cuda.Stream(model.device) if self.use_gpu else None
         self.last_timings: Optional[Timings] = None
+
+    @property
+    def tower(self) -> VisionTower:
+        if self._tower is None:
+            ops = self.ops
+            if ops is None and self.use_gpu:
+                from .native import QuickPrefillOps
+                ops = self.ops = QuickPrefillOps(self.model.device)
+            self._tower = VisionTower(self.model.vision, ops=ops if self.use_gpu else None)
+        return self._tower
 
     # ------------------------------------------------------------------ planning (no pixels needed)
     def plan(self, reader, question: str):

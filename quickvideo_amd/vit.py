@@ -127,8 +127,11 @@ def _rotate_half(x):
 class VisionTower:
     """Stateless forward over VisionWeights; runs on whatever device the weights live on (MI355X in the product)."""
 
-    def __init__(self, weights: VisionWeights):
+    def __init__(self, weights: VisionWeights, ops=None):
+        """ops: quickvideo_amd.native.QuickPrefillOps -> rotary / attention / quick-GELU run as HIP kernels
+        (qp_vit_rope, qp_vit_attn, qp_quick_gelu; head_dim 80 only); None -> the same math in plain torch ops."""
         self.w, self.spec = weights, weights.spec
+        self.ops = ops if (ops is not None and weights.spec.head_dim == 80 and hasattr(ops, "vit_attn")) else None
 
     @torch.no_grad()
     def forward(self, pixel_rows: torch.Tensor, grid_thw: Tuple[int, int, int]) -> torch.Tensor:
@@ -144,21 +147,32 @@ class VisionTower:
         emb = torch.cat((rot, rot), dim=-1)
         cos, sin = emb.cos()[:, None, :], emb.sin()[:, None, :]                         # fp32 [n, 1, head_dim]
         H, hd = s.num_heads, s.head_dim
+        ops = self.ops
+        if ops is not None:
+            cos_h, sin_h = rot.cos().contiguous(), rot.sin().contiguous()                # fp32 [n, head_dim/2]
         for b in w.blocks:
             y = F.layer_norm(x, (s.embed_dim,), b.ln1_w, b.ln1_b, 1e-6)
-            qkv = F.linear(y, b.qkv_w, b.qkv_b).view(n, 3, H, hd)
-            q, k, v = qkv[:, 0], qkv[:, 1], qkv[:, 2]
-            qf, kf = q.float(), k.float()
-            q = (qf * cos + _rotate_half(qf) * sin).to(x.dtype)
-            k = (kf * cos + _rotate_half(kf) * sin).to(x.dtype)
-            # one attention sequence per temporal patch: [t, H, seq, hd]
-            q4, k4, v4 = (z.reshape(t, seq, H, hd).transpose(1, 2) for z in (q, k, v))
-            a = F.scaled_dot_product_attention(q4, k4, v4, is_causal=False)
-            a = a.transpose(1, 2).reshape(n, H * hd)
+            qkv = F.linear(y, b.qkv_w, b.qkv_b)                                          # [n, 3*H*hd]
+            if ops is not None:
+                ops.vit_rope(qkv, cos_h, sin_h, H, hd)                                   # q, k rotated in place
+                a = torch.empty(n, H * hd, dtype=x.dtype, device=x.device)
+                ops.vit_attn(qkv, t, seq, H, hd, hd ** -0.5, a)                          # one sequence per temporal patch
+            else:
+                qkv = qkv.view(n, 3, H, hd)
+                q, k, v = qkv[:, 0], qkv[:, 1], qkv[:, 2]
+                qf, kf = q.float(), k.float()
+                q = (qf * cos + _rotate_half(qf) * sin).to(x.dtype)
+                k = (kf * cos + _rotate_half(kf) * sin).to(x.dtype)
+                q4, k4, v4 = (z.reshape(t, seq, H, hd).transpose(1, 2) for z in (q, k, v))   # [t, H, seq, hd]
+                a = F.scaled_dot_product_attention(q4, k4, v4, is_causal=False)
+                a = a.transpose(1, 2).reshape(n, H * hd)
             x = x + F.linear(a, b.proj_w, b.proj_b)
             y = F.layer_norm(x, (s.embed_dim,), b.ln2_w, b.ln2_b, 1e-6)
             y = F.linear(y, b.fc1_w, b.fc1_b)
-            y = y * torch.sigmoid(1.702 * y)                                             # quick_gelu
+            if ops is not None:
+                ops.quick_gelu(y, y)
+            else:
+                y = y * torch.sigmoid(1.702 * y)                                         # quick_gelu
             x = x + F.linear(y, b.fc2_w, b.fc2_b)
         y = F.layer_norm(x, (s.embed_dim,), w.ln_q_w, w.ln_q_b, 1e-6).view(-1, s.embed_dim * s.spatial_merge_size ** 2)
         y = F.gelu(F.linear(y, w.m1_w, w.m1_b))

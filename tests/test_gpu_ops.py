@@ -262,3 +262,43 @@ def test_error_behaviour(ops):
         ops.prefill_attn(q, None, None, 0, 0, q, q, 4 * D, 4, 3, 2, D, 1.0, q)     # 3 q heads over 2 kv heads
     with pytest.raises(QuickPrefillError):
         ops.prefill_attn(q, None, None, 0, 0, q, q, 4 * 64, 4, 2, 1, 64, 1.0, q)   # head_dim 64 unsupported
+
+
+def test_vit_kernels_match_torch_path(ops):
+    """ViT front end: HIP rotary / batched non-causal attention (head_dim 80) / quick-GELU vs the plain-torch tower
+    (which tests/test_vit_cpu.py pins to transformers' Qwen2-VL vision model)."""
+    from quickvideo_amd.vit import VisionSpec, VisionTower, VisionWeights
+    spec = VisionSpec(depth=2, embed_dim=1280, num_heads=16, mlp_ratio=4.0, out_hidden=256)
+    w = VisionWeights.synthetic(spec, "cuda:0", seed=4, std=0.03)
+    rs = np.random.RandomState(2)
+    for grid in ((3, 10, 14), (2, 28, 40), (1, 2, 2)):
+        n = grid[0] * grid[1] * grid[2]
+        rows = torch.from_numpy(rs.standard_normal((n, spec.patch_dim)).astype(np.float32)).to(torch.bfloat16).cuda()
+        ref = VisionTower(w).forward(rows, grid).float()
+        got = VisionTower(w, ops=ops).forward(rows, grid).float()
+        torch.cuda.synchronize()
+        assert torch.isfinite(got).all()
+        err = (got - ref).abs()
+        assert err.max().item() <= 2e-2 * ref.abs().max().item(), err.max().item()   # bf16 tower: <= ~2 bf16 ulps of the output scale
+    # operator-level: rotary is exact vs the fp32 formula; attention within the attention tolerance
+    H, hd, t, S = 16, 80, 3, 200
+    n = t * S
+    qkv = torch.from_numpy(rs.standard_normal((n, 3 * H * hd)).astype(np.float32)).to(torch.bfloat16).cuda()
+    ang = torch.from_numpy(rs.uniform(0, 50, (n, hd // 2)).astype(np.float32)).cuda()
+    cos, sin = ang.cos().contiguous(), ang.sin().contiguous()
+    q0 = qkv.view(n, 3, H, hd)[:, :2].float()
+    c, s_ = torch.cat([cos, cos], -1)[:, None, None], torch.cat([sin, sin], -1)[:, None, None]
+    rot = torch.cat((-q0[..., hd // 2:], q0[..., :hd // 2]), -1)
+    want = (q0 * c + rot * s_).to(torch.bfloat16)
+    buf = qkv.clone()
+    ops.vit_rope(buf, cos, sin, H, hd)
+    assert torch.equal(buf.view(n, 3, H, hd)[:, :2], want) and torch.equal(buf.view(n, 3, H, hd)[:, 2], qkv.view(n, 3, H, hd)[:, 2])
+    out = torch.empty(n, H * hd, dtype=torch.bfloat16, device="cuda")
+    ops.vit_attn(buf, t, S, H, hd, hd ** -0.5, out)
+    q4, k4, v4 = (buf.view(t, S, 3, H, hd)[:, :, i].transpose(1, 2).float() for i in range(3))
+    ref = torch.softmax(q4 @ k4.transpose(-1, -2) * hd ** -0.5, -1) @ v4
+    err = (out.view(t, S, H, hd).transpose(1, 2).float() - ref).abs()
+    assert (err <= 1.5e-2 + 1.5e-2 * ref.abs()).all(), err.max().item()
+    y = torch.from_numpy(rs.standard_normal((77, 5120)).astype(np.float32) * 3).to(torch.bfloat16).cuda()
+    g = torch.empty_like(y); ops.quick_gelu(y, g)
+    assert torch.equal(g, y * torch.sigmoid(1.702 * y))

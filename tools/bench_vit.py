@@ -4,7 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from quickvideo_amd.vit import QWEN2_VL_VIT_7B, VisionTower, VisionWeights, patchify_frames
 dev = torch.device("cuda:0")
 w = VisionWeights.synthetic(QWEN2_VL_VIT_7B, dev)
-tower = VisionTower(w)
+from quickvideo_amd.native import QuickPrefillOps
+tower = VisionTower(w, ops=QuickPrefillOps(dev) if os.environ.get('QP_VIT_OPS','1')=='1' else None)
 frames = torch.randint(0, 256, (16, 3, 560, 1008), dtype=torch.uint8, device=dev)
 def f():
     rows, grid = patchify_frames(frames, w.spec)
