@@ -302,3 +302,62 @@ def test_vit_kernels_match_torch_path(ops):
     y = torch.from_numpy(rs.standard_normal((77, 5120)).astype(np.float32) * 3).to(torch.bfloat16).cuda()
     g = torch.empty_like(y); ops.quick_gelu(y, g)
     assert torch.equal(g, y * torch.sigmoid(1.702 * y))
+
+
+@pytest.mark.parametrize("n,P,hq,hkv", [(5760, 8647, 28, 4), (2240, 60000, 28, 4), (960, 7000, 8, 1), (5775, 0, 12, 2)])
+def test_prefill_attn_full_size_properties(ops, n, P, hq, hkv):
+    """BASELINE.json sizes (cfg2 / cfg4 / cfg5-per-rank / 2B): the production kernel (XCD map + kv split + deferred rescale)
+    vs (a) the independent v1 kernel on every element and (b) an fp32 torch reference on the last 256 query rows;
+    plus linearity in V (attention is linear in V for fixed q, k): attn(q,k,2v) == 2 attn(q,k,v) up to bf16 rounding."""
+    g = torch.Generator(device="cuda"); g.manual_seed(n + P)
+    q = torch.randn(n, hq, D, generator=g, device="cuda").to(torch.bfloat16)
+    k = torch.randn(hkv, P + n, D, generator=g, device="cuda").to(torch.bfloat16)
+    v = torch.randn(hkv, P + n, D, generator=g, device="cuda").to(torch.bfloat16)
+    run = lambda vv, out: ops.prefill_attn(q, k, vv, (P + n) * D, P, k[:, P:], vv[:, P:], (P + n) * D, n, hq, hkv, D, D ** -0.5, out)
+    out = torch.empty(n, hq, D, dtype=torch.bfloat16, device="cuda"); run(v, out)
+    os.environ["QP_ATTN_VARIANT"] = "1"
+    try:
+        out1 = torch.empty_like(out); run(v, out1)
+    finally:
+        del os.environ["QP_ATTN_VARIANT"]
+    torch.cuda.synchronize()
+    assert torch.isfinite(out.float()).all()
+    assert (out.float() - out1.float()).abs().max().item() <= 8e-3          # two independent kernels, bf16 outputs |o| < ~1
+    out2 = torch.empty_like(out); run(v * 2, out2)
+    assert (out2.float() - 2 * out.float()).abs().max().item() <= 2e-2
+    rows = slice(n - 256, n)
+    grp = hq // hkv
+    kk, vv = k.repeat_interleave(grp, 0).float(), v.repeat_interleave(grp, 0).float()
+    sc = torch.einsum("rhd,hkd->hrk", q[rows].float(), kk) * D ** -0.5
+    ii = torch.arange(n - 256, n, device="cuda")[:, None] + P
+    sc = sc.masked_fill(torch.arange(P + n, device="cuda")[None, :] > ii, float("-inf"))
+    ref = torch.einsum("hrk,hkd->rhd", torch.softmax(sc, -1), vv)
+    err = (out[rows].float() - ref).abs()
+    assert (err <= 1.5e-2 + 1.5e-2 * ref.abs()).all(), err.max().item()
+
+
+def test_prune_full_size_round_trip(ops):
+    """cfg2 group size: select + gather then a second select on the kept rows with k' = k must return the identity
+    (idempotence), and the kept rows must equal an index_select of the staging rows (checksum of checksums)."""
+    n, k, hkv = 5775, 2887, 4
+    g = torch.Generator(device="cuda"); g.manual_seed(7)
+    ks = (torch.randn(hkv, n, D, generator=g, device="cuda") * torch.rand(1, n, 1, generator=g, device="cuda")).to(torch.bfloat16)
+    vs = torch.randn(hkv, n, D, generator=g, device="cuda").to(torch.bfloat16)
+    ss = torch.empty(hkv, n, dtype=torch.float32, device="cuda")
+    ops.key_sumsq(ks, n * D, 0, n, hkv, D, ss)
+    idx = torch.empty(k, dtype=torch.int32, device="cuda"); nb = torch.empty(n, dtype=torch.int16, device="cuda")
+    ops.select_k_smallest(ss, hkv, n, k, idx, nb)
+    kc = torch.zeros(hkv, k + 5, D, dtype=torch.bfloat16, device="cuda"); vc = torch.zeros_like(kc)
+    ops.gather_kv(ks, vs, n * D, idx, k, hkv, D, kc, vc, (k + 5) * D, 0)
+    torch.cuda.synchronize()
+    il = idx.long()
+    assert torch.all(il[1:] > il[:-1]) and torch.equal(kc[:, :k], ks[:, il]) and torch.equal(vc[:, :k], vs[:, il])
+    norms = nb.view(torch.bfloat16).float()
+    tau = norms[il].max()
+    kept = torch.zeros(n, dtype=torch.bool, device="cuda"); kept[il] = True
+    assert torch.all(kept[norms < tau]) and not torch.any(kept[norms > tau])        # threshold property at full size
+    ss2 = torch.empty(hkv, k, dtype=torch.float32, device="cuda")
+    ops.key_sumsq(kc, (k + 5) * D, 0, k, hkv, D, ss2)
+    idx2 = torch.empty(k, dtype=torch.int32, device="cuda")
+    ops.select_k_smallest(ss2, hkv, k, k, idx2)
+    assert torch.equal(idx2.long(), torch.arange(k, device="cuda"))
