@@ -39,6 +39,7 @@ CONFIGS = {
     "cfg3": ("qwen2-vl-7b", 256, 280, 504, 32, 0.25, 15, 30),
     "cfg4s": ("qwen2-vl-7b", 720, 392, 560, 16, 0.5, 15, 30),     # 1/10 of the 1-hour video (100k tokens)
     "cfg4": ("qwen2-vl-7b", 7200, 392, 560, 16, 0.5, 15, 30),      # synthetic 1-hour video, ~1M vision tokens
+    "cfg5": ("qwen2-vl-72b", 512, 224, 420, 16, 0.5, 15, 30),      # 72B: TP=8 in BASELINE.json; also fits ONE MI355X (145 GB of 288 GB)
     "tiny": ("tiny", 16, 112, 168, 4, 0.5, 5, 7),
 }
 PEAK_BF16_TFLOPS = 2500.0     # dense MFMA peak, MI355X_MICROARCH.md
@@ -253,7 +254,7 @@ def main():
     roofline = None
     extra = {}
     if not args.no_kernel_timing:
-        timed = TimedOps(eng.ops, ["prefill_attn", "select_k_smallest", "gather_kv", "rope_append", "add_rmsnorm", "swiglu"])
+        timed = TimedOps(eng.ops, ["prefill_attn", "prune_staged", "rope_append", "add_rmsnorm", "swiglu"])
         real_ops, eng.ops = eng.ops, timed
         run_step(eng, plan, embeds, pos)
         eng.ops = real_ops
@@ -269,12 +270,12 @@ def main():
                     "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                     "traffic": traffic, "launches": att_n, "avg_launch_ms": round(att_ms / max(att_n, 1), 4),
                     "algorithmic_flops_per_step": att_local}
-        pr_ms = tot["select_k_smallest"][0] + tot["gather_kv"][0]
+        pr_ms = tot["prune_staged"][0]
         if pr_ms > 0:
             pb = prune_bytes / world if world > 1 else prune_bytes
-            extra["roofline_prune"] = {"kernels": "select_kernel + gather_kv_kernel", "bound": "hbm",
+            extra["roofline_prune"] = {"kernels": "prune_fused_kernel (select + gather, one launch)", "bound": "hbm",
                                        "achieved": round(pb / (pr_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                       "frac": round(pb / (pr_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "launches": tot["select_k_smallest"][1] * 2,
+                                       "frac": round(pb / (pr_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "launches": tot["prune_staged"][1],
                                        "ms_per_step": round(pr_ms, 3), "algorithmic_bytes_per_step": pb}
         extra["kernel_ms_per_step"] = {k: round(v[0], 3) for k, v in tot.items()}
 

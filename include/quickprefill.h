@@ -104,6 +104,12 @@ int qp_gather_kv(qp_ctx* ctx, const void* k_src, const void* v_src, int64_t src_
                  int64_t k, int n_kv_heads, int head_dim, void* k_dst, void* v_dst, int64_t dst_head_stride,
                  int64_t dst_row0, void* stream);
 
+/* qp_select_k_smallest + qp_gather_kv in ONE launch (the engine's prune step): every workgroup repeats the LDS-resident
+ * select on head_sumsq and moves its slice of the kept rows src -> dst; kept_idx_out / norm_bits_out as above. */
+int qp_prune_staged(qp_ctx* ctx, const float* head_sumsq, int n_heads_total, int64_t n, int64_t k, const void* k_src,
+                    const void* v_src, int64_t src_head_stride, int n_kv_heads, int head_dim, void* k_dst, void* v_dst,
+                    int64_t dst_head_stride, int64_t dst_row0, int32_t* kept_idx_out, uint16_t* norm_bits_out, void* stream);
+
 /* In-place drop-in for post_process_kv_cache's KV part on the arena (utils.py:266-342):
  * rows [past_len, past_len+n) are the group's new tokens; on return rows [past_len, past_len+k) hold the
  * kept ones in original order and kept_idx_out[k] lists them.  workspace >= qp_prune_workspace_bytes(). */

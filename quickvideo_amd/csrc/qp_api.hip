@@ -148,6 +148,26 @@ int qp_gather_kv(qp_ctx* ctx, const void* k_src, const void* v_src, int64_t src_
                              (hipStream_t)stream);
 }
 
+int qp_prune_staged(qp_ctx* ctx, const float* head_sumsq, int n_heads_total, int64_t n, int64_t k, const void* k_src,
+                    const void* v_src, int64_t src_head_stride, int n_kv_heads, int head_dim, void* k_dst, void* v_dst,
+                    int64_t dst_head_stride, int64_t dst_row0, int32_t* kept_idx_out, uint16_t* norm_bits_out, void* stream) {
+  QP_REQUIRE(ctx && head_sumsq && k_src && v_src && k_dst && v_dst && kept_idx_out, QP_ERR_INVALID, "qp_prune_staged: NULL argument");
+  QP_REQUIRE(head_dim == 128, QP_ERR_UNSUPPORTED, "qp_prune_staged: head_dim=%d (only 128)", head_dim);
+  QP_REQUIRE(n_heads_total > 0 && n_kv_heads > 0 && k > 0 && k <= n, QP_ERR_INVALID,
+             "qp_prune_staged: need 0 < k <= n, got k=%lld n=%lld", (long long)k, (long long)n);
+  QP_REQUIRE(n <= 65536, QP_ERR_UNSUPPORTED, "qp_prune_staged: n=%lld > 65536", (long long)n);
+  QP_REQUIRE(dst_row0 >= 0 && src_head_stride % 8 == 0 && dst_head_stride % 8 == 0 && dst_head_stride >= (dst_row0 + k) * head_dim,
+             QP_ERR_INVALID, "qp_prune_staged: bad strides");
+  QP_REQUIRE(aligned16(k_src) && aligned16(v_src) && aligned16(k_dst) && aligned16(v_dst), QP_ERR_INVALID, "qp_prune_staged: alignment");
+  hipStream_t s = (hipStream_t)stream;
+  int rc = qp_launch_prune_fused(head_sumsq, n_heads_total, n, k, k_src, v_src, src_head_stride, n_kv_heads, k_dst, v_dst,
+                                 dst_head_stride, dst_row0, kept_idx_out, norm_bits_out, ctx->cus, s);
+  if (rc != 1) return rc;
+  rc = qp_launch_select(head_sumsq, n_heads_total, n, k, kept_idx_out, norm_bits_out, nullptr, s);     // large n: two launches
+  if (rc) return rc;
+  return qp_launch_gather_kv(k_src, v_src, src_head_stride, kept_idx_out, k, n_kv_heads, k_dst, v_dst, dst_head_stride, dst_row0, s);
+}
+
 // workspace layout of qp_prune_tail: [head_sumsq fp32 Hkv*n][pad to 256][K rows Hkv*k*D bf16][V rows Hkv*k*D bf16]
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 

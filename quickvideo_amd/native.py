@@ -46,6 +46,7 @@ SIGNATURES = {
     "qp_select_workspace_bytes": (_sz, [_i64]),
     "qp_select_k_smallest": (_i32, [_vp, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
     "qp_gather_kv": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _i64, _vp]),
+    "qp_prune_staged": (_i32, [_vp, _vp, _i32, _i64, _i64, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     "qp_prune_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32]),
     "qp_prune_tail": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _vp, _vp, _sz, _vp]),
     "qp_gather_rows": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _vp]),
@@ -156,6 +157,12 @@ class QuickPrefillOps:
         self._check(self.lib.qp_gather_kv(self.ctx, k_src.data_ptr(), v_src.data_ptr(), src_head_stride, idx.data_ptr(), k, n_kv,
                                           head_dim, k_dst.data_ptr(), v_dst.data_ptr(), dst_head_stride, dst_row0,
                                           self._stream()))
+
+    def prune_staged(self, head_sumsq, n_heads_total, n, k, k_src, v_src, src_head_stride, n_kv, head_dim, k_dst, v_dst,
+                     dst_head_stride, dst_row0, kept_idx, norm_bits=None):
+        self._check(self.lib.qp_prune_staged(self.ctx, head_sumsq.data_ptr(), n_heads_total, n, k, k_src.data_ptr(), v_src.data_ptr(),
+                                             src_head_stride, n_kv, head_dim, k_dst.data_ptr(), v_dst.data_ptr(), dst_head_stride,
+                                             dst_row0, kept_idx.data_ptr(), _ptr(norm_bits), self._stream()))
 
     def prune_workspace_bytes(self, n, k, n_kv, head_dim) -> int:
         return int(self.lib.qp_prune_workspace_bytes(n, k, n_kv, head_dim))

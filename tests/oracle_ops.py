@@ -60,6 +60,11 @@ class OracleOps:
             self._rows(k_dst, h, dst_head_stride, dst_row0, k, D).copy_(self._rows(k_src, h, src_head_stride, 0, n_src, D)[ii])
             self._rows(v_dst, h, dst_head_stride, dst_row0, k, D).copy_(self._rows(v_src, h, src_head_stride, 0, n_src, D)[ii])
 
+    def prune_staged(self, head_sumsq, n_heads_total, n, k, k_src, v_src, src_head_stride, n_kv, D, k_dst, v_dst, dst_head_stride,
+                     dst_row0, kept_idx, norm_bits=None):
+        self.select_k_smallest(head_sumsq, n_heads_total, n, k, kept_idx)
+        self.gather_kv(k_src, v_src, src_head_stride, kept_idx, k, n_kv, D, k_dst, v_dst, dst_head_stride, dst_row0)
+
     def gather_rows(self, src, idx, k, row_bytes, dst):
         dst[:k].copy_(src[idx[:k].long()])
 

@@ -114,6 +114,13 @@ def test_prune_tail_inplace_and_staged(ops, golden_dir, ci):
     torch.cuda.synchronize()
     assert sha(dev_bits(kc2[:, :past + k])) == meta["k_sha"] and sha(dev_bits(vc2[:, :past + k])) == meta["v_sha"]
     assert torch.count_nonzero(kc2[:, past + k:]).item() == 0      # nothing written past the kept rows
+    # (c) the engine's fused single-launch form
+    kc3 = torch.zeros(hkv, cap, D, dtype=torch.bfloat16, device="cuda"); vc3 = torch.zeros_like(kc3)
+    idx3 = torch.empty(k, dtype=torch.int32, device="cuda"); nb3 = torch.zeros(n, dtype=torch.int16, device="cuda")
+    ops.prune_staged(ss, hkv, n, k, ks, vs, n * D, hkv, D, kc3, vc3, cap * D, past, idx3, nb3)
+    torch.cuda.synchronize()
+    assert torch.equal(idx3, idx2) and torch.equal(kc3[:, past:], kc2[:, past:]) and torch.equal(vc3[:, past:], vc2[:, past:])
+    assert np.array_equal(nb3.cpu().numpy().view(np.uint16), O.key_norms_bf16(ss.cpu().numpy()))
     # hidden-state pruning hand-off uses the same index list (utils.py:292-331)
     hid = torch.from_numpy(rs.standard_normal((1, n, 16)).astype(np.float32))[0]
     out = torch.empty(k, 16, dtype=torch.float32, device="cuda")
