@@ -9,10 +9,10 @@ from .models import lvu_chat_model_map, lvu_init_model_map, lvu_run_model_map
 from .pipeline import QwenVLNative
 from .processor import SyntheticProcessor
 from .spec import PRESETS
-from .vit import QWEN2_VL_VIT_2B, QWEN2_VL_VIT_72B, QWEN2_VL_VIT_7B, TINY_VIT, VisionWeights
+from .vit import QWEN25_VL_VIT_7B, QWEN2_VL_VIT_2B, QWEN2_VL_VIT_72B, QWEN2_VL_VIT_7B, TINY_VIT, VisionWeights
 from .weights import DecoderWeights
 
-_VIT = {"qwen2-vl-2b": QWEN2_VL_VIT_2B, "qwen2-vl-7b": QWEN2_VL_VIT_7B, "qwen2.5-vl-7b": QWEN2_VL_VIT_7B, "qwen2-vl-72b": QWEN2_VL_VIT_72B,
+_VIT = {"qwen2-vl-2b": QWEN2_VL_VIT_2B, "qwen2-vl-7b": QWEN2_VL_VIT_7B, "qwen2.5-vl-7b": QWEN25_VL_VIT_7B, "qwen2-vl-72b": QWEN2_VL_VIT_72B,
         "tiny": TINY_VIT}
 
 

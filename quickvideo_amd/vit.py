@@ -31,6 +31,12 @@ class VisionSpec:
     spatial_merge_size: int = 2
     in_channels: int = 3
     out_hidden: int = 3584          # LLM width
+    # Qwen2.5-VL tower (the reference's model family, lvu.py:60): RMSNorm, gated-SiLU MLP, windowed attention except in
+    # `fullatt_blocks`; arch "qwen2" = Qwen2-VL tower (LayerNorm, quick-GELU MLP, full attention per temporal patch).
+    arch: str = "qwen2"
+    intermediate: int = 3420
+    window_size: int = 112
+    fullatt_blocks: Tuple[int, ...] = (7, 15, 23, 31)
 
     @property
     def head_dim(self) -> int:
@@ -45,6 +51,7 @@ class VisionSpec:
         return 2.0 * (self.patch_dim * d + self.depth * (4 * d * d + 2 * d * m)) + 2.0 * (4 * d * 4 * d + 4 * d * self.out_hidden) / 4
 
 
+QWEN25_VL_VIT_7B = VisionSpec(arch="qwen2.5", out_hidden=3584)
 QWEN2_VL_VIT_7B = VisionSpec(out_hidden=3584)
 QWEN2_VL_VIT_2B = VisionSpec(out_hidden=1536)
 QWEN2_VL_VIT_72B = VisionSpec(out_hidden=8192)
@@ -85,6 +92,16 @@ class VisionBlockWeights:
 
 
 @dataclass
+class VisionBlockWeights25:
+    n1: torch.Tensor; n2: torch.Tensor                       # RMSNorm weights
+    qkv_w: torch.Tensor; qkv_b: torch.Tensor
+    proj_w: torch.Tensor; proj_b: torch.Tensor
+    gate_w: torch.Tensor; gate_b: torch.Tensor
+    up_w: torch.Tensor; up_b: torch.Tensor
+    down_w: torch.Tensor; down_b: torch.Tensor
+
+
+@dataclass
 class VisionWeights:
     spec: VisionSpec
     patch_w: torch.Tensor                 # [embed_dim, patch_dim]  (Conv3d weight flattened)
@@ -97,6 +114,16 @@ class VisionWeights:
     def from_named(spec: VisionSpec, sd: Dict[str, torch.Tensor], device, dtype=torch.bfloat16, prefix: str = "") -> "VisionWeights":
         g = lambda k: sd[prefix + k].to(device=device, dtype=dtype).contiguous()
         blocks = []
+        if spec.arch == "qwen2.5":
+            for i in range(spec.depth):
+                p = f"blocks.{i}."
+                blocks.append(VisionBlockWeights25(g(p + "norm1.weight"), g(p + "norm2.weight"), g(p + "attn.qkv.weight"), g(p + "attn.qkv.bias"),
+                                                   g(p + "attn.proj.weight"), g(p + "attn.proj.bias"), g(p + "mlp.gate_proj.weight"),
+                                                   g(p + "mlp.gate_proj.bias"), g(p + "mlp.up_proj.weight"), g(p + "mlp.up_proj.bias"),
+                                                   g(p + "mlp.down_proj.weight"), g(p + "mlp.down_proj.bias")))
+            return VisionWeights(spec, g("patch_embed.proj.weight").reshape(spec.embed_dim, -1).contiguous(), blocks,
+                                 g("merger.ln_q.weight"), None, g("merger.mlp.0.weight"), g("merger.mlp.0.bias"),
+                                 g("merger.mlp.2.weight"), g("merger.mlp.2.bias"))
         for i in range(spec.depth):
             p = f"blocks.{i}."
             blocks.append(VisionBlockWeights(g(p + "norm1.weight"), g(p + "norm1.bias"), g(p + "attn.qkv.weight"), g(p + "attn.qkv.bias"),
@@ -113,6 +140,12 @@ class VisionWeights:
         one = lambda n: torch.ones(n, device=device, dtype=dtype)
         zero = lambda n: torch.zeros(n, device=device, dtype=dtype)
         d, m, d4 = spec.embed_dim, int(spec.embed_dim * spec.mlp_ratio), spec.embed_dim * spec.spatial_merge_size ** 2
+        if spec.arch == "qwen2.5":
+            it = spec.intermediate
+            blocks = [VisionBlockWeights25(one(d), one(d), mat(3 * d, d), mat(3 * d), mat(d, d), mat(d), mat(it, d), mat(it), mat(it, d), mat(it),
+                                           mat(d, it), mat(d)) for _ in range(spec.depth)]
+            return VisionWeights(spec, mat(d, spec.patch_dim), blocks, one(d), None, mat(d4, d4), mat(d4), mat(spec.out_hidden, d4),
+                                 mat(spec.out_hidden))
         blocks = [VisionBlockWeights(one(d), zero(d), mat(3 * d, d), mat(3 * d), mat(d, d), mat(d), one(d), zero(d), mat(m, d), mat(m),
                                      mat(d, m), mat(d)) for _ in range(spec.depth)]
         return VisionWeights(spec, mat(d, spec.patch_dim), blocks, one(d), zero(d), mat(d4, d4), mat(d4), mat(spec.out_hidden, d4),
@@ -135,6 +168,8 @@ class VisionTower:
 
     @torch.no_grad()
     def forward(self, pixel_rows: torch.Tensor, grid_thw: Tuple[int, int, int]) -> torch.Tensor:
+        if self.spec.arch == "qwen2.5":
+            return self._forward_qwen25(pixel_rows, grid_thw)
         s, w = self.spec, self.w
         t, h, wd = grid_thw
         n, seq = pixel_rows.shape[0], h * wd
@@ -177,3 +212,81 @@ class VisionTower:
         y = F.layer_norm(x, (s.embed_dim,), w.ln_q_w, w.ln_q_b, 1e-6).view(-1, s.embed_dim * s.spatial_merge_size ** 2)
         y = F.gelu(F.linear(y, w.m1_w, w.m1_b))
         return F.linear(y, w.m2_w, w.m2_b)                                               # [n/4, out_hidden]
+
+
+    # ------------------------------------------------------------------ Qwen2.5-VL tower
+    @staticmethod
+    def window_index(grid_thw: Tuple[int, int, int], merge: int, window_size: int, patch_size: int, device):
+        """transformers get_vision_window_index [3P]: permutation of the merged (2x2) token units into window-major order
+        and the cumulative patch counts of the windows (ragged at the borders)."""
+        t, h, w = grid_thw
+        vw = window_size // merge // patch_size
+        lh, lw = h // merge, w // merge
+        idx = torch.arange(t * lh * lw).reshape(t, lh, lw)
+        ph, pw = vw - lh % vw, vw - lw % vw
+        nh, nw = (lh + ph) // vw, (lw + pw) // vw
+        pad = F.pad(idx, (0, pw, 0, ph), "constant", -100).reshape(t, nh, vw, nw, vw).permute(0, 1, 3, 2, 4).reshape(t, nh * nw, vw, vw)
+        seqlens = (pad != -100).sum([2, 3]).reshape(-1)
+        flat = pad.reshape(-1)
+        win = flat[flat != -100]
+        lens = seqlens[seqlens > 0] * merge * merge
+        return win.to(device), lens.to(device)
+
+    def _forward_qwen25(self, pixel_rows: torch.Tensor, grid_thw: Tuple[int, int, int]) -> torch.Tensor:
+        s, w = self.spec, self.w
+        t, h, wd = grid_thw
+        n, seq, unit = pixel_rows.shape[0], h * wd, s.spatial_merge_size ** 2
+        H, hd, d = s.num_heads, s.head_dim, s.embed_dim
+        x = F.linear(pixel_rows.to(w.patch_w.dtype), w.patch_w)
+        win, lens = self.window_index(grid_thw, s.spatial_merge_size, s.window_size, s.patch_size, x.device)
+        x = x.reshape(n // unit, unit, d)[win].reshape(n, d)                             # window-major token order
+        pos = vision_pos_ids(grid_thw, s.spatial_merge_size, x.device)
+        rd = hd // 2
+        inv_freq = 1.0 / (10000.0 ** (torch.arange(0, rd, 2, dtype=torch.float32, device=x.device) / rd))
+        rot = (pos.unsqueeze(-1).float() * inv_freq).flatten(1)
+        rot = rot.reshape(n // unit, unit, -1)[win].reshape(n, -1)
+        emb = torch.cat((rot, rot), dim=-1)
+        cos, sin = emb.cos()[:, None, :], emb.sin()[:, None, :]
+        ops = self.ops
+        if ops is not None:
+            cos_h, sin_h = rot.cos().contiguous(), rot.sin().contiguous()
+        # windows padded to the longest one: gather map [n_win, Lmax] (-1 = pad) for the windowed layers
+        nwin, lmax = lens.numel(), int(lens.max())
+        starts = torch.cumsum(lens, 0) - lens
+        ar = torch.arange(lmax, device=x.device)
+        wmap = starts[:, None] + ar[None, :]
+        wvalid = ar[None, :] < lens[:, None]
+        wmap = torch.where(wvalid, wmap, torch.zeros_like(wmap))
+        rms = lambda z, g: (z.float() * torch.rsqrt(z.float().pow(2).mean(-1, keepdim=True) + 1e-6)).to(z.dtype) * g
+        for li, b in enumerate(w.blocks):
+            y = rms(x, b.n1)
+            qkv = F.linear(y, b.qkv_w, b.qkv_b)
+            full = li in s.fullatt_blocks
+            if ops is not None:
+                ops.vit_rope(qkv, cos_h, sin_h, H, hd)
+            if ops is not None and full:
+                a = torch.empty(n, H * hd, dtype=x.dtype, device=x.device)
+                ops.vit_attn(qkv, t, seq, H, hd, hd ** -0.5, a)
+            else:
+                q3 = qkv.view(n, 3, H, hd)
+                q, k, v = q3[:, 0], q3[:, 1], q3[:, 2]
+                if ops is None:
+                    qf, kf = q.float(), k.float()
+                    q = (qf * cos + _rotate_half(qf) * sin).to(x.dtype)
+                    k = (kf * cos + _rotate_half(kf) * sin).to(x.dtype)
+                if full:
+                    q4, k4, v4 = (z.reshape(t, seq, H, hd).transpose(1, 2) for z in (q, k, v))
+                    a = F.scaled_dot_product_attention(q4, k4, v4).transpose(1, 2).reshape(n, H * hd)
+                else:                                                                  # ragged windows, padded + key mask
+                    q4, k4, v4 = (z[wmap].transpose(1, 2) for z in (q, k, v))          # [n_win, H, Lmax, hd]
+                    o = F.scaled_dot_product_attention(q4, k4, v4, attn_mask=wvalid[:, None, None, :])
+                    a = torch.empty(n, H, hd, dtype=x.dtype, device=x.device)
+                    a[wmap[wvalid]] = o.transpose(1, 2)[wvalid]
+                    a = a.reshape(n, H * hd)
+            x = x + F.linear(a, b.proj_w, b.proj_b)
+            y = rms(x, b.n2)
+            y = F.silu(F.linear(y, b.gate_w, b.gate_b)) * F.linear(y, b.up_w, b.up_b)
+            x = x + F.linear(y, b.down_w, b.down_b)
+        y = rms(x, w.ln_q_w).view(-1, d * unit)
+        y = F.linear(F.gelu(F.linear(y, w.m1_w, w.m1_b)), w.m2_w, w.m2_b)
+        return y[torch.argsort(win)]                                                   # back to raster (t, h/2, w/2) order

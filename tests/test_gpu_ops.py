@@ -368,3 +368,19 @@ def test_prune_full_size_round_trip(ops):
     idx2 = torch.empty(k, dtype=torch.int32, device="cuda")
     ops.select_k_smallest(ss2, hkv, k, k, idx2)
     assert torch.equal(idx2.long(), torch.arange(k, device="cuda"))
+
+
+def test_qwen25_tower_hip_vs_torch(ops):
+    """Qwen2.5-VL tower on the GPU: HIP rotary + full-attention layers vs the plain-torch tower (pinned to HF on CPU)."""
+    from quickvideo_amd.vit import VisionSpec, VisionTower, VisionWeights
+    spec = VisionSpec(arch="qwen2.5", depth=3, embed_dim=1280, num_heads=16, out_hidden=256, intermediate=3420, fullatt_blocks=(1,))
+    w = VisionWeights.synthetic(spec, "cuda:0", seed=9, std=0.03)
+    rs = np.random.RandomState(3)
+    for grid in ((2, 20, 28), (1, 6, 10)):
+        n = grid[0] * grid[1] * grid[2]
+        rows = torch.from_numpy(rs.standard_normal((n, spec.patch_dim)).astype(np.float32)).to(torch.bfloat16).cuda()
+        ref = VisionTower(w).forward(rows, grid).float()
+        got = VisionTower(w, ops=ops).forward(rows, grid).float()
+        torch.cuda.synchronize()
+        assert torch.isfinite(got).all()
+        assert (got - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()

@@ -58,3 +58,26 @@ def test_patchify_layout():
         assert np.allclose(rows[idx].numpy(), want, atol=1e-5)
     pos = vision_pos_ids(grid, 2, "cpu")
     assert pos[:6].tolist() == [[0, 0], [0, 1], [1, 0], [1, 1], [0, 2], [0, 3]]
+
+
+@pytest.mark.parametrize("grid", [(2, 8, 12), (1, 10, 6), (3, 4, 4), (1, 18, 22)])
+def test_qwen25_tower_matches_hf(grid):
+    """Qwen2.5-VL tower (the reference's model family): RMSNorm, gated-SiLU MLP, windowed attention + 4 full layers."""
+    from transformers.models.qwen2_5_vl.configuration_qwen2_5_vl import Qwen2_5_VLVisionConfig
+    from transformers.models.qwen2_5_vl.modeling_qwen2_5_vl import Qwen2_5_VisionTransformerPretrainedModel
+    spec = VisionSpec(arch="qwen2.5", depth=3, embed_dim=64, num_heads=4, out_hidden=96, intermediate=80, window_size=112, fullatt_blocks=(1,))
+    cfg = Qwen2_5_VLVisionConfig(depth=3, hidden_size=64, intermediate_size=80, num_heads=4, out_hidden_size=96, window_size=112,
+                                 fullatt_block_indexes=[1], patch_size=14, spatial_merge_size=2, temporal_patch_size=2, hidden_act="silu")
+    cfg._attn_implementation = "eager"
+    torch.manual_seed(5)
+    m = Qwen2_5_VisionTransformerPretrainedModel(cfg).eval().float()
+    for p in m.parameters():
+        torch.nn.init.normal_(p, std=0.05)
+    w = VisionWeights.from_named(spec, m.state_dict(), "cpu", dtype=torch.float32)
+    t, h, wd = grid
+    pix = torch.from_numpy(np.random.RandomState(1).standard_normal((t * h * wd, spec.patch_dim)).astype(np.float32))
+    with torch.no_grad():
+        ref = m(pix, grid_thw=torch.tensor([list(grid)])).pooler_output
+    got = VisionTower(w).forward(pix, grid)
+    assert got.shape == ref.shape
+    assert torch.allclose(got, ref, atol=3e-5, rtol=1e-4), (got - ref).abs().max()
