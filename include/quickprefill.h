@@ -93,7 +93,8 @@ size_t qp_select_workspace_bytes(int64_t n);
  * parallelism the all-gathered per-rank partials).  norm[t] = bf16(sqrt(((s0+s1)+s2)+...)).
  * kept_idx_out int32 [k]: the k smallest norms, ties -> lowest index, listed in ascending index order
  * (utils.py:136,191-194,284).  norm_bits_out (uint16 [n], may be NULL) receives the bf16 norms.
- * Requires 0 < k <= n <= 65536. */
+ * Requires 0 < k <= n.  n <= 65536: norms stay in LDS, workspace may be NULL; larger n (single-group baseline mode on
+ * long videos): pass a workspace of qp_select_workspace_bytes(n). */
 int qp_select_k_smallest(qp_ctx* ctx, const float* head_sumsq, int n_heads_total, int64_t n, int64_t k,
                          int32_t* kept_idx_out, uint16_t* norm_bits_out, void* workspace, size_t workspace_bytes,
                          void* stream);

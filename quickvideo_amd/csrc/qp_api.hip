@@ -118,7 +118,7 @@ int qp_key_sumsq(qp_ctx* ctx, const void* k, int64_t head_stride, int64_t row0, 
   return qp_launch_key_sumsq(k, head_stride, row0, n, n_kv_heads, head_sumsq, (hipStream_t)stream);
 }
 
-size_t qp_select_workspace_bytes(int64_t n) { (void)n; return 256; }
+size_t qp_select_workspace_bytes(int64_t n) { return n > 65536 ? (size_t)n * 2 + 256 : 256; }
 
 int qp_select_k_smallest(qp_ctx* ctx, const float* head_sumsq, int n_heads_total, int64_t n, int64_t k,
                          int32_t* kept_idx_out, uint16_t* norm_bits_out, void* workspace, size_t workspace_bytes,
@@ -127,9 +127,9 @@ int qp_select_k_smallest(qp_ctx* ctx, const float* head_sumsq, int n_heads_total
   QP_REQUIRE(n_heads_total > 0, QP_ERR_INVALID, "qp_select_k_smallest: n_heads_total=%d", n_heads_total);
   QP_REQUIRE(k > 0 && k <= n, QP_ERR_INVALID, "qp_select_k_smallest: need 0 < k <= n, got k=%lld n=%lld", (long long)k,
              (long long)n);
-  QP_REQUIRE(n <= 65536, QP_ERR_UNSUPPORTED, "qp_select_k_smallest: n=%lld > 65536", (long long)n);
-  QP_REQUIRE(workspace_bytes >= qp_select_workspace_bytes(n) || workspace == nullptr, QP_ERR_WORKSPACE,
-             "qp_select_k_smallest: workspace too small");
+  QP_REQUIRE(n < (1ll << 31), QP_ERR_UNSUPPORTED, "qp_select_k_smallest: n=%lld too large", (long long)n);
+  QP_REQUIRE(n <= 65536 || (workspace != nullptr && workspace_bytes >= qp_select_workspace_bytes(n)), QP_ERR_WORKSPACE,
+             "qp_select_k_smallest: n=%lld > 65536 needs a workspace of %zu bytes", (long long)n, qp_select_workspace_bytes(n));
   return qp_launch_select(head_sumsq, n_heads_total, n, k, kept_idx_out, norm_bits_out, workspace, (hipStream_t)stream);
 }
 

@@ -54,6 +54,11 @@ int qp_launch_key_sumsq(const void* k, int64_t head_stride, int64_t row0, int64_
 //   emits  {t : key<tau}  U  {first r ties of key==tau}.  No host round trip (the reference does
 //   .tolist() + torch.tensor + nonzero().cpu(): utils.py:136,191,284).
 // ------------------------------------------------------------------------------------------------
+// Correctly rounded fp32 square root.  hipcc's sqrtf/__fsqrt_rn can be 1 ulp off (measured: s = 262.03513 gave
+// 16.187498 instead of 16.1875, which flipped a bf16 round-to-even tie and with it a kept index); the fp64 square root
+// rounded once to fp32 is exact because sqrt of an fp32 value is never within 2^-48 of an fp32 rounding boundary.
+__device__ __forceinline__ float sqrt_rn_f32(float s) { return (float)sqrt((double)s); }
+
 __device__ __forceinline__ unsigned block_excl_scan_1024(unsigned v, unsigned* wave_tot, unsigned* total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   unsigned incl = v;
@@ -109,21 +114,25 @@ __device__ __forceinline__ void find_bucket_256(const unsigned* hist, int nh, in
   __syncthreads();
 }
 
+// kLds: norm patterns live in LDS (n <= 65536); otherwise in a caller-provided global scratch (any n: the one workgroup
+// then streams them from L2 a few times — the rarely used "single group" baseline mode of very long videos).
+template <bool kLds>
 __global__ __launch_bounds__(1024) void select_kernel(const float* __restrict__ head_sumsq, int n_heads, int n, int k,
-                                                      int32_t* __restrict__ kept, uint16_t* __restrict__ norm_bits_out) {
+                                                      int32_t* __restrict__ kept, uint16_t* __restrict__ norm_bits_out,
+                                                      uint16_t* __restrict__ keys_glb) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned* hist = (unsigned*)smem;            // 256
   unsigned* scan = hist + 256;                 // 256
   unsigned* wave_tot = scan + 256;             // 16
   unsigned* res = wave_tot + 16;               // 4
   unsigned* tot = res + 4;                     // 4
-  uint16_t* keys = (uint16_t*)(tot + 4);       // n
+  uint16_t* keys = kLds ? (uint16_t*)(tot + 4) : keys_glb;       // n
   const int tid = threadIdx.x;
 
   for (int t = tid; t < n; t += 1024) {
     float s = head_sumsq[t];
     for (int h = 1; h < n_heads; ++h) s = s + head_sumsq[(int64_t)h * n + t];
-    uint16_t b = f32_to_bf16_bits(__fsqrt_rn(s));
+    uint16_t b = f32_to_bf16_bits(sqrt_rn_f32(s));
     keys[t] = b;
     if (norm_bits_out) norm_bits_out[t] = b;
   }
@@ -186,7 +195,7 @@ __global__ __launch_bounds__(1024) void prune_fused_kernel(const float* __restri
   for (int t = tid; t < n; t += 1024) {
     float s = head_sumsq[t];
     for (int h = 1; h < n_heads; ++h) s = s + head_sumsq[(int64_t)h * n + t];
-    uint16_t b = f32_to_bf16_bits(__fsqrt_rn(s));
+    uint16_t b = f32_to_bf16_bits(sqrt_rn_f32(s));
     keys[t] = b;
     if (blockIdx.x == 0 && norm_bits_out) norm_bits_out[t] = b;
   }
@@ -260,15 +269,19 @@ static size_t select_smem_bytes(int64_t n) { return (256 + 256 + 16 + 4 + 4) * 4
 
 int qp_launch_select(const float* head_sumsq, int n_heads, int64_t n, int64_t k, int32_t* kept, uint16_t* norm_bits,
                      void* ws, hipStream_t s) {
-  (void)ws;
+  if (n > 65536) {
+    if (ws == nullptr) return qp_fail(QP_ERR_WORKSPACE, "select: n=%lld > 65536 needs a workspace of qp_select_workspace_bytes(n)", (long long)n);
+    select_kernel<false><<<1, 1024, select_smem_bytes(0), s>>>(head_sumsq, n_heads, (int)n, (int)k, kept, norm_bits, (uint16_t*)ws);
+    return qp_check_launch("select(global keys)");
+  }
   size_t smem = select_smem_bytes(n);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+    hipError_t e = hipFuncSetAttribute((const void*)select_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
     if (e != hipSuccess) return qp_fail(QP_ERR_HIP, "hipFuncSetAttribute(select): %s", hipGetErrorString(e));
     attr_set = true;
   }
-  select_kernel<<<1, 1024, smem, s>>>(head_sumsq, n_heads, (int)n, (int)k, kept, norm_bits);
+  select_kernel<true><<<1, 1024, smem, s>>>(head_sumsq, n_heads, (int)n, (int)k, kept, norm_bits, nullptr);
   return qp_check_launch("select");
 }
 

@@ -149,6 +149,9 @@ class QuickPrefillOps:
                                           self._stream()))
 
     def select_k_smallest(self, head_sumsq, n_heads_total, n, k, kept_idx, norm_bits=None):
+        need = int(self.lib.qp_select_workspace_bytes(n))
+        if self._select_ws.numel() < need:
+            self._select_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         self._check(self.lib.qp_select_k_smallest(self.ctx, head_sumsq.data_ptr(), n_heads_total, n, k, kept_idx.data_ptr(),
                                                   _ptr(norm_bits), self._select_ws.data_ptr(), self._select_ws.numel(),
                                                   self._stream()))

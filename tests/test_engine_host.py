@@ -119,3 +119,27 @@ def test_planner_matches_oracle():
         pa, da = planner.mrope_positions(p, g, t, temporal_scale=sc); pb, db = O.mrope_positions(p, g, t, temporal_scale=sc)
         assert np.array_equal(pa, pb) and da == db
     assert planner.video_frame_size(64, 1080, 1920) == O.video_frame_size(64, 1080, 1920) == (560, 1008)
+
+
+def test_decode_step_positions_match_tail_prefill():
+    """a10: greedy decode positions = original sequence index + rope_delta on all three streams (the reference keeps the
+    caller-supplied cache_position, qwen25_lvu.py:445-464).  Decoding the last prompt token must give the same logits as
+    prefetching it as part of the tail."""
+    spec_o, w, plan, pos, delta, embeds = make_case(8, 4, 6, 4, 5, 7)
+    cfg = LVUConfig("x", top_p=0.5, video_group_size=4)
+    T = embeds.shape[0]
+    post = torch.from_numpy(pos)
+
+    def run(split_last):
+        dw = DecoderWeights.from_named(TINY, w, "cpu")
+        eng = QuickPrefillEngine(dw, cfg, capacity=T + 8, max_group_tokens=32, device="cpu", ops=OracleOps())
+        st = 0
+        for n in plan.tokens:
+            eng.prefill_group(embeds[st:st + n], post[:, st:st + n]); st += n
+        if not split_last:
+            return eng.prefill_tail(embeds[st:], post[:, st:])
+        eng.prefill_tail(embeds[st:T - 1], post[:, st:T - 1])
+        return eng.decode_step(embeds[T - 1], delta)
+
+    a, b = run(False), run(True)
+    assert torch.allclose(a, b, atol=2e-2) and int(a.argmax()) == int(b.argmax())

@@ -63,7 +63,8 @@ def test_sumsq_select_bit_exact(ops, golden_dir, ci):
         assert np.array_equal(idx, data[f"c{ci}_ref_idx_stable"])
 
 
-@pytest.mark.parametrize("n,k,hkv", [(1, 1, 4), (2, 1, 2), (64, 64, 4), (1025, 1, 4), (5775, 2887, 4), (65536, 32768, 1), (40000, 39999, 2)])
+@pytest.mark.parametrize("n,k,hkv", [(1, 1, 4), (2, 1, 2), (64, 64, 4), (1025, 1, 4), (5775, 2887, 4), (65536, 32768, 1), (40000, 39999, 2),
+                                     (65537, 100, 1), (300000, 60000, 2)])
 def test_select_edge_sizes(ops, n, k, hkv):
     rs = np.random.RandomState(n + k)
     keys = torch.from_numpy(rs.standard_normal((hkv, n, D)).astype(np.float32)).to(torch.bfloat16)
@@ -262,8 +263,6 @@ def test_error_behaviour(ops):
         ops.select_k_smallest(ss, 4, 10, 0, idx)           # k must be > 0  (reference: "no prune" handled by the caller)
     with pytest.raises(ValueError):
         ops.select_k_smallest(ss, 4, 10, 11, idx)          # k > n
-    with pytest.raises(QuickPrefillError):
-        ops.select_k_smallest(ss, 4, 70000, 5, idx)        # unsupported size
     q = torch.zeros(4, 3, D, dtype=torch.bfloat16, device="cuda")
     with pytest.raises(ValueError):
         ops.prefill_attn(q, None, None, 0, 0, q, q, 4 * D, 4, 3, 2, D, 1.0, q)     # 3 q heads over 2 kv heads
@@ -384,3 +383,20 @@ def test_qwen25_tower_hip_vs_torch(ops):
         torch.cuda.synchronize()
         assert torch.isfinite(got).all()
         assert (got - ref).abs().max().item() <= 2e-2 * ref.abs().max().item()
+
+
+def test_norm_sqrt_is_correctly_rounded(ops):
+    """1M sums spread over the fp32 range incl. exact bf16 ties: norm patterns must equal the IEEE sqrt + RNE of the oracle."""
+    rs = np.random.RandomState(11)
+    n = 1 << 20
+    s0 = np.exp(rs.uniform(np.log(1e-6), np.log(1e6), n)).astype(np.float32)
+    # plant exact ties: squares of bf16 midpoints
+    mid = (O.bf16_bits_to_f32(rs.randint(0x3f80, 0x4300, 4096).astype(np.uint16)).astype(np.float64) * (1 + 2.0 ** -9)).astype(np.float32)
+    s0[:4096] = (mid.astype(np.float64) ** 2).astype(np.float32)
+    ss = torch.from_numpy(np.stack([s0, np.zeros_like(s0)])).cuda()
+    idx = torch.empty(8, dtype=torch.int32, device="cuda"); nb = torch.zeros(n, dtype=torch.int16, device="cuda")
+    ops.select_k_smallest(ss, 2, n, 8, idx, nb)
+    torch.cuda.synchronize()
+    ref = O.key_norms_bf16(ss.cpu().numpy())
+    assert np.array_equal(nb.cpu().numpy().view(np.uint16), ref)
+    assert np.array_equal(idx.cpu().numpy(), O.select_k_smallest(ref, 8))
