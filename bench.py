@@ -211,12 +211,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+    # QP_BENCH_SINGLE_DEVICE=1: developer hook to exercise the multi-process path on a 1-GPU box (all ranks on cuda:0, gloo
+    # collectives) — never used by the driver, numbers from it are meaningless.
+    single_dev = os.environ.get("QP_BENCH_SINGLE_DEVICE") == "1"
+    if single_dev:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     tp_group = None
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.distributed.init_process_group("nccl", device_id=device)        # nccl == RCCL over xGMI on ROCm
+        if single_dev:
+            torch.distributed.init_process_group("gloo")
+        else:
+            torch.distributed.init_process_group("nccl", device_id=device)    # nccl == RCCL over xGMI on ROCm
         tp_group = torch.distributed.group.WORLD
 
     spec, cfg, plan, eng, embeds, pos, T = build_workload(args.config, device, rank, world)
