@@ -183,3 +183,43 @@ def test_tensor_parallel_gloo_world4_replicated_kv_heads():
             assert (a is None) == (b is None) and (a is None or np.array_equal(a, b))
         assert np.array_equal(ret["logits0"], ret[f"logits{r}"])
     assert np.max(np.abs(ret["logits0"] - ret["ref_logits"])) <= 4e-2
+
+
+def test_load_hf_checkpoint_directory(tmp_path):
+    """Local HF-layout checkpoint (config.json + model.safetensors with the transformers Qwen2-VL parameter names) loads
+    into the native weight layout and produces the same logits as weights passed directly."""
+    import json
+    from safetensors.torch import save_file
+    from transformers import Qwen2VLConfig, Qwen2VLForConditionalGeneration
+    from quickvideo_amd.lvu import load_native_model
+    cfg = Qwen2VLConfig(
+        text_config=dict(hidden_size=256, num_attention_heads=2, num_key_value_heads=1, intermediate_size=512, num_hidden_layers=2,
+                         vocab_size=320, rms_norm_eps=1e-6, tie_word_embeddings=False,
+                         rope_parameters=dict(rope_type="default", mrope_section=[16, 24, 24], rope_theta=1_000_000.0)),
+        vision_config=dict(depth=2, embed_dim=64, hidden_size=256, num_heads=4, mlp_ratio=2, patch_size=14, spatial_merge_size=2,
+                           temporal_patch_size=2),
+        video_token_id=300, vision_start_token_id=301, vision_end_token_id=302)
+    torch.manual_seed(0)
+    hf = Qwen2VLForConditionalGeneration(cfg).eval()
+    sd = {k: v.contiguous() for k, v in hf.state_dict().items()}
+    save_file(sd, str(tmp_path / "model.safetensors"))
+    d = cfg.to_dict()
+    d["text_config"]["rope_scaling"] = {"mrope_section": [16, 24, 24]}
+    d["text_config"]["rope_theta"] = 1_000_000.0
+    json.dump(d, open(tmp_path / "config.json", "w"), default=str)
+    m = load_native_model(str(tmp_path), device="cpu")
+    s = m.spec
+    assert (s.hidden, s.n_heads, s.n_kv_heads, s.head_dim, s.intermediate, s.n_layers, s.vocab) == (256, 2, 1, 128, 512, 2, 320)
+    assert (s.video_token_id, s.vision_start_token_id) == (300, 301) and tuple(s.mrope_section) == (16, 24, 24)
+    lm = hf.model.language_model
+    assert torch.equal(m.text.layers[1].w_qkv[:256].float(), lm.layers[1].self_attn.q_proj.weight.to(torch.bfloat16).float())
+    assert torch.equal(m.text.layers[0].w_gate_up[512:].float(), lm.layers[0].mlp.up_proj.weight.to(torch.bfloat16).float())
+    assert torch.equal(m.text.lm_head.float(), hf.lm_head.weight.to(torch.bfloat16).float())
+    assert m.vision.spec.depth == 2 and m.vision.spec.embed_dim == 64 and m.vision.spec.out_hidden == 256
+    assert torch.equal(m.vision.blocks[1].fc1_w.float(), hf.model.visual.blocks[1].mlp.fc1.weight.to(torch.bfloat16).float())
+    # and it runs end to end through the drop-in API
+    import lvu
+    obj = lvu.LVU(lvu.LVUConfig(str(tmp_path), top_p=0.5, video_group_size=4, num_frames=8), model=m)
+    obj._ops = OracleOps()
+    out = obj.generate("hi", "synthetic://?frames=16&h=56&w=84&seed=1", max_new_tokens=2)
+    assert out[0].count("<tok_") == 2
