@@ -237,11 +237,12 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel_s4(AttnParams p) {
   if (partial) {
     // raw accumulators + (m, l) to the workspace; combined by attn_combine_kernel (same thread geometry)
     float* w = p.ws + ((int64_t)(kvh * (p.items - p.n_whole) + (item - p.n_whole)) * p.nsplit + split) * kPartialFloats;
-    float* wo = w + wave * 64 * 64 + lane;
+    // layout [wave][reg/4][lane][4]: 16-B stores, 1 KB contiguous per wave instruction (combine reads the same way)
+    f32x4_t* wo = reinterpret_cast<f32x4_t*>(w) + (wave * 16) * 64 + lane;
 #pragma unroll
     for (int db = 0; db < NDB; ++db)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) wo[(db * 16 + r) * 64] = o[db][r];
+      for (int r4 = 0; r4 < 4; ++r4) wo[(db * 4 + r4) * 64] = (f32x4_t){o[db][r4 * 4 + 0], o[db][r4 * 4 + 1], o[db][r4 * 4 + 2], o[db][r4 * 4 + 3]};
     float* wm = w + 4 * 64 * 64 + wave * 128 + lane;
     wm[0] = m_run; wm[64] = l_run;
     return;
@@ -262,7 +263,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel_s4(AttnParams p) {
   }
 }
 
-// merges the kv-split partials of one item: O = sum_s O_s 2^{(m_s-M)c} / sum_s l_s 2^{(m_s-M)c}
+// merges the kv-split partials of one item: O = sum_s O_s 2^{(m_s-M)c} / sum_s l_s 2^{(m_s-M)c}.  Same thread geometry as the
+// producer (thread = (wave, lane) -> one query), 16-B loads; all (m, l) pairs are fetched first so the loads of every split
+// are independent.
+constexpr int kMaxSplit = 16;
 template <int D, bool kVit>
 __global__ __launch_bounds__(256) void attn_combine_kernel(AttnParams p) {
   constexpr int NDB = (D + 31) / 32;
@@ -274,20 +278,38 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(AttnParams p) {
   const int head = kvh * p.group + item % p.group;
   const int qi = qb * kQB + wave * 32 + (lane & 31);
   const float* base = p.ws + (int64_t)(kvh * n_split_items + it) * p.nsplit * kPartialFloats;
+  float ms[kMaxSplit], f[kMaxSplit];
   float M = -1e30f;
-  for (int s = 0; s < p.nsplit; ++s) M = fmaxf(M, base[(int64_t)s * kPartialFloats + 4 * 64 * 64 + wave * 128 + lane]);
+#pragma unroll
+  for (int s = 0; s < kMaxSplit; ++s) {
+    ms[s] = -1e30f; f[s] = 0.f;
+    if (s < p.nsplit) {
+      const float* wm = base + (int64_t)s * kPartialFloats + 4 * 64 * 64 + wave * 128 + lane;
+      ms[s] = wm[0]; f[s] = wm[64];                      // f temporarily holds l_s
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < kMaxSplit; ++s) M = fmaxf(M, ms[s]);
   float L = 0.f;
-  float acc[NDB * 16];
 #pragma unroll
-  for (int r = 0; r < NDB * 16; ++r) acc[r] = 0.f;
+  for (int s = 0; s < kMaxSplit; ++s) {
+    const float e = __builtin_amdgcn_exp2f((ms[s] - M) * p.c);
+    L += f[s] * e;
+    f[s] = e;
+  }
+  f32x4_t acc[NDB * 4];
+#pragma unroll
+  for (int r = 0; r < NDB * 4; ++r) acc[r] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   for (int s = 0; s < p.nsplit; ++s) {
-    const float* w = base + (int64_t)s * kPartialFloats;
-    const float ms = w[4 * 64 * 64 + wave * 128 + lane], ls = w[4 * 64 * 64 + wave * 128 + 64 + lane];
-    const float f = __builtin_amdgcn_exp2f((ms - M) * p.c);
-    L += ls * f;
-    const float* wo = w + wave * 64 * 64 + lane;
+    const f32x4_t* wo = reinterpret_cast<const f32x4_t*>(base + (int64_t)s * kPartialFloats) + (wave * 16) * 64 + lane;
+    float fs = f[0];
 #pragma unroll
-    for (int r = 0; r < NDB * 16; ++r) acc[r] = __builtin_fmaf(wo[r * 64], f, acc[r]);
+    for (int k = 1; k < kMaxSplit; ++k) fs = (s == k) ? f[k] : fs;       // static indexing only (runtime index -> scratch)
+#pragma unroll
+    for (int r = 0; r < NDB * 4; ++r) {
+      const f32x4_t v = wo[r * 64];
+      acc[r] += v * fs;
+    }
   }
   if (qi < (int)p.n) {
     const float inv = 1.0f / L;
@@ -297,8 +319,8 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(AttnParams p) {
     for (int db = 0; db < NDB; ++db)
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
-        bf16x4_t v = {(__bf16)(acc[db * 16 + r4 * 4 + 0] * inv), (__bf16)(acc[db * 16 + r4 * 4 + 1] * inv),
-                      (__bf16)(acc[db * 16 + r4 * 4 + 2] * inv), (__bf16)(acc[db * 16 + r4 * 4 + 3] * inv)};
+        const f32x4_t a = acc[db * 4 + r4];
+        bf16x4_t v = {(__bf16)(a[0] * inv), (__bf16)(a[1] * inv), (__bf16)(a[2] * inv), (__bf16)(a[3] * inv)};
         if (db * 32 + 8 * r4 + 4 * hi < D) op[db * 8 + r4 * 2 + hi] = __builtin_bit_cast(uint2, v);
       }
   }
@@ -473,7 +495,7 @@ AttnPlan plan_items(int64_t n, int64_t P, int hq, int hkv, int cus, int split_mo
   if (a.items < slots) ns = (2 * slots + rem - 1) / rem;          // under-filled grid: aim at two rounds
   int64_t cap = tiles_min / 4; if (cap < 1) cap = 1;              // keep >= 4 tiles per piece
   if (ns > cap) ns = (int)cap;
-  if (ns > 64) ns = 64;
+  if (ns > kMaxSplit) ns = kMaxSplit;
   if (ns <= 1) return a;
   a.n_whole = a.items - rem; a.nsplit = ns;
   return a;

@@ -74,10 +74,6 @@ class QuickPrefillEngine:
         self.b_ss_all = e(self.tp_size, self.hkv, n, dtype=torch.float32) if self.tp_size > 1 else None
         self.b_idx = e(n, dtype=torch.int32)
         self.b_h2 = e(n, d)
-        # The prune step (select + gather staging -> arena) only has to finish before the NEXT layer reuses the staging
-        # block, so on the GPU it runs on a side stream underneath this layer's attention / o_proj / MLP.
-        self.side_stream = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
-        self._prune_done = None
         self.kept_trace: Optional[list] = None      # tests: set to [] to record kept indices per (group, layer)
         self.seq_pos = 0                            # tokens of the original sequence consumed so far
 
@@ -128,9 +124,6 @@ class QuickPrefillEngine:
             assert past + (k_keep if k_keep is not None else n) <= self.arena.capacity, "KV arena overflow"
             q = self.b_q[:n]
             if k_keep is not None:                                           # prune layer: new K/V go to staging
-                if self._prune_done is not None:                             # previous layer's prune still reads the staging block
-                    torch.cuda.current_stream(self.device).wait_event(self._prune_done)
-                    self._prune_done = None
                 kn = self.b_stage[0].view(-1)[: self.hkv * n * D].view(self.hkv, n, D)
                 vn = self.b_stage[1].view(-1)[: self.hkv * n * D].view(self.hkv, n, D)
                 ops.rope_append(qkv, cos, sin, self.hq, self.hkv, D, q, kn, vn, n * D, 0, self.b_ss)
@@ -153,18 +146,8 @@ class QuickPrefillEngine:
             if k_keep is not None:                                           # post_process_kv_cache         (:183-192)
                 ss_all, heads_total = self._global_sumsq(n)
                 idx = self.b_idx[:k_keep]
-                aside = self.side_stream is not None and not prune_hidden and self.kept_trace is None
-                if aside:
-                    main = torch.cuda.current_stream(self.device)
-                    self.side_stream.wait_stream(main)                       # rope_append / attention launches are queued
-                    with torch.cuda.stream(self.side_stream):
-                        ops.prune_staged(ss_all, heads_total, n, k_keep, kn, vn, n * D, self.hkv, D, self.arena.k(l), self.arena.v(l),
-                                         self.arena.head_stride, past, idx)
-                        self._prune_done = torch.cuda.Event()
-                        self._prune_done.record(self.side_stream)
-                else:
-                    ops.prune_staged(ss_all, heads_total, n, k_keep, kn, vn, n * D, self.hkv, D, self.arena.k(l), self.arena.v(l),
-                                     self.arena.head_stride, past, idx)                # select + gather, one launch
+                ops.prune_staged(ss_all, heads_total, n, k_keep, kn, vn, n * D, self.hkv, D, self.arena.k(l), self.arena.v(l),
+                                 self.arena.head_stride, past, idx)                    # select + gather, one launch
                 self.arena.len[l] = past + k_keep
                 if self.kept_trace is not None:
                     self.kept_trace.append((l, idx.clone()))
@@ -195,9 +178,6 @@ class QuickPrefillEngine:
             self._all_reduce(dn)
             delta = dn
         ops.add_inplace(h, delta)                                            # last residual                  (:198)
-        if self._prune_done is not None:                                     # the arena must be complete before anyone reads it
-            torch.cuda.current_stream(self.device).wait_event(self._prune_done)
-            self._prune_done = None
         return h
 
     # ------------------------------------------------------------------ public steps of the group loop
