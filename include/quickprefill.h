@@ -76,6 +76,12 @@ int qp_prefill_attn(qp_ctx* ctx, const void* q, const void* k_prefix, const void
                     int64_t prefix_head_stride, int64_t prefix_len, const void* k_new, const void* v_new,
                     int64_t new_head_stride, int64_t n, int n_q_heads, int n_kv_heads, int head_dim, float scale,
                     void* out, void* workspace, size_t workspace_bytes, void* stream);
+/* Same, for a sub-range of the group's queries (group-token parallel ranks: every rank holds all n new K/V rows but only
+ * the queries [q_row0, q_row0+nq)): q and out are [nq][n_q][128]; query i of the sub-range attends new keys j <= q_row0+i. */
+int qp_prefill_attn_rows(qp_ctx* ctx, const void* q, const void* k_prefix, const void* v_prefix,
+                         int64_t prefix_head_stride, int64_t prefix_len, const void* k_new, const void* v_new,
+                         int64_t new_head_stride, int64_t n, int64_t q_row0, int64_t nq, int n_q_heads, int n_kv_heads,
+                         int head_dim, float scale, void* out, void* workspace, size_t workspace_bytes, void* stream);
 /* Scratch for the kv-split partial results (work items of a ragged last round are cut along KV and merged by a combine
  * kernel so every CU stays busy; small grids — few heads x few query blocks — are split the same way).  workspace may
  * be NULL: the launch then runs unsplit. */

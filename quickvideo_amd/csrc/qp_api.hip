@@ -80,13 +80,15 @@ int qp_rope_append(qp_ctx* ctx, const void* qkv, const void* cos, const void* si
                                head_sumsq, (hipStream_t)stream);
 }
 
-int qp_prefill_attn(qp_ctx* ctx, const void* q, const void* k_prefix, const void* v_prefix, int64_t prefix_head_stride,
-                    int64_t prefix_len, const void* k_new, const void* v_new, int64_t new_head_stride, int64_t n,
-                    int n_q_heads, int n_kv_heads, int head_dim, float scale, void* out, void* workspace, size_t workspace_bytes,
-                    void* stream) {
+int qp_prefill_attn_rows(qp_ctx* ctx, const void* q, const void* k_prefix, const void* v_prefix, int64_t prefix_head_stride,
+                         int64_t prefix_len, const void* k_new, const void* v_new, int64_t new_head_stride, int64_t n, int64_t q_row0,
+                         int64_t nq, int n_q_heads, int n_kv_heads, int head_dim, float scale, void* out, void* workspace,
+                         size_t workspace_bytes, void* stream) {
   QP_REQUIRE(ctx && q && k_new && v_new && out, QP_ERR_INVALID, "qp_prefill_attn: NULL argument");
   QP_REQUIRE(head_dim == 128, QP_ERR_UNSUPPORTED, "qp_prefill_attn: head_dim=%d (only 128)", head_dim);
   QP_REQUIRE(n >= 0 && prefix_len >= 0, QP_ERR_INVALID, "qp_prefill_attn: negative length");
+  QP_REQUIRE(q_row0 >= 0 && nq >= 0 && q_row0 + nq <= n, QP_ERR_INVALID, "qp_prefill_attn: query rows [%lld,%lld) outside the group's %lld tokens",
+             (long long)q_row0, (long long)(q_row0 + nq), (long long)n);
   QP_REQUIRE(n_q_heads > 0 && n_kv_heads > 0 && n_q_heads % n_kv_heads == 0, QP_ERR_INVALID,
              "qp_prefill_attn: n_q_heads=%d not a multiple of n_kv_heads=%d", n_q_heads, n_kv_heads);
   QP_REQUIRE(prefix_len == 0 || (k_prefix && v_prefix && prefix_head_stride >= prefix_len * head_dim), QP_ERR_INVALID,
@@ -96,10 +98,18 @@ int qp_prefill_attn(qp_ctx* ctx, const void* q, const void* k_prefix, const void
   QP_REQUIRE(aligned16(q) && aligned16(k_new) && aligned16(v_new) && aligned16(out) && aligned16(k_prefix) && aligned16(v_prefix),
              QP_ERR_INVALID, "qp_prefill_attn: pointers must be 16-byte aligned");
   QP_REQUIRE(n_q_heads <= 65535, QP_ERR_UNSUPPORTED, "qp_prefill_attn: too many heads");
-  if (n == 0) return QP_OK;
   QP_REQUIRE(workspace == nullptr || aligned16(workspace), QP_ERR_INVALID, "qp_prefill_attn: workspace must be 16-byte aligned");
-  return qp_launch_prefill_attn(ctx, q, k_prefix, v_prefix, prefix_head_stride, prefix_len, k_new, v_new, new_head_stride, n,
-                                n_q_heads, n_kv_heads, scale, out, workspace, workspace_bytes, (hipStream_t)stream);
+  if (nq == 0) return QP_OK;
+  return qp_launch_prefill_attn(ctx, q, k_prefix, v_prefix, prefix_head_stride, prefix_len, k_new, v_new, new_head_stride, n, q_row0,
+                                nq, n_q_heads, n_kv_heads, scale, out, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+int qp_prefill_attn(qp_ctx* ctx, const void* q, const void* k_prefix, const void* v_prefix, int64_t prefix_head_stride,
+                    int64_t prefix_len, const void* k_new, const void* v_new, int64_t new_head_stride, int64_t n,
+                    int n_q_heads, int n_kv_heads, int head_dim, float scale, void* out, void* workspace, size_t workspace_bytes,
+                    void* stream) {
+  return qp_prefill_attn_rows(ctx, q, k_prefix, v_prefix, prefix_head_stride, prefix_len, k_new, v_new, new_head_stride, n, 0, n,
+                              n_q_heads, n_kv_heads, head_dim, scale, out, workspace, workspace_bytes, stream);
 }
 
 size_t qp_attn_workspace_bytes(const qp_ctx* ctx, int64_t n, int64_t prefix_len, int n_q_heads, int n_kv_heads) {

@@ -41,6 +41,8 @@ struct AttnParams {
   int heads_per_seq;            // "kv head" index = seq * heads_per_seq + head
   int64_t seq_stride16;         // uint4 between consecutive sequences (K/V and Q)
   int kv_row_bytes;             // byte stride between consecutive K/V (and Q) rows
+  // query sub-range (group-token parallel ranks): q/out hold rows [q_row0, q_row0+nq) of the group's n new tokens
+  int q_row0; int nq;
 };
 
 __device__ __forceinline__ bf16x8_t lds_read_b128(const unsigned char* lds, int off) {
@@ -88,13 +90,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel_s4(AttnParams p) {
   if (item >= p.items) return;
   const int qb = p.nqb - 1 - item / p.group;               // heaviest (latest) q blocks first
   const int head = kvh * p.group + item % p.group;
-  const int q0w = qb * kQB + wave * 32;
-  const int qi = q0w + (lane & 31);
+  const int q0l = qb * kQB + wave * 32;                      // local query row of this wave (q / out indexing)
+  const int qi = q0l + (lane & 31);
+  const int q0w = p.q_row0 + q0l;                            // row inside the group's new segment (causal mask)
   const int hi = lane >> 5, l31 = lane & 31;
-  const int n = (int)p.n, P = (int)p.P;
+  const int n = (int)p.n, P = (int)p.P, nq = p.nq;
 
   int blk_end = qb * kQB + kQB;
-  if (blk_end > n) blk_end = n;
+  if (blk_end > nq) blk_end = nq;
+  blk_end += p.q_row0;                                        // new keys this workgroup can see: [0, blk_end)
   const int ntp = (P + kKV - 1) / kKV, ntt = kVit ? 0 : (blk_end + kKV - 1) / kKV, nt = ntp + ntt;
   int ti_lo = 0, ti_hi = nt;
   if (partial) { ti_lo = (int)((int64_t)split * nt / p.nsplit); ti_hi = (int)((int64_t)(split + 1) * nt / p.nsplit); }
@@ -119,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel_s4(AttnParams p) {
 
   bf16x8_t qf[KSTEPS];
   {
-    const int qrow = qi < n ? qi : n - 1;
+    const int qrow = qi < nq ? qi : nq - 1;
     const uint4* qp = kVit ? p.q + (int64_t)seq * p.seq_stride16 + (int64_t)qrow * (row_bytes / 16) + (int64_t)(kvh % p.heads_per_seq) * SLOTS
                            : p.q + ((int64_t)qrow * p.hq + head) * 16;
 #pragma unroll
@@ -178,7 +182,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel_s4(AttnParams p) {
     __builtin_amdgcn_s_setprio(0);
     const bool need_mask = (t0 + kKV > seg_len) || (!pre && t0 + kKV - 1 > q0w);
     if (need_mask) {                                    // wave-uniform side branch: ragged or diagonal tiles only
-      const int qlim = pre ? 0x7fffffff : qi;
+      const int qlim = pre ? 0x7fffffff : p.q_row0 + qi;
 #pragma unroll
       for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
@@ -247,9 +251,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel_s4(AttnParams p) {
     wm[0] = m_run; wm[64] = l_run;
     return;
   }
-  if (qi < n) {
+  if (qi < nq) {
     const float inv = 1.0f / l_run;
-    // LLM: out [n][hq][128]; ViT: out [seq][S][heads][D]  (D/4 x 8 B per row)
+    // LLM: out [nq][hq][128]; ViT: out [seq][S][heads][D]  (D/4 x 8 B per row)
     uint2* op = kVit ? p.out + (((int64_t)seq * n + qi) * p.heads_per_seq + (kvh % p.heads_per_seq)) * (D / 4)
                      : p.out + ((int64_t)qi * p.hq + head) * 32;
 #pragma unroll
@@ -311,7 +315,7 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(AttnParams p) {
       acc[r] += v * fs;
     }
   }
-  if (qi < (int)p.n) {
+  if (qi < p.nq) {
     const float inv = 1.0f / L;
     uint2* op = kVit ? p.out + (((int64_t)(kvh / p.heads_per_seq) * p.n + qi) * p.heads_per_seq + (kvh % p.heads_per_seq)) * (D / 4)
                      : p.out + ((int64_t)qi * p.hq + head) * 32;
@@ -503,32 +507,35 @@ AttnPlan plan_items(int64_t n, int64_t P, int hq, int hkv, int cus, int split_mo
 
 }  // namespace
 
-size_t qp_attn_workspace_bytes_impl(const qp_ctx* ctx, int64_t n, int64_t prefix_len, int hq, int hkv) {
-  AttnPlan a = plan_items(n, prefix_len, hq, hkv, ctx->cus, 1);
+size_t qp_attn_workspace_bytes_impl(const qp_ctx* ctx, int64_t nq, int64_t prefix_len, int hq, int hkv) {
+  AttnPlan a = plan_items(nq, prefix_len, hq, hkv, ctx->cus, 1);
   return (size_t)hkv * (size_t)(a.items - a.n_whole) * (size_t)a.nsplit * kPartialFloats * sizeof(float) + 256;
 }
 
 int qp_launch_prefill_attn(const qp_ctx* ctx, const void* q, const void* k_prefix, const void* v_prefix,
                            int64_t prefix_head_stride, int64_t prefix_len, const void* k_new, const void* v_new,
-                           int64_t new_head_stride, int64_t n, int hq, int hkv, float scale, void* out, void* workspace,
-                           size_t workspace_bytes, hipStream_t s) {
+                           int64_t new_head_stride, int64_t n, int64_t q_row0, int64_t nq, int hq, int hkv, float scale, void* out,
+                           void* workspace, size_t workspace_bytes, hipStream_t s) {
   AttnParams p;
   p.q = (const uint4*)q; p.out = (uint2*)out;
   p.kp = (const uint4*)k_prefix; p.vp = (const uint4*)v_prefix; p.pre_hs16 = prefix_head_stride / 8; p.P = prefix_len;
   p.kn = (const uint4*)k_new; p.vn = (const uint4*)v_new; p.new_hs16 = new_head_stride / 8; p.n = n;
   p.hq = hq; p.group = hq / hkv; p.c = scale * 1.4426950408889634f;
-  p.nqb = (int)((n + kQB - 1) / kQB); p.hkv = hkv; p.ws = (float*)workspace;
+  p.nqb = (int)((nq + kQB - 1) / kQB); p.hkv = hkv; p.ws = (float*)workspace;
   p.items = p.nqb * p.group; p.n_whole = p.items; p.nsplit = 1;
   p.heads_per_seq = hkv; p.seq_stride16 = 0; p.kv_row_bytes = 256;
+  p.q_row0 = (int)q_row0; p.nq = (int)nq;
   const char* var = getenv("QP_ATTN_VARIANT");        // developer A/B switch (tools/bench_attn.py); default = production kernel
   const int variant = var ? atoi(var) : 0;
   const bool big = prefix_len * 256 >= (1ll << 31) || n * 256 >= (1ll << 31);
+  if ((variant == 1 || big) && !(q_row0 == 0 && nq == n))
+    return qp_fail(QP_ERR_UNSUPPORTED, "qp_prefill_attn: query sub-ranges need K/V segments below 2 GiB per head");
   if (variant == 1 || big) {
     attn_fwd_kernel_v1<<<dim3((unsigned)p.nqb, (unsigned)hq), 256, 0, s>>>(p);
     return qp_check_launch("prefill_attn(v1)");
   }
   // variant 2: no kv split; variant 3: no XCD mapping
-  AttnPlan a = plan_items(n, prefix_len, hq, hkv, ctx->cus, (variant == 2 || workspace == nullptr) ? 0 : 1);
+  AttnPlan a = plan_items(nq, prefix_len + q_row0, hq, hkv, ctx->cus, (variant == 2 || workspace == nullptr) ? 0 : 1);
   p.items = a.items; p.n_whole = a.n_whole; p.nsplit = a.nsplit;
   if (a.nsplit > 1) {
     const size_t need = (size_t)hkv * (size_t)(a.items - a.n_whole) * (size_t)a.nsplit * kPartialFloats * sizeof(float);
@@ -567,7 +574,7 @@ int qp_launch_vit_attn(const qp_ctx* ctx, const void* qkv, int64_t n_seq, int64_
   p.hq = hk; p.group = 1; p.c = scale * 1.4426950408889634f;
   p.nqb = (int)((S + kQB - 1) / kQB); p.hkv = hk; p.ws = nullptr;
   p.heads_per_seq = heads; p.seq_stride16 = S * row16; p.kv_row_bytes = row16 * 16;
-  p.items = p.nqb; p.n_whole = p.nqb; p.nsplit = 1;
+  p.items = p.nqb; p.n_whole = p.nqb; p.nsplit = 1; p.q_row0 = 0; p.nq = (int)S;
   attn_fwd_kernel_s4<false, D, true><<<dim3((unsigned)p.nqb, (unsigned)hk), 256, 0, s>>>(p);
   return qp_check_launch("vit_attn");
 }

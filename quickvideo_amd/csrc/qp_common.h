@@ -56,8 +56,8 @@ int qp_launch_add_inplace(void* h, const void* delta, int64_t n_elems, hipStream
 int qp_launch_swiglu(const void* gate_up, int64_t n, int inter, void* out, hipStream_t s);
 int qp_launch_prefill_attn(const qp_ctx* ctx, const void* q, const void* k_prefix, const void* v_prefix,
                            int64_t prefix_head_stride, int64_t prefix_len, const void* k_new, const void* v_new,
-                           int64_t new_head_stride, int64_t n, int hq, int hkv, float scale, void* out, void* workspace,
-                           size_t workspace_bytes, hipStream_t s);
+                           int64_t new_head_stride, int64_t n, int64_t q_row0, int64_t nq, int hq, int hkv, float scale, void* out,
+                           void* workspace, size_t workspace_bytes, hipStream_t s);
 size_t qp_attn_workspace_bytes_impl(const qp_ctx* ctx, int64_t n, int64_t prefix_len, int hq, int hkv);
 int qp_launch_vit_attn(const qp_ctx* ctx, const void* qkv, int64_t n_seq, int64_t S, int heads, float scale, void* out,
                        hipStream_t s);

@@ -41,6 +41,7 @@ SIGNATURES = {
     "qp_mrope_table": (_i32, [_vp, _vp, _i64, _c.POINTER(_c.c_int32), _f32, _i32, _vp, _vp, _vp]),
     "qp_rope_append": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _vp, _vp]),
     "qp_prefill_attn": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _f32, _vp, _vp, _sz, _vp]),
+    "qp_prefill_attn_rows": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _f32, _vp, _vp, _sz, _vp]),
     "qp_attn_workspace_bytes": (_sz, [_vp, _i64, _i64, _i32, _i32]),
     "qp_key_sumsq": (_i32, [_vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _vp]),
     "qp_select_workspace_bytes": (_sz, [_i64]),
@@ -134,14 +135,16 @@ class QuickPrefillOps:
 
     # -- seam 3
     def prefill_attn(self, q, k_prefix, v_prefix, prefix_head_stride, prefix_len, k_new, v_new, new_head_stride, n, n_q, n_kv,
-                     head_dim, scale, out):
-        need = int(self.lib.qp_attn_workspace_bytes(self.ctx, n, prefix_len, n_q, n_kv))
+                     head_dim, scale, out, q_row0=0, nq=None):
+        """q/out rows = the group's new tokens [q_row0, q_row0+nq) (default: all n)."""
+        nq = n if nq is None else nq
+        need = int(self.lib.qp_attn_workspace_bytes(self.ctx, nq, prefix_len + q_row0, n_q, n_kv))
         if self._attn_ws is None or self._attn_ws.numel() < need:          # caller-owned scratch, grown on demand
             self._attn_ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=self.device)
-        self._check(self.lib.qp_prefill_attn(self.ctx, q.data_ptr(), _ptr(k_prefix), _ptr(v_prefix), prefix_head_stride,
-                                             prefix_len, k_new.data_ptr(), v_new.data_ptr(), new_head_stride, n, n_q, n_kv,
-                                             head_dim, float(scale), out.data_ptr(), self._attn_ws.data_ptr(),
-                                             self._attn_ws.numel(), self._stream()))
+        self._check(self.lib.qp_prefill_attn_rows(self.ctx, q.data_ptr(), _ptr(k_prefix), _ptr(v_prefix), prefix_head_stride,
+                                                  prefix_len, k_new.data_ptr(), v_new.data_ptr(), new_head_stride, n, q_row0, nq,
+                                                  n_q, n_kv, head_dim, float(scale), out.data_ptr(), self._attn_ws.data_ptr(),
+                                                  self._attn_ws.numel(), self._stream()))
 
     # -- seam 1
     def key_sumsq(self, k, head_stride, row0, n, n_kv, head_dim, head_sumsq):

@@ -400,3 +400,28 @@ def test_norm_sqrt_is_correctly_rounded(ops):
     ref = O.key_norms_bf16(ss.cpu().numpy())
     assert np.array_equal(nb.cpu().numpy().view(np.uint16), ref)
     assert np.array_equal(idx.cpu().numpy(), O.select_k_smallest(ref, 8))
+
+
+@pytest.mark.parametrize("n,P,hq,hkv,parts", [(1000, 700, 8, 2, 3), (5760, 2887, 28, 4, 8), (333, 0, 4, 4, 2)])
+def test_prefill_attn_query_subranges(ops, n, P, hq, hkv, parts):
+    """Group-token parallel ranks compute disjoint query sub-ranges over the same (prefix, new) K/V: the pieces must tile
+    the full result."""
+    g = torch.Generator(device="cuda"); g.manual_seed(n * 3 + P)
+    q = torch.randn(n, hq, D, generator=g, device="cuda").to(torch.bfloat16)
+    k = torch.randn(hkv, P + n, D, generator=g, device="cuda").to(torch.bfloat16)
+    v = torch.randn(hkv, P + n, D, generator=g, device="cuda").to(torch.bfloat16)
+    full = torch.empty(n, hq, D, dtype=torch.bfloat16, device="cuda")
+    ops.prefill_attn(q, k, v, (P + n) * D, P, k[:, P:], v[:, P:], (P + n) * D, n, hq, hkv, D, D ** -0.5, full)
+    m = -(-n // parts)
+    pieces = []
+    for r in range(parts):
+        lo, hi = r * m, min(n, (r + 1) * m)
+        out = torch.zeros(hi - lo, hq, D, dtype=torch.bfloat16, device="cuda")
+        ops.prefill_attn(q[lo:hi].contiguous(), k, v, (P + n) * D, P, k[:, P:], v[:, P:], (P + n) * D, n, hq, hkv, D, D ** -0.5, out,
+                         q_row0=lo, nq=hi - lo)
+        pieces.append(out)
+    torch.cuda.synchronize()
+    got = torch.cat(pieces, 0)
+    assert (got.float() - full.float()).abs().max().item() <= 4e-3     # only the kv-split plan may differ between the two
+    with pytest.raises(ValueError):
+        ops.prefill_attn(q[:10].contiguous(), k, v, (P + n) * D, P, k[:, P:], v[:, P:], (P + n) * D, n, hq, hkv, D, 1.0, full, q_row0=n - 5, nq=10)
