@@ -71,7 +71,7 @@ class TimedOps:
         return {n: (sum(s.elapsed_time(e) for s, e in ev), len(ev)) for n, ev in self.events.items()}
 
 
-def build_workload(name, device, tp_rank, tp_size, seed=0):
+def build_workload(name, device, rank, world, seed=0, parallel="sp"):
     model, frames, fh, fw, gs, rho, prefix, tail = CONFIGS[name]
     spec = PRESETS[model]
     gh, gw = fh // 14, fw // 14
@@ -80,10 +80,12 @@ def build_workload(name, device, tp_rank, tp_size, seed=0):
     plan = planner.plan_groups(frames, gs, gh, gw, prefix, T)
     pos, delta = planner.mrope_positions(prefix, (frames // 2, gh, gw), tail, temporal_scale=spec.temporal_scale)
     cfg = LVUConfig(model, top_p=rho, video_group_size=gs, num_frames=frames)
-    weights = DecoderWeights.synthetic(spec, device, seed=seed, tp_rank=tp_rank, tp_size=tp_size)
+    tp = parallel == "tp" and world > 1
+    weights = DecoderWeights.synthetic(spec, device, seed=seed, tp_rank=rank if tp else 0, tp_size=world if tp else 1)
     kept = sum(effective_k(n, cfg, 0, spec.n_layers) or n for n in plan.tokens)
     cap = kept + plan.tail_len + 64
-    eng = QuickPrefillEngine(weights, cfg, capacity=cap, max_group_tokens=max(plan.tokens + [plan.tail_len]), device=device)
+    eng = QuickPrefillEngine(weights, cfg, capacity=cap, max_group_tokens=max(plan.tokens + [plan.tail_len]), device=device,
+                             sp_rank=0 if tp else rank, sp_size=1 if tp else world)
     g = torch.Generator(device=device); g.manual_seed(1234)      # same embeddings on every TP rank
     # synthetic ViT output / text embeddings: N(0, 1) scaled like embedding rows (the ViT front end is bench'd separately)
     embeds = (torch.randn(T, spec.hidden, generator=g, device=device, dtype=torch.float32) * 0.5).to(torch.bfloat16)
@@ -204,6 +206,9 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true")
     ap.add_argument("--no-ttft", action="store_true", help="skip the extra step that times prefill -> first token id on the host")
+    ap.add_argument("--parallel", default="sp", choices=["sp", "tp"],
+                    help="N>1: sp = group-token parallel (replicated weights/KV, one K/V all-gather per layer; default), "
+                         "tp = tensor parallel over heads / MLP columns (two [n,d] all-reduces per layer)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -227,8 +232,11 @@ def main():
             torch.distributed.init_process_group("nccl", device_id=device)    # nccl == RCCL over xGMI on ROCm
         tp_group = torch.distributed.group.WORLD
 
-    spec, cfg, plan, eng, embeds, pos, T = build_workload(args.config, device, rank, world)
-    eng.tp_group = tp_group
+    spec, cfg, plan, eng, embeds, pos, T = build_workload(args.config, device, rank, world, parallel=args.parallel)
+    if args.parallel == "tp":
+        eng.tp_group = tp_group
+    else:
+        eng.sp_group = tp_group
     tokens = sum(plan.tokens)                 # tokens prefetched in the group loop (the reference's total_prefill span)
 
     def barrier():
@@ -268,7 +276,18 @@ def main():
         eng.ops = real_ops
         tot = timed.totals_ms()
         att_ms, att_n = tot["prefill_attn"]
-        att_local = att / world                                  # heads are sharded under TP
+        att_local = att / world                                  # tp: heads sharded; sp: query rows sharded (rank 0 = earliest rows)
+        if world > 1 and args.parallel == "sp":
+            att_local, Pp = 0.0, 0
+            for n in plan.tokens:
+                m = -(-n // world)
+                lo, hi = min(n, rank * m), min(n, (rank + 1) * m)
+                if n >= 64 * world:
+                    att_local += 4.0 * spec.n_layers * spec.n_heads * spec.head_dim * sum(Pp + i + 1 for i in range(lo, hi))
+                else:
+                    att_local += spec.attn_flops(n, Pp)
+                Pp += effective_k(n, cfg, 0, spec.n_layers) or n
+            att_local += spec.attn_flops(plan.tail_len, Pp)
         ach = att_local / (att_ms * 1e-3) / 1e12
         traffic = None            # HBM bytes per launch from the committed rocprofv3 PMC passes (tools/profile_bench.sh), same command
         tpath = os.path.join(ROOT, "profiles", "attn_pmc_traffic_latest.json")
@@ -300,7 +319,7 @@ def main():
                                    f"{CONFIGS[args.config][2]}x{CONFIGS[args.config][3]}, group_size {CONFIGS[args.config][4]}, "
                                    f"key-norm rho={CONFIGS[args.config][5]}",
                        "groups": len(plan.tokens), "tokens_per_group": plan.tokens[-1], "prefill_tokens": tokens,
-                       "tail_tokens": plan.tail_len, "layers": spec.n_layers, "parallelism": f"tp{world}",
+                       "tail_tokens": plan.tail_len, "layers": spec.n_layers, "parallelism": (f"{args.parallel}{world}" if world > 1 else "single"),
                        "vit": "excluded (synthetic ViT-output embeddings resident in HBM)",
                        "weights": "seeded random at real dims"},
             "ttft_ms_prefill_leg": None if ttft_ms is None else round(ttft_ms, 3), "first_token": first,

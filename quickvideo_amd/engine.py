@@ -47,7 +47,7 @@ class KVArena:
 
 class QuickPrefillEngine:
     def __init__(self, weights: DecoderWeights, cfg: LVUConfig, capacity: int, max_group_tokens: int, device=None, ops=None,
-                 tp_group=None):
+                 tp_group=None, sp_group=None, sp_rank: int = 0, sp_size: int = 1):
         self.w, self.spec, self.cfg = weights, weights.spec, cfg
         self.device = torch.device(device if device is not None else weights.embed.device)
         if ops is None:
@@ -57,6 +57,11 @@ class QuickPrefillEngine:
         self.tp_group = tp_group
         self.tp_size = weights.tp_size
         self.tp_rank = weights.tp_rank
+        # group-token parallelism ("sp"): weights and the KV arena are replicated (288 GB of HBM per GPU), every rank takes a
+        # contiguous slice of each group's tokens through all layers and the ranks exchange only the group's new K/V rows
+        # (+ key sums) once per layer — ~14x fewer bytes on xGMI than the two [n, d] all-reduces of tensor parallelism.
+        self.sp_group, self.sp_rank, self.sp_size = sp_group, sp_rank, sp_size
+        assert not (self.sp_size > 1 and self.tp_size > 1), "choose tensor parallel OR group-token parallel"
         s = self.spec
         self.hq, self.hkv, self.li = weights.local_q_heads, weights.local_kv_heads, weights.local_inter
         self.D = s.head_dim
@@ -69,7 +74,12 @@ class QuickPrefillEngine:
         self.b_qkv = e(n, (self.hq + 2 * self.hkv) * self.D)
         self.b_q, self.b_att = e(n, self.hq, self.D), e(n, self.hq, self.D)
         self.b_gu, self.b_act = e(n, 2 * self.li), e(n, self.li)
-        self.b_stage = e(2, self.hkv, n, self.D)
+        self.b_stage = e(2, self.hkv, n + self.sp_size, self.D)
+        if self.sp_size > 1:
+            m = -(-n // self.sp_size)
+            self.sp_chunk = 2 * self.hkv * m * self.D * 2 + self.hkv * m * 4              # bytes: K | V | key sums of one rank
+            self.b_xsend = e(self.sp_chunk, dtype=torch.uint8)
+            self.b_xall = e(self.sp_size * self.sp_chunk, dtype=torch.uint8)
         self.b_ss = e(self.hkv, n, dtype=torch.float32)
         self.b_ss_all = e(self.tp_size, self.hkv, n, dtype=torch.float32) if self.tp_size > 1 else None
         self.b_idx = e(n, dtype=torch.int32)
@@ -106,6 +116,8 @@ class QuickPrefillEngine:
         s, ops, cfg, D = self.spec, self.ops, self.cfg, self.D
         n = embeds.shape[0]
         assert n <= self.n_max, f"group of {n} tokens exceeds max_group_tokens={self.n_max}"
+        if self.sp_size > 1 and n >= 64 * self.sp_size:
+            return self._forward_segment_sp(embeds, pos, prune)
         L = len(self.w.layers)
         cos, sin = ops.mrope_table(pos.contiguous(), s.mrope_section, s.rope_theta, D)
         hbufs, hsel = (self.b_h, self.b_h2), 0
@@ -178,6 +190,80 @@ class QuickPrefillEngine:
             self._all_reduce(dn)
             delta = dn
         ops.add_inplace(h, delta)                                            # last residual                  (:198)
+        return h
+
+    # ------------------------------------------------------------------ group-token parallel variant of forward_segment
+    def _forward_segment_sp(self, embeds: torch.Tensor, pos: torch.Tensor, prune: bool) -> torch.Tensor:
+        """Rank r runs tokens [r*m, (r+1)*m) of the segment (m = ceil(n/N)) through every layer; per layer ONE all-gather
+        moves the ranks' new K/V rows and key sums, after which every rank holds the whole group's K/V in its staging block,
+        attends its own query rows (qp_prefill_attn_rows) and applies the identical prune to its arena replica.
+        Returns this rank's hidden rows (callers only need them for the replicated prompt tail)."""
+        s, ops, cfg, D, N, r = self.spec, self.ops, self.cfg, self.D, self.sp_size, self.sp_rank
+        n = embeds.shape[0]
+        if cfg.enable and isinstance(cfg.prefill_prune_starting_layer, int) and cfg.prefill_prune_starting_layer >= 0 and prune:
+            raise NotImplementedError("hidden-state pruning (prefill_prune_starting_layer) is not combined with group-token parallelism")
+        m = -(-n // N)
+        lo, hi = min(n, r * m), min(n, (r + 1) * m)
+        ml = hi - lo
+        L = len(self.w.layers)
+        cos, sin = ops.mrope_table(pos[:, lo:hi].contiguous(), s.mrope_section, s.rope_theta, D)
+        h = self.b_h[:ml]
+        h.copy_(embeds[lo:hi])
+        delta = None
+        scale = D ** -0.5
+        kv_bytes = self.hkv * m * D * 2
+        send_k = self.b_xsend[:kv_bytes].view(self.dtype).view(self.hkv, m, D)
+        send_v = self.b_xsend[kv_bytes:2 * kv_bytes].view(self.dtype).view(self.hkv, m, D)
+        send_ss = self.b_xsend[2 * kv_bytes:2 * kv_bytes + self.hkv * m * 4].view(torch.float32).view(self.hkv, m)
+        chunk = 2 * kv_bytes + self.hkv * m * 4
+        xall = self.b_xall[: N * chunk].view(N, chunk)
+        stage = self.b_stage.view(-1)[: 2 * self.hkv * N * m * D].view(2, self.hkv, N * m, D)
+        kn, vn, new_stride = stage[0], stage[1], N * m * D
+        ss_loc = self.b_ss.view(-1)[: self.hkv * ml].view(self.hkv, ml)
+        for l, lw in enumerate(self.w.layers):
+            x = self.b_x[:ml]
+            ops.add_rmsnorm(h, delta, lw.ln1, x, s.rms_eps)
+            qkv = self.b_qkv[:ml]
+            torch.addmm(lw.b_qkv, x, lw.w_qkv.t(), out=qkv)
+            k_keep = effective_k(n, cfg, l, L) if prune else None
+            past = self.arena.len[l]
+            assert past + (k_keep if k_keep is not None else n) <= self.arena.capacity, "KV arena overflow"
+            q = self.b_q[:ml]
+            ops.rope_append(qkv, cos, sin, self.hq, self.hkv, D, q, send_k, send_v, m * D, 0, ss_loc)
+            send_ss[:, :ml].copy_(ss_loc)
+            torch.distributed.all_gather_into_tensor(self.b_xall[: N * chunk], self.b_xsend[:chunk], group=self.sp_group)
+            # [rank][K|V][head][m][D] -> staging [K|V][head][rank*m + t][D]  (rows >= n are the last rank's padding, never read)
+            stage.view(2, self.hkv, N, m, D).copy_(xall[:, : 2 * kv_bytes].view(self.dtype).view(N, 2, self.hkv, m, D).permute(1, 2, 0, 3, 4))
+            att = self.b_att[:ml]
+            past_attn = past if (cfg.adaptive_local_attention or not prune) else 0
+            ops.prefill_attn(q, self.arena.k(l), self.arena.v(l), self.arena.head_stride, past_attn, kn, vn, new_stride, n, self.hq,
+                             self.hkv, D, scale, att, q_row0=lo, nq=ml)
+            o = self.b_o[:ml]
+            torch.mm(att.view(ml, self.hq * D), lw.w_o.t(), out=o)
+            if k_keep is not None:
+                ss_all = xall[:, 2 * kv_bytes:].view(torch.float32).view(N, self.hkv, m).permute(1, 0, 2).reshape(self.hkv, N * m)[:, :n].contiguous()
+                idx = self.b_idx[:k_keep]
+                ops.prune_staged(ss_all, self.hkv, n, k_keep, kn, vn, new_stride, self.hkv, D, self.arena.k(l), self.arena.v(l),
+                                 self.arena.head_stride, past, idx)
+                self.arena.len[l] = past + k_keep
+                if self.kept_trace is not None:
+                    self.kept_trace.append((l, idx.clone()))
+            else:
+                self.arena.k(l)[:, past:past + n].copy_(kn[:, :n])
+                self.arena.v(l)[:, past:past + n].copy_(vn[:, :n])
+                self.arena.len[l] = past + n
+                if self.kept_trace is not None:
+                    self.kept_trace.append((l, None))
+            x2 = self.b_x[:ml]
+            ops.add_rmsnorm(h, o, lw.ln2, x2, s.rms_eps)
+            gu = self.b_gu[:ml]
+            torch.mm(x2, lw.w_gate_up.t(), out=gu)
+            act = self.b_act[:ml]
+            ops.swiglu(gu, act)
+            dn = self.b_dn[:ml]
+            torch.mm(act, lw.w_down.t(), out=dn)
+            delta = dn
+        ops.add_inplace(h, delta)
         return h
 
     # ------------------------------------------------------------------ public steps of the group loop

@@ -38,7 +38,17 @@ class OracleOps:
         base = t.as_strided((t.untyped_storage().nbytes() // t.element_size() - t.storage_offset(),), (1,), t.storage_offset())
         return base[h * head_stride + row0 * D: h * head_stride + (row0 + n) * D].view(n, D)
 
-    def prefill_attn(self, q, k_prefix, v_prefix, prefix_head_stride, P, k_new, v_new, new_head_stride, n, n_q, n_kv, D, scale, out):
+    def prefill_attn(self, q, k_prefix, v_prefix, prefix_head_stride, P, k_new, v_new, new_head_stride, n, n_q, n_kv, D, scale, out,
+                     q_row0=0, nq=None):
+        nq = n if nq is None else nq
+        if (q_row0, nq) != (0, n):        # query sub-range: the keys after the last local query are invisible anyway
+            n_vis = q_row0 + nq
+            qfull = torch.zeros(n_vis, n_q, D, dtype=q.dtype)
+            qfull[q_row0:] = q[:nq]
+            tmp = torch.empty(n_vis, n_q, D, dtype=q.dtype)
+            self.prefill_attn(qfull, k_prefix, v_prefix, prefix_head_stride, P, k_new, v_new, new_head_stride, n_vis, n_q, n_kv, D, scale, tmp)
+            out[:nq].copy_(tmp[q_row0:])
+            return
         ks, vs = [], []
         for h in range(n_kv):
             parts_k, parts_v = [], []

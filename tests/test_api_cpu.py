@@ -223,3 +223,60 @@ def test_load_hf_checkpoint_directory(tmp_path):
     obj._ops = OracleOps()
     out = obj.generate("hi", "synthetic://?frames=16&h=56&w=84&seed=1", max_new_tokens=2)
     assert out[0].count("<tok_") == 2
+
+
+# ---------------------------------------------------------------- group-token parallel ("sp") over gloo
+def _sp_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from quickvideo_amd.engine import QuickPrefillEngine
+    from quickvideo_amd.lvu_config import LVUConfig
+    from quickvideo_amd.spec import TextSpec
+    from quickvideo_amd.weights import DecoderWeights
+    so = O.TextSpec(hidden=256, n_heads=4, n_kv_heads=2, head_dim=128, intermediate=256, n_layers=2, vocab=128)
+    spec = TextSpec(hidden=256, n_heads=4, n_kv_heads=2, head_dim=128, intermediate=256, n_layers=2, vocab=128)
+    w = {k: v.to(torch.bfloat16) for k, v in O.synthetic_text_weights(so, seed=5, norm_jitter=0.1).items()}
+    rs = np.random.RandomState(9)
+    groups = [64 * world + 5, 64 * world + 70]          # uneven split: the last rank gets fewer tokens
+    T = sum(groups) + 9
+    embeds = torch.from_numpy(rs.standard_normal((T, 256)).astype(np.float32) * 0.5).to(torch.bfloat16)
+    pos = np.tile(np.arange(T, dtype=np.int64), (3, 1))
+    cfg = LVUConfig("x", top_p=0.5, video_group_size=4)
+    eng = QuickPrefillEngine(DecoderWeights.from_named(spec, w, "cpu"), cfg, capacity=T + 4, max_group_tokens=max(groups), device="cpu",
+                             ops=OracleOps(), sp_group=dist.group.WORLD, sp_rank=rank, sp_size=world)
+    eng.kept_trace = []
+    post = torch.from_numpy(pos)
+    st = 0
+    for n in groups:
+        eng.prefill_group(embeds[st:st + n], post[:, st:st + n]); st += n
+    logits = eng.prefill_tail(embeds[st:], post[:, st:])          # 9 tokens < 64*world: replicated path
+    kept = [None if k is None else k.numpy().copy() for _, k in eng.kept_trace]
+    if rank == 0:
+        ref = O.group_prefill(w, so, embeds, pos, groups, O.PruneCfg(top_p=0.5))
+        ret["ref_logits"], ret["ref_len"] = ref["logits"].numpy(), ref["cache_len"]
+        ret["ref_kept"] = [k for g in ref["kept"] for k in g]
+        ret["ref_k0"] = ref["cache"].k[0].float().numpy()
+    ret[f"logits{rank}"], ret[f"kept{rank}"], ret[f"len{rank}"] = logits.numpy(), kept, list(eng.arena.len)
+    ret[f"k0_{rank}"] = eng.arena.k(0)[:, :eng.arena.len[0]].float().numpy()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_group_token_parallel_gloo(world):
+    port = 33500 + os.getpid() % 2000 + world
+    ret = mp.Manager().dict()
+    mp.spawn(_sp_worker, args=(world, port, ret), nprocs=world, join=True)
+    for r in range(world):
+        assert ret[f"len{r}"] == ret["ref_len"]
+        assert np.array_equal(ret[f"k0_{r}"], ret["k0_0"])                       # every rank holds the identical arena replica
+        assert np.array_equal(ret[f"logits{r}"], ret["logits0"])
+        for a, b in zip(ret[f"kept{r}"], ret["kept0"]):
+            assert (a is None) == (b is None) and (a is None or np.array_equal(a, b))
+    tot = same = 0
+    for a, rk in zip(ret["kept0"], ret["ref_kept"]):
+        if rk is not None:
+            tot += len(rk); same += len(set(a.tolist()) & set(rk.tolist()))
+    assert same / tot >= 0.95
+    assert np.max(np.abs(ret["logits0"] - ret["ref_logits"])) <= 4e-2
+    assert np.max(np.abs(ret["k0_0"] - ret["ref_k0"])) <= 0.25                   # layer-0 keys: per-row GEMM rounding only
