@@ -77,9 +77,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel_s4(AttnParams p) {
   if (kXcd) {
     // Workgroup b is observed to run on XCD b % 8 (used for speed only, never for correctness).  G = 8/Hkv XCDs serve one
     // kv head: all workgroups resident on an XCD stream the same K/V rows, so they hit in that XCD's private L2.
-    const int G = 8 / p.hkv, xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    kvh = xcd / G;
-    j = slot * G + (xcd % G);
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    if (kVit) {
+      // every q block of one (sequence, head) pair runs on the same XCD: its K/V rows are fetched into one L2, not eight
+      kvh = (slot / p.items) * 8 + xcd;
+      j = slot % p.items;
+      if (kvh >= p.hkv) return;
+    } else {
+      const int G = 8 / p.hkv;
+      kvh = xcd / G;
+      j = slot * G + (xcd % G);
+    }
   } else {
     kvh = blockIdx.y; j = blockIdx.x;
   }
@@ -559,8 +567,8 @@ int qp_launch_prefill_attn(const qp_ctx* ctx, const void* q, const void* k_prefi
 }
 
 // Batched non-causal attention of the ViT tower: qkv bf16 [n_seq*S][3][H][80] (after the rotary), out [n_seq*S][H][80].
-// Every (sequence, head) pair is its own "kv head" with one q head; 2-D grid, no kv split (n_seq*H*ceil(S/128) workgroups
-// is several rounds of the chip for the video shapes).
+// Every (sequence, head) pair is its own "kv head" with one q head; 1-D grid with all q blocks of a pair on one XCD (neutral
+// at the video shapes, where the whole qkv fits the MALL), no kv split (n_seq*H*ceil(S/128) workgroups is several rounds).
 int qp_launch_vit_attn(const qp_ctx* ctx, const void* qkv, int64_t n_seq, int64_t S, int heads, float scale, void* out,
                        hipStream_t s) {
   (void)ctx;
@@ -575,6 +583,8 @@ int qp_launch_vit_attn(const qp_ctx* ctx, const void* qkv, int64_t n_seq, int64_
   p.nqb = (int)((S + kQB - 1) / kQB); p.hkv = hk; p.ws = nullptr;
   p.heads_per_seq = heads; p.seq_stride16 = S * row16; p.kv_row_bytes = row16 * 16;
   p.items = p.nqb; p.n_whole = p.nqb; p.nsplit = 1; p.q_row0 = 0; p.nq = (int)S;
-  attn_fwd_kernel_s4<false, D, true><<<dim3((unsigned)p.nqb, (unsigned)hk), 256, 0, s>>>(p);
+  const char* var = getenv("QP_ATTN_VARIANT");        // 3: plain 2-D grid (A/B of the XCD mapping)
+  if (var && atoi(var) == 3) attn_fwd_kernel_s4<false, D, true><<<dim3((unsigned)p.nqb, (unsigned)hk), 256, 0, s>>>(p);
+  else attn_fwd_kernel_s4<true, D, true><<<dim3((unsigned)(((hk + 7) / 8) * 8 * p.nqb)), 256, 0, s>>>(p);
   return qp_check_launch("vit_attn");
 }

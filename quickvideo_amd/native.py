@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libquickprefill.so")
+LIB_PATH = os.environ.get("QUICKPREFILL_LIB") or os.path.join(_HERE, "libquickprefill.so")   # override: kernel A/B builds (tools/)
 
 QP_OK, QP_ERR_INVALID, QP_ERR_UNSUPPORTED, QP_ERR_HIP, QP_ERR_WORKSPACE = 0, -1, -2, -3, -4
 
