@@ -1,0 +1,52 @@
+// Internal definitions shared by the prefill-attention kernels (qp_attn.hip: production/ViT/v1 kernels + launch code,
+// qp_attn_s6.hip: software-pipelined kernel).  Not part of the C ABI.
+#pragma once
+#include "qp_common.h"
+
+namespace qpattn {
+
+constexpr int kQB = 128;     // query rows per workgroup
+constexpr int kKV = 64;      // keys per tile
+constexpr int kD = 128;
+constexpr int kPartialFloats = 4 * 64 * 64 + 4 * 2 * 64;   // per split: O^T raw accumulators [wave][reg][lane] + (m,l) [wave][2][lane]
+
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+
+struct AttnParams {
+  const uint4* q; uint2* out;
+  const uint4* kp; const uint4* vp; int64_t pre_hs16; int64_t P;
+  const uint4* kn; const uint4* vn; int64_t new_hs16; int64_t n;
+  int hq; int group; float c;   // c = scale * log2(e)
+  int nqb; int hkv;
+  int items;                    // q-block x q-head-in-group items per kv head
+  int n_whole;                  // first n_whole items of a kv head run unsplit; the rest are cut into `nsplit` kv ranges
+  int nsplit;
+  float* ws;                    // partial results of split items (kPartialFloats floats each)
+  // batched non-causal mode (ViT tower: D = 80, one sequence per temporal patch, q/k/v interleaved in one qkv row):
+  int heads_per_seq;            // "kv head" index = seq * heads_per_seq + head
+  int64_t seq_stride16;         // uint4 between consecutive sequences (K/V and Q)
+  int kv_row_bytes;             // byte stride between consecutive K/V (and Q) rows
+  // query sub-range (group-token parallel ranks): q/out hold rows [q_row0, q_row0+nq) of the group's n new tokens
+  int q_row0; int nq;
+};
+
+__device__ __forceinline__ bf16x8_t lds_read_b128(const unsigned char* lds, int off) {
+  return *reinterpret_cast<const bf16x8_t*>(lds + off);
+}
+__device__ __forceinline__ s16x4_t lds_read_tr16(const unsigned char* lds, int off) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(lds + off));
+}
+__device__ __forceinline__ float xhalf_max(float x) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float xhalf_sum(float x) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+}  // namespace qpattn
+
+// qp_attn_s6.hip
+void qp_launch_attn_s6(const qpattn::AttnParams& p, bool xcd, unsigned per_kvh, hipStream_t s);

@@ -14,51 +14,12 @@
 //   rows past the segment end read as zero).  Work items are (kv head, q block, kv split): a 1-D grid maps workgroup
 //   b (XCD b%8) to a kv head so that an XCD's private L2 serves one kv head; the heaviest q blocks run first; items
 //   that would form a ragged last round are split along KV (partials in a caller-owned workspace + combine kernel).
-#include "qp_common.h"
+#include "qp_attn.h"
 #include <cstdlib>
 
+using namespace qpattn;
+
 namespace {
-
-constexpr int kQB = 128;     // query rows per workgroup
-constexpr int kKV = 64;      // keys per tile
-constexpr int kD = 128;
-constexpr int kPartialFloats = 4 * 64 * 64 + 4 * 2 * 64;   // per split: O^T raw accumulators [wave][reg][lane] + (m,l) [wave][2][lane]
-
-typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-typedef short s16x8_t __attribute__((ext_vector_type(8)));
-
-struct AttnParams {
-  const uint4* q; uint2* out;
-  const uint4* kp; const uint4* vp; int64_t pre_hs16; int64_t P;
-  const uint4* kn; const uint4* vn; int64_t new_hs16; int64_t n;
-  int hq; int group; float c;   // c = scale * log2(e)
-  int nqb; int hkv;
-  int items;                    // q-block x q-head-in-group items per kv head
-  int n_whole;                  // first n_whole items of a kv head run unsplit; the rest are cut into `nsplit` kv ranges
-  int nsplit;
-  float* ws;                    // partial results of split items (kPartialFloats floats each)
-  // batched non-causal mode (ViT tower: D = 80, one sequence per temporal patch, q/k/v interleaved in one qkv row):
-  int heads_per_seq;            // "kv head" index = seq * heads_per_seq + head
-  int64_t seq_stride16;         // uint4 between consecutive sequences (K/V and Q)
-  int kv_row_bytes;             // byte stride between consecutive K/V (and Q) rows
-  // query sub-range (group-token parallel ranks): q/out hold rows [q_row0, q_row0+nq) of the group's n new tokens
-  int q_row0; int nq;
-};
-
-__device__ __forceinline__ bf16x8_t lds_read_b128(const unsigned char* lds, int off) {
-  return *reinterpret_cast<const bf16x8_t*>(lds + off);
-}
-__device__ __forceinline__ s16x4_t lds_read_tr16(const unsigned char* lds, int off) {
-  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(lds + off));
-}
-__device__ __forceinline__ float xhalf_max(float x) {
-  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
-}
-__device__ __forceinline__ float xhalf_sum(float x) {
-  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
-  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
-}
 
 // ------------------------------------------------------------------------------------------------
 // Production kernel.  kXcd: 1-D grid with the XCD/kv-head mapping (needs 8 % Hkv == 0); otherwise grid = (items, Hkv).
@@ -493,13 +454,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel_v1(AttnParams p) {
 // ranges so that it forms at least one more full round of finer-grained workgroups.
 struct AttnPlan { int items, n_whole, nsplit; };
 
-AttnPlan plan_items(int64_t n, int64_t P, int hq, int hkv, int cus, int split_mode) {
+AttnPlan plan_items(int64_t n, int64_t P, int hq, int hkv, int cus, int split_mode, int wg_per_cu = 3) {
   AttnPlan a;
   const int nqb = (int)((n + kQB - 1) / kQB), group = hq / hkv;
   a.items = nqb * group;
   a.n_whole = a.items; a.nsplit = 1;
   if (split_mode == 0) return a;
-  const int slots = cus * 3 / hkv > 0 ? cus * 3 / hkv : 1;       // 3 resident workgroups per CU (165 VGPRs, 32 KB LDS)
+  const int slots = cus * wg_per_cu / hkv > 0 ? cus * wg_per_cu / hkv : 1;   // resident workgroups per kv head (s4: 3 per CU, s6: 2)
   const int rem = a.items % slots;
   if (rem == 0) return a;
   const int64_t tiles_min = (P + kKV - 1) / kKV + 2;              // tiles of the lightest item (q block 0)
@@ -516,8 +477,13 @@ AttnPlan plan_items(int64_t n, int64_t P, int hq, int hkv, int cus, int split_mo
 }  // namespace
 
 size_t qp_attn_workspace_bytes_impl(const qp_ctx* ctx, int64_t nq, int64_t prefix_len, int hq, int hkv) {
-  AttnPlan a = plan_items(nq, prefix_len, hq, hkv, ctx->cus, 1);
-  return (size_t)hkv * (size_t)(a.items - a.n_whole) * (size_t)a.nsplit * kPartialFloats * sizeof(float) + 256;
+  size_t need = 0;
+  for (int wg = 2; wg <= 3; ++wg) {                        // either kernel may serve the call: size for the larger plan
+    AttnPlan a = plan_items(nq, prefix_len, hq, hkv, ctx->cus, 1, wg);
+    const size_t b = (size_t)hkv * (size_t)(a.items - a.n_whole) * (size_t)a.nsplit * kPartialFloats * sizeof(float);
+    if (b > need) need = b;
+  }
+  return need + 256;
 }
 
 int qp_launch_prefill_attn(const qp_ctx* ctx, const void* q, const void* k_prefix, const void* v_prefix,
@@ -543,7 +509,7 @@ int qp_launch_prefill_attn(const qp_ctx* ctx, const void* q, const void* k_prefi
     return qp_check_launch("prefill_attn(v1)");
   }
   // variant 2: no kv split; variant 3: no XCD mapping
-  AttnPlan a = plan_items(nq, prefix_len + q_row0, hq, hkv, ctx->cus, (variant == 2 || workspace == nullptr) ? 0 : 1);
+  AttnPlan a = plan_items(nq, prefix_len + q_row0, hq, hkv, ctx->cus, (variant == 2 || workspace == nullptr) ? 0 : 1, variant == 6 ? 2 : 3);
   p.items = a.items; p.n_whole = a.n_whole; p.nsplit = a.nsplit;
   if (a.nsplit > 1) {
     const size_t need = (size_t)hkv * (size_t)(a.items - a.n_whole) * (size_t)a.nsplit * kPartialFloats * sizeof(float);
@@ -551,7 +517,9 @@ int qp_launch_prefill_attn(const qp_ctx* ctx, const void* q, const void* k_prefi
   }
   const int per_kvh = a.n_whole + (a.items - a.n_whole) * a.nsplit;
   const bool xcd = (hkv <= 8 && 8 % hkv == 0 && variant != 3);
-  if (xcd) {
+  if (variant == 6) {
+    qp_launch_attn_s6(p, xcd, (unsigned)per_kvh, s);
+  } else if (xcd) {
     const int G = 8 / hkv;
     attn_fwd_kernel_s4<true, 128, false><<<dim3(8 * ((per_kvh + G - 1) / G)), 256, 0, s>>>(p);
   } else {
