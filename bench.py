@@ -292,8 +292,8 @@ def main():
         traffic = None            # HBM bytes per launch from the committed rocprofv3 PMC passes (tools/profile_bench.sh), same command
         tpath = os.path.join(ROOT, "profiles", "attn_pmc_traffic_latest.json")
         if args.config == "cfg2" and world == 1 and os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("attn_fwd_kernel_s4", {}).get("traffic_bytes_per_launch")
-        roofline = {"kernel": "attn_fwd_kernel_s4 (MFMA prefill attention over pruned prefix + causal tail)", "bound": "mfma",
+            traffic = json.load(open(tpath)).get("attn_fwd_kernel_s6", {}).get("traffic_bytes_per_launch")
+        roofline = {"kernel": "attn_fwd_kernel_s6 (MFMA prefill attention over pruned prefix + causal tail)", "bound": "mfma",
                     "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
                     "traffic": traffic, "launches": att_n, "avg_launch_ms": round(att_ms / max(att_n, 1), 4),
                     "algorithmic_flops_per_step": att_local}

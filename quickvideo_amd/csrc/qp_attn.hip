@@ -508,8 +508,8 @@ int qp_launch_prefill_attn(const qp_ctx* ctx, const void* q, const void* k_prefi
     attn_fwd_kernel_v1<<<dim3((unsigned)p.nqb, (unsigned)hq), 256, 0, s>>>(p);
     return qp_check_launch("prefill_attn(v1)");
   }
-  // variant 2: no kv split; variant 3: no XCD mapping
-  AttnPlan a = plan_items(nq, prefix_len + q_row0, hq, hkv, ctx->cus, (variant == 2 || workspace == nullptr) ? 0 : 1, variant == 6 ? 2 : 3);
+  // variant 2: no kv split; variant 3: no XCD mapping; variant 4: previous production kernel s4 (phase-sequential waves)
+  AttnPlan a = plan_items(nq, prefix_len + q_row0, hq, hkv, ctx->cus, (variant == 2 || workspace == nullptr) ? 0 : 1, variant == 4 ? 3 : 2);
   p.items = a.items; p.n_whole = a.n_whole; p.nsplit = a.nsplit;
   if (a.nsplit > 1) {
     const size_t need = (size_t)hkv * (size_t)(a.items - a.n_whole) * (size_t)a.nsplit * kPartialFloats * sizeof(float);
@@ -517,7 +517,7 @@ int qp_launch_prefill_attn(const qp_ctx* ctx, const void* q, const void* k_prefi
   }
   const int per_kvh = a.n_whole + (a.items - a.n_whole) * a.nsplit;
   const bool xcd = (hkv <= 8 && 8 % hkv == 0 && variant != 3);
-  if (variant == 6) {
+  if (variant != 4) {                                    // production: software-pipelined kernel (qp_attn_s6.hip); 4: s4
     qp_launch_attn_s6(p, xcd, (unsigned)per_kvh, s);
   } else if (xcd) {
     const int G = 8 / hkv;
