@@ -5,10 +5,11 @@
 
 namespace qpattn {
 
-constexpr int kQB = 128;     // query rows per workgroup
+constexpr int kQB = 128;     // query rows per workgroup of the 4-wave kernels (s4, v1, s6<4>); s6<8> uses 256 (AttnParams::qb_rows)
 constexpr int kKV = 64;      // keys per tile
 constexpr int kD = 128;
-constexpr int kPartialFloats = 4 * 64 * 64 + 4 * 2 * 64;   // per split: O^T raw accumulators [wave][reg][lane] + (m,l) [wave][2][lane]
+constexpr int kPartialFloats = 4 * 64 * 64 + 4 * 2 * 64;   // per split of a 128-row item: O^T raw accumulators [wave][reg][lane] + (m,l) [wave][2][lane]
+constexpr int partial_floats(int qb_rows) { return (qb_rows / 32) * (64 * 64 + 2 * 64); }   // ... of a qb_rows-row item
 
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 typedef short s16x8_t __attribute__((ext_vector_type(8)));
@@ -29,6 +30,7 @@ struct AttnParams {
   int kv_row_bytes;             // byte stride between consecutive K/V (and Q) rows
   // query sub-range (group-token parallel ranks): q/out hold rows [q_row0, q_row0+nq) of the group's n new tokens
   int q_row0; int nq;
+  int qb_rows;                  // query rows per workgroup / work item (128 or 256); partials hold partial_floats(qb_rows) floats
 };
 
 __device__ __forceinline__ bf16x8_t lds_read_b128(const unsigned char* lds, int off) {
@@ -49,4 +51,4 @@ __device__ __forceinline__ float xhalf_sum(float x) {
 }  // namespace qpattn
 
 // qp_attn_s6.hip
-void qp_launch_attn_s6(const qpattn::AttnParams& p, bool xcd, unsigned per_kvh, hipStream_t s);
+void qp_launch_attn_s6(const qpattn::AttnParams& p, bool xcd, unsigned per_kvh, hipStream_t s);   // p.qb_rows selects 4 or 8 waves

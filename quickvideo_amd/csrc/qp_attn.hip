@@ -15,7 +15,13 @@
 //   b (XCD b%8) to a kv head so that an XCD's private L2 serves one kv head; the heaviest q blocks run first; items
 //   that would form a ragged last round are split along KV (partials in a caller-owned workspace + combine kernel).
 #include "qp_attn.h"
+#include <algorithm>
+#include <cstdio>
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
 
 using namespace qpattn;
 
@@ -241,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel_s4(AttnParams p) {
 // are independent.
 constexpr int kMaxSplit = 16;
 template <int D, bool kVit>
-__global__ __launch_bounds__(256) void attn_combine_kernel(AttnParams p) {
+__global__ __launch_bounds__(512) void attn_combine_kernel(AttnParams p) {   // blockDim = 2 * qb_rows (one thread per query x half)
   constexpr int NDB = (D + 31) / 32;
   const int n_split_items = p.items - p.n_whole;
   const int kvh = blockIdx.x / n_split_items, it = blockIdx.x % n_split_items;
@@ -249,15 +255,16 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(AttnParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
   const int qb = p.nqb - 1 - item / p.group;
   const int head = kvh * p.group + item % p.group;
-  const int qi = qb * kQB + wave * 32 + (lane & 31);
-  const float* base = p.ws + (int64_t)(kvh * n_split_items + it) * p.nsplit * kPartialFloats;
+  const int qi = qb * p.qb_rows + wave * 32 + (lane & 31);
+  const int pfl = partial_floats(p.qb_rows), o_floats = p.qb_rows * 128;
+  const float* base = p.ws + (int64_t)(kvh * n_split_items + it) * p.nsplit * pfl;
   float ms[kMaxSplit], f[kMaxSplit];
   float M = -1e30f;
 #pragma unroll
   for (int s = 0; s < kMaxSplit; ++s) {
     ms[s] = -1e30f; f[s] = 0.f;
     if (s < p.nsplit) {
-      const float* wm = base + (int64_t)s * kPartialFloats + 4 * 64 * 64 + wave * 128 + lane;
+      const float* wm = base + (int64_t)s * pfl + o_floats + wave * 128 + lane;
       ms[s] = wm[0]; f[s] = wm[64];                      // f temporarily holds l_s
     }
   }
@@ -274,7 +281,7 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(AttnParams p) {
 #pragma unroll
   for (int r = 0; r < NDB * 4; ++r) acc[r] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
   for (int s = 0; s < p.nsplit; ++s) {
-    const f32x4_t* wo = reinterpret_cast<const f32x4_t*>(base + (int64_t)s * kPartialFloats) + (wave * 16) * 64 + lane;
+    const f32x4_t* wo = reinterpret_cast<const f32x4_t*>(base + (int64_t)s * pfl) + (wave * 16) * 64 + lane;
     float fs = f[0];
 #pragma unroll
     for (int k = 1; k < kMaxSplit; ++k) fs = (s == k) ? f[k] : fs;       // static indexing only (runtime index -> scratch)
@@ -449,28 +456,80 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel_v1(AttnParams p) {
   }
 }
 
-// Work-item plan of one launch: per kv head, `items` = nqb*group items sorted heaviest first; with S workgroup slots per
-// kv head the first floor(items/S)*S items (whole rounds) run unsplit and the ragged remainder is cut into `nsplit` kv
-// ranges so that it forms at least one more full round of finer-grained workgroups.
-struct AttnPlan { int items, n_whole, nsplit; };
+// Work-item plan of one launch.  Per kv head there are `items` = nqb*group items (q block x q head), dispatched heaviest
+// (latest q block) first onto S = CUs * workgroups-per-CU / Hkv resident workgroup slots.  The first `n_whole` items run
+// unsplit; the ragged remainder is cut into `nsplit` kv ranges whose partials are merged by attn_combine_kernel.  n_whole and
+// nsplit are chosen by simulating that dispatch (greedy: next workgroup to the first free slot) with per-item tile counts and
+// taking the smallest makespan; the same estimate picks between the 4-wave (128-row, 2 per CU) and 8-wave (256-row, 1 per CU)
+// forms of the s6 kernel, which differ mostly in how the grid quantises.  Plans are cached per shape.
+struct AttnPlan { int items, n_whole, nsplit, rows; double cost; };
 
-AttnPlan plan_items(int64_t n, int64_t P, int hq, int hkv, int cus, int split_mode, int wg_per_cu = 3) {
+double simulate_makespan(int64_t nq, int64_t Peff, int group, int nqb, int rows, int slots, int n_whole, int ns, double c0) {
+  const int items = nqb * group;
+  std::vector<double> heap(slots, 0.0);                           // min-heap of slot finish times
+  auto cmp = [](double x, double y) { return x > y; };
+  double makespan = 0.0;
+  auto place = [&](double w) {
+    std::pop_heap(heap.begin(), heap.end(), cmp);
+    double& t = heap.back();
+    t += w;
+    if (t > makespan) makespan = t;
+    std::push_heap(heap.begin(), heap.end(), cmp);
+  };
+  const int64_t ntp = (Peff + kKV - 1) / kKV;
+  auto tiles_of = [&](int item) {
+    const int qb = nqb - 1 - item / group;
+    int64_t end = (int64_t)(qb + 1) * rows; if (end > nq) end = nq;
+    return (double)(ntp + (end + kKV - 1) / kKV);
+  };
+  for (int it = 0; it < n_whole; ++it) place(tiles_of(it) + c0);
+  for (int it = n_whole; it < items; ++it) {
+    const double t = tiles_of(it);
+    for (int sp = 0; sp < ns; ++sp) place(t / ns + c0 + 1.0);     // + partial store
+  }
+  return makespan;
+}
+
+AttnPlan plan_items(int64_t n, int64_t P, int hq, int hkv, int cus, int split_mode, int wg_per_cu = 3, int qb_rows = kQB) {
   AttnPlan a;
-  const int nqb = (int)((n + kQB - 1) / kQB), group = hq / hkv;
-  a.items = nqb * group;
-  a.n_whole = a.items; a.nsplit = 1;
+  const int nqb = (int)((n + qb_rows - 1) / qb_rows), group = hq / hkv;
+  a.items = nqb * group; a.rows = qb_rows;
+  a.n_whole = a.items; a.nsplit = 1; a.cost = 0.0;
+  const int slots = cus * wg_per_cu / hkv > 0 ? cus * wg_per_cu / hkv : 1;   // resident workgroups per kv head
+  const double c0 = wg_per_cu == 1 ? 6.0 : 4.0;                  // prologue + epilogue of a workgroup, in tile steps
+  const double tstep = qb_rows == 256 ? 0.95 : 1.0;              // measured: an 8-wave tile step is ~5 % shorter (half the DMA pieces per wave)
+  a.cost = simulate_makespan(n, P, group, nqb, qb_rows, slots, a.items, 1, c0) * tstep;
   if (split_mode == 0) return a;
-  const int slots = cus * wg_per_cu / hkv > 0 ? cus * wg_per_cu / hkv : 1;   // resident workgroups per kv head (s4: 3 per CU, s6: 2)
-  const int rem = a.items % slots;
-  if (rem == 0) return a;
   const int64_t tiles_min = (P + kKV - 1) / kKV + 2;              // tiles of the lightest item (q block 0)
-  int ns = (slots + rem - 1) / rem;                               // enough pieces for one more full round
-  if (a.items < slots) ns = (2 * slots + rem - 1) / rem;          // under-filled grid: aim at two rounds
   int64_t cap = tiles_min / 4; if (cap < 1) cap = 1;              // keep >= 4 tiles per piece
-  if (ns > cap) ns = (int)cap;
-  if (ns > kMaxSplit) ns = kMaxSplit;
-  if (ns <= 1) return a;
-  a.n_whole = a.items - rem; a.nsplit = ns;
+  if (cap > kMaxSplit) cap = kMaxSplit;
+  const int full = a.items / slots * slots;
+  for (int pass = 0; pass < 2; ++pass) {
+    const int nw = pass == 0 ? full : full - slots;               // split the last ragged round, or that and one full round
+    if (nw < 0 || nw == a.items) continue;
+    for (int ns = 2; ns <= (int)cap; ++ns) {
+      const double c = (simulate_makespan(n, P, group, nqb, qb_rows, slots, nw, ns, c0) + 3.0) * tstep;   // + combine launch
+      if (c < a.cost * 0.995) { a.cost = c; a.n_whole = nw; a.nsplit = ns; }
+    }
+  }
+  return a;
+}
+
+// cached plans: same (shape, prefix) for every layer of a group
+AttnPlan plan_cached(int64_t n, int64_t P, int hq, int hkv, int cus, int split_mode, int wg_per_cu, int qb_rows) {
+  typedef std::tuple<int64_t, int64_t, int, int, int, int, int, int> Key;
+  static std::map<Key, AttnPlan> cache;
+  static std::mutex mu;
+  const Key k(n, P, hq, hkv, cus, split_mode, wg_per_cu, qb_rows);
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = cache.find(k);
+  if (it != cache.end()) return it->second;
+  if (cache.size() > 4096) cache.clear();
+  const AttnPlan a = plan_items(n, P, hq, hkv, cus, split_mode, wg_per_cu, qb_rows);
+  if (getenv("QP_ATTN_DEBUG"))
+    fprintf(stderr, "[qp_attn plan] n=%lld P=%lld hq=%d hkv=%d wg/cu=%d rows=%d: items=%d n_whole=%d nsplit=%d cost=%.1f\n", (long long)n,
+            (long long)P, hq, hkv, wg_per_cu, qb_rows, a.items, a.n_whole, a.nsplit, a.cost);
+  cache[k] = a;
   return a;
 }
 
@@ -478,9 +537,10 @@ AttnPlan plan_items(int64_t n, int64_t P, int hq, int hkv, int cus, int split_mo
 
 size_t qp_attn_workspace_bytes_impl(const qp_ctx* ctx, int64_t nq, int64_t prefix_len, int hq, int hkv) {
   size_t need = 0;
-  for (int wg = 2; wg <= 3; ++wg) {                        // either kernel may serve the call: size for the larger plan
-    AttnPlan a = plan_items(nq, prefix_len, hq, hkv, ctx->cus, 1, wg);
-    const size_t b = (size_t)hkv * (size_t)(a.items - a.n_whole) * (size_t)a.nsplit * kPartialFloats * sizeof(float);
+  for (int cfg = 0; cfg < 3; ++cfg) {                      // any of the kernels may serve the call: size for the largest plan
+    const int wg = cfg == 0 ? 3 : cfg == 1 ? 2 : 1, rows = cfg == 2 ? 256 : 128;     // s4 | s6<4> | s6<8>
+    AttnPlan a = plan_cached(nq, prefix_len, hq, hkv, ctx->cus, 1, wg, rows);
+    const size_t b = (size_t)hkv * (size_t)(a.items - a.n_whole) * (size_t)a.nsplit * partial_floats(rows) * sizeof(float);
     if (b > need) need = b;
   }
   return need + 256;
@@ -498,7 +558,7 @@ int qp_launch_prefill_attn(const qp_ctx* ctx, const void* q, const void* k_prefi
   p.nqb = (int)((nq + kQB - 1) / kQB); p.hkv = hkv; p.ws = (float*)workspace;
   p.items = p.nqb * p.group; p.n_whole = p.items; p.nsplit = 1;
   p.heads_per_seq = hkv; p.seq_stride16 = 0; p.kv_row_bytes = 256;
-  p.q_row0 = (int)q_row0; p.nq = (int)nq;
+  p.q_row0 = (int)q_row0; p.nq = (int)nq; p.qb_rows = kQB;
   const char* var = getenv("QP_ATTN_VARIANT");        // developer A/B switch (tools/bench_attn.py); default = production kernel
   const int variant = var ? atoi(var) : 0;
   const bool big = prefix_len * 256 >= (1ll << 31) || n * 256 >= (1ll << 31);
@@ -508,11 +568,24 @@ int qp_launch_prefill_attn(const qp_ctx* ctx, const void* q, const void* k_prefi
     attn_fwd_kernel_v1<<<dim3((unsigned)p.nqb, (unsigned)hq), 256, 0, s>>>(p);
     return qp_check_launch("prefill_attn(v1)");
   }
-  // variant 2: no kv split; variant 3: no XCD mapping; variant 4: previous production kernel s4 (phase-sequential waves)
-  AttnPlan a = plan_items(nq, prefix_len + q_row0, hq, hkv, ctx->cus, (variant == 2 || workspace == nullptr) ? 0 : 1, variant == 4 ? 3 : 2);
+  // variant 2: no kv split; variant 3: no XCD mapping; variant 4: previous production kernel s4 (phase-sequential waves);
+  // variant 7 / 8: s6 with 4-wave (128 rows, 2 per CU) / 8-wave (256 rows, 1 per CU) workgroups
+  // default: whichever s6 form the dispatch simulation predicts to finish first; 8: force 8-wave
+  const int split_mode = (variant == 2 || workspace == nullptr) ? 0 : 1;
+  AttnPlan a;
+  if (variant == 4) a = plan_cached(nq, prefix_len + q_row0, hq, hkv, ctx->cus, split_mode, 3, 128);
+  else if (variant == 7) a = plan_cached(nq, prefix_len + q_row0, hq, hkv, ctx->cus, split_mode, 2, 128);
+  else if (variant == 8) a = plan_cached(nq, prefix_len + q_row0, hq, hkv, ctx->cus, split_mode, 1, 256);
+  else {
+    a = plan_cached(nq, prefix_len + q_row0, hq, hkv, ctx->cus, split_mode, 2, 128);
+    const AttnPlan b = plan_cached(nq, prefix_len + q_row0, hq, hkv, ctx->cus, split_mode, 1, 256);
+    if (b.cost < a.cost) a = b;
+  }
+  const int rows = a.rows;
+  p.qb_rows = rows; p.nqb = (int)((nq + rows - 1) / rows);
   p.items = a.items; p.n_whole = a.n_whole; p.nsplit = a.nsplit;
   if (a.nsplit > 1) {
-    const size_t need = (size_t)hkv * (size_t)(a.items - a.n_whole) * (size_t)a.nsplit * kPartialFloats * sizeof(float);
+    const size_t need = (size_t)hkv * (size_t)(a.items - a.n_whole) * (size_t)a.nsplit * partial_floats(rows) * sizeof(float);
     if (workspace_bytes < need) return qp_fail(QP_ERR_WORKSPACE, "qp_prefill_attn: workspace %zu < %zu bytes", workspace_bytes, need);
   }
   const int per_kvh = a.n_whole + (a.items - a.n_whole) * a.nsplit;
@@ -528,7 +601,7 @@ int qp_launch_prefill_attn(const qp_ctx* ctx, const void* q, const void* k_prefi
   int rc = qp_check_launch("prefill_attn");
   if (rc) return rc;
   if (a.nsplit > 1) {
-    attn_combine_kernel<128, false><<<dim3((unsigned)(hkv * (a.items - a.n_whole))), 256, 0, s>>>(p);
+    attn_combine_kernel<128, false><<<dim3((unsigned)(hkv * (a.items - a.n_whole))), 2 * rows, 0, s>>>(p);
     rc = qp_check_launch("prefill_attn(combine)");
   }
   return rc;
@@ -550,7 +623,7 @@ int qp_launch_vit_attn(const qp_ctx* ctx, const void* qkv, int64_t n_seq, int64_
   p.hq = hk; p.group = 1; p.c = scale * 1.4426950408889634f;
   p.nqb = (int)((S + kQB - 1) / kQB); p.hkv = hk; p.ws = nullptr;
   p.heads_per_seq = heads; p.seq_stride16 = S * row16; p.kv_row_bytes = row16 * 16;
-  p.items = p.nqb; p.n_whole = p.nqb; p.nsplit = 1; p.q_row0 = 0; p.nq = (int)S;
+  p.items = p.nqb; p.n_whole = p.nqb; p.nsplit = 1; p.q_row0 = 0; p.nq = (int)S; p.qb_rows = kQB;
   const char* var = getenv("QP_ATTN_VARIANT");        // 3: plain 2-D grid (A/B of the XCD mapping)
   if (var && atoi(var) == 3) attn_fwd_kernel_s4<false, D, true><<<dim3((unsigned)p.nqb, (unsigned)hk), 256, 0, s>>>(p);
   else attn_fwd_kernel_s4<true, D, true><<<dim3((unsigned)(((hk + 7) / 8) * 8 * p.nqb)), 256, 0, s>>>(p);

@@ -12,6 +12,8 @@ if os.environ.get("QP_SHAPES") == "small":
     shapes = shapes[:3]
 if os.environ.get("QP_SHAPES") == "one":
     shapes = shapes[2:3]
+if os.environ.get("QP_SHAPES") == "sweep":          # 4- vs 8-wave workgroup crossover
+    shapes = [(n, P, 28, 4) for n in (2240, 5760) for P in (16000, 32000, 64000)]
 
 def bench(f, it=10):
     for _ in range(2): f()
@@ -37,8 +39,10 @@ for (n, P, hq, hkv) in shapes:
     sc = sc.masked_fill(torch.arange(P + n, device="cuda")[None, :] > ii, float("-inf"))
     ref = torch.einsum("hrk,hkd->rhd", torch.softmax(sc, -1), vv)
     del sc, kk, vv
-    for var in variants:
+    for vi, var in enumerate(variants):
         os.environ["QP_ATTN_VARIANT"] = var
+        if vi == 0:                                   # clocks / caches warm before the first timed variant
+            bench(lambda: ops.prefill_attn(q, k, v, (P + n) * D, P, k[:, P:], v[:, P:], (P + n) * D, n, hq, hkv, D, D ** -0.5, out), it=20)
         f = lambda: ops.prefill_attn(q, k, v, (P + n) * D, P, k[:, P:], v[:, P:], (P + n) * D, n, hq, hkv, D, D ** -0.5, out)
         out.zero_(); f(); torch.cuda.synchronize()
         err = (out[rows].float() - ref).abs().max().item()
