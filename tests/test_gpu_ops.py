@@ -425,3 +425,48 @@ def test_prefill_attn_query_subranges(ops, n, P, hq, hkv, parts):
     assert (got.float() - full.float()).abs().max().item() <= 4e-3     # only the kv-split plan may differ between the two
     with pytest.raises(ValueError):
         ops.prefill_attn(q[:10].contiguous(), k, v, (P + n) * D, P, k[:, P:], v[:, P:], (P + n) * D, n, hq, hkv, D, 1.0, full, q_row0=n - 5, nq=10)
+
+
+@pytest.mark.parametrize("variant", ["4", "7", "8", "2"])
+def test_prefill_attn_every_kernel_form(ops, variant, monkeypatch):
+    """The launch picks a kernel form per shape (s6 with 4- or 8-wave workgroups, planner-chosen kv-split); force each form
+    (QP_ATTN_VARIANT: 4 = s4, 7 / 8 = s6 4- / 8-wave, 2 = no kv split) over ragged sizes, prefix lengths around the tile size,
+    single-tile and sub-range launches, and the rescale branch."""
+    monkeypatch.setenv("QP_ATTN_VARIANT", variant)
+    for (n, P, hq, hkv, staged) in [(1, 0, 2, 1, True), (31, 1, 2, 1, False), (64, 63, 4, 2, True), (65, 64, 2, 1, False),
+                                    (127, 65, 4, 4, True), (256, 0, 2, 1, False), (257, 191, 7, 1, True), (300, 1000, 6, 2, False),
+                                    (640, 129, 8, 1, True), (1100, 4000, 28, 4, False)]:
+        attn_case(ops, n, P, hq, hkv, staged, seed=n * 7 + P + int(variant))
+    attn_case(ops, 300, 500, 4, 2, True, seed=5, spike=True)
+    # query sub-ranges tile the full result (same K/V, different q_row0)
+    n, P, hq, hkv = 700, 333, 8, 2
+    g = torch.Generator(device="cuda"); g.manual_seed(11)
+    q = torch.randn(n, hq, D, generator=g, device="cuda").to(torch.bfloat16)
+    k = torch.randn(hkv, P + n, D, generator=g, device="cuda").to(torch.bfloat16)
+    v = torch.randn(hkv, P + n, D, generator=g, device="cuda").to(torch.bfloat16)
+    full = torch.empty(n, hq, D, dtype=torch.bfloat16, device="cuda")
+    ops.prefill_attn(q, k, v, (P + n) * D, P, k[:, P:], v[:, P:], (P + n) * D, n, hq, hkv, D, D ** -0.5, full)
+    for lo, hi in [(0, 233), (233, 500), (500, 700)]:
+        out = torch.zeros(hi - lo, hq, D, dtype=torch.bfloat16, device="cuda")
+        ops.prefill_attn(q[lo:hi].contiguous(), k, v, (P + n) * D, P, k[:, P:], v[:, P:], (P + n) * D, n, hq, hkv, D, D ** -0.5, out,
+                         q_row0=lo, nq=hi - lo)
+        assert (out.float() - full[lo:hi].float()).abs().max().item() <= 4e-3
+
+
+def test_prefill_attn_forms_agree_at_full_size(ops, monkeypatch):
+    """s4, s6<4> and s6<8> compute the same math in a different instruction order: outputs agree to bf16 rounding at cfg2 size."""
+    n, P, hq, hkv = 5760, 8647, 28, 4
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    q = torch.randn(n, hq, D, generator=g, device="cuda").to(torch.bfloat16)
+    k = torch.randn(hkv, P + n, D, generator=g, device="cuda").to(torch.bfloat16)
+    v = torch.randn(hkv, P + n, D, generator=g, device="cuda").to(torch.bfloat16)
+    outs = {}
+    for variant in ("4", "7", "8"):
+        monkeypatch.setenv("QP_ATTN_VARIANT", variant)
+        o = torch.empty(n, hq, D, dtype=torch.bfloat16, device="cuda")
+        ops.prefill_attn(q, k, v, (P + n) * D, P, k[:, P:], v[:, P:], (P + n) * D, n, hq, hkv, D, D ** -0.5, o)
+        outs[variant] = o.float()
+    torch.cuda.synchronize()
+    for a, b in (("4", "7"), ("4", "8")):
+        d = (outs[a] - outs[b]).abs()
+        assert d.max().item() <= 4e-3 and d.mean().item() < 1e-4, (a, b, d.max().item(), d.mean().item())   # ~1 bf16 ulp of the outputs
