@@ -575,7 +575,7 @@ int qp_launch_prefill_attn(const qp_ctx* ctx, const void* q, const void* k_prefi
   AttnPlan a;
   if (variant == 4) a = plan_cached(nq, prefix_len + q_row0, hq, hkv, ctx->cus, split_mode, 3, 128);
   else if (variant == 7) a = plan_cached(nq, prefix_len + q_row0, hq, hkv, ctx->cus, split_mode, 2, 128);
-  else if (variant == 8) a = plan_cached(nq, prefix_len + q_row0, hq, hkv, ctx->cus, split_mode, 1, 256);
+  else if (variant == 8 || variant == 9) a = plan_cached(nq, prefix_len + q_row0, hq, hkv, ctx->cus, split_mode, 1, 256);
   else {
     a = plan_cached(nq, prefix_len + q_row0, hq, hkv, ctx->cus, split_mode, 2, 128);
     const AttnPlan b = plan_cached(nq, prefix_len + q_row0, hq, hkv, ctx->cus, split_mode, 1, 256);
