@@ -28,7 +28,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from quickvideo_amd import planner  # noqa: E402
-from quickvideo_amd.engine import QuickPrefillEngine  # noqa: E402
+from quickvideo_amd.engine import QuickPrefillEngine, sp_row_ranges  # noqa: E402
 from quickvideo_amd.lvu_config import LVUConfig, effective_k  # noqa: E402
 from quickvideo_amd.spec import PRESETS  # noqa: E402
 from quickvideo_amd.weights import DecoderWeights  # noqa: E402
@@ -276,14 +276,13 @@ def main():
         eng.ops = real_ops
         tot = timed.totals_ms()
         att_ms, att_n = tot["prefill_attn"]
-        att_local = att / world                                  # tp: heads sharded; sp: query rows sharded (rank 0 = earliest rows)
+        att_local = att / world                                  # tp: heads sharded; sp: query rows sharded (zigzag chunks)
         if world > 1 and args.parallel == "sp":
             att_local, Pp = 0.0, 0
             for n in plan.tokens:
-                m = -(-n // world)
-                lo, hi = min(n, rank * m), min(n, (rank + 1) * m)
                 if n >= 64 * world:
-                    att_local += 4.0 * spec.n_layers * spec.n_heads * spec.head_dim * sum(Pp + i + 1 for i in range(lo, hi))
+                    for lo, hi in sp_row_ranges(n, world, rank):     # this rank's two zigzag chunks
+                        att_local += 4.0 * spec.n_layers * spec.n_heads * spec.head_dim * sum(Pp + i + 1 for i in range(lo, hi))
                 else:
                     att_local += spec.attn_flops(n, Pp)
                 Pp += effective_k(n, cfg, 0, spec.n_layers) or n

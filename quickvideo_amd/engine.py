@@ -26,6 +26,15 @@ from .spec import TextSpec
 from .weights import DecoderWeights
 
 
+def sp_row_ranges(n: int, world: int, rank: int):
+    """Group-token parallel row assignment: the n rows are cut into 2*world chunks of ceil(n / (2*world)) rows; rank r owns
+    chunks r and 2*world-1-r, which balances the causal attention work.  Returns ((a0, a1), (b0, b1)), possibly empty ranges."""
+    m2 = -(-n // (2 * world))
+    a0, a1 = min(n, rank * m2), min(n, (rank + 1) * m2)
+    b0, b1 = min(n, (2 * world - 1 - rank) * m2), min(n, (2 * world - rank) * m2)
+    return (a0, a1), (b0, b1)
+
+
 class KVArena:
     """Pre-allocated per-layer KV store.  k(l)/v(l): [Hkv_local, capacity, D]; len[l] = rows in use."""
 
@@ -74,9 +83,9 @@ class QuickPrefillEngine:
         self.b_qkv = e(n, (self.hq + 2 * self.hkv) * self.D)
         self.b_q, self.b_att = e(n, self.hq, self.D), e(n, self.hq, self.D)
         self.b_gu, self.b_act = e(n, 2 * self.li), e(n, self.li)
-        self.b_stage = e(2, self.hkv, n + self.sp_size, self.D)
+        self.b_stage = e(2, self.hkv, n + 2 * self.sp_size, self.D)
         if self.sp_size > 1:
-            m = -(-n // self.sp_size)
+            m = 2 * -(-n // (2 * self.sp_size))                                           # two chunks of ceil(n / 2N) rows
             self.sp_chunk = 2 * self.hkv * m * self.D * 2 + self.hkv * m * 4              # bytes: K | V | key sums of one rank
             self.b_xsend = e(self.sp_chunk, dtype=torch.uint8)
             self.b_xall = e(self.sp_size * self.sp_chunk, dtype=torch.uint8)
@@ -194,21 +203,27 @@ class QuickPrefillEngine:
 
     # ------------------------------------------------------------------ group-token parallel variant of forward_segment
     def _forward_segment_sp(self, embeds: torch.Tensor, pos: torch.Tensor, prune: bool) -> torch.Tensor:
-        """Rank r runs tokens [r*m, (r+1)*m) of the segment (m = ceil(n/N)) through every layer; per layer ONE all-gather
-        moves the ranks' new K/V rows and key sums, after which every rank holds the whole group's K/V in its staging block,
-        attends its own query rows (qp_prefill_attn_rows) and applies the identical prune to its arena replica.
+        """Rank r runs its token rows of the segment through every layer; per layer ONE all-gather moves the ranks' new K/V rows
+        and key sums, after which every rank holds the whole group's K/V in its staging block, attends its own query rows
+        (qp_prefill_attn_rows) and applies the identical prune to its arena replica.  Rows are dealt "zigzag" (sp_row_ranges):
+        the segment is cut into 2N chunks and rank r takes chunks r and 2N-1-r, so every rank gets the same share of the causal
+        attention work (an early, cheap chunk plus a late, expensive one).
         Returns this rank's hidden rows (callers only need them for the replicated prompt tail)."""
         s, ops, cfg, D, N, r = self.spec, self.ops, self.cfg, self.D, self.sp_size, self.sp_rank
         n = embeds.shape[0]
         if cfg.enable and isinstance(cfg.prefill_prune_starting_layer, int) and cfg.prefill_prune_starting_layer >= 0 and prune:
             raise NotImplementedError("hidden-state pruning (prefill_prune_starting_layer) is not combined with group-token parallelism")
-        m = -(-n // N)
-        lo, hi = min(n, r * m), min(n, (r + 1) * m)
-        ml = hi - lo
+        (a0, a1), (b0, b1) = sp_row_ranges(n, N, r)
+        m2 = -(-n // (2 * N))
+        m = 2 * m2                                   # rows per rank slot in the exchange buffers
+        nA, nB = a1 - a0, b1 - b0
+        ml = nA + nB                                 # local rows: [chunk r | chunk 2N-1-r]; nA == m2 whenever nB > 0
         L = len(self.w.layers)
-        cos, sin = ops.mrope_table(pos[:, lo:hi].contiguous(), s.mrope_section, s.rope_theta, D)
+        rows = torch.cat([torch.arange(a0, a1, device=self.device), torch.arange(b0, b1, device=self.device)])
+        cos, sin = ops.mrope_table(pos.index_select(1, rows).contiguous(), s.mrope_section, s.rope_theta, D)
         h = self.b_h[:ml]
-        h.copy_(embeds[lo:hi])
+        h[:nA].copy_(embeds[a0:a1])
+        h[nA:].copy_(embeds[b0:b1])
         delta = None
         scale = D ** -0.5
         kv_bytes = self.hkv * m * D * 2
@@ -218,8 +233,10 @@ class QuickPrefillEngine:
         chunk = 2 * kv_bytes + self.hkv * m * 4
         xall = self.b_xall[: N * chunk].view(N, chunk)
         stage = self.b_stage.view(-1)[: 2 * self.hkv * N * m * D].view(2, self.hkv, N * m, D)
+        stage6 = stage.view(2, self.hkv, 2 * N, m2, D)
         kn, vn, new_stride = stage[0], stage[1], N * m * D
         ss_loc = self.b_ss.view(-1)[: self.hkv * ml].view(self.hkv, ml)
+        rev = torch.arange(N - 1, -1, -1, device=self.device)
         for l, lw in enumerate(self.w.layers):
             x = self.b_x[:ml]
             ops.add_rmsnorm(h, delta, lw.ln1, x, s.rms_eps)
@@ -232,16 +249,22 @@ class QuickPrefillEngine:
             ops.rope_append(qkv, cos, sin, self.hq, self.hkv, D, q, send_k, send_v, m * D, 0, ss_loc)
             send_ss[:, :ml].copy_(ss_loc)
             torch.distributed.all_gather_into_tensor(self.b_xall[: N * chunk], self.b_xsend[:chunk], group=self.sp_group)
-            # [rank][K|V][head][m][D] -> staging [K|V][head][rank*m + t][D]  (rows >= n are the last rank's padding, never read)
-            stage.view(2, self.hkv, N, m, D).copy_(xall[:, : 2 * kv_bytes].view(self.dtype).view(N, 2, self.hkv, m, D).permute(1, 2, 0, 3, 4))
+            # [rank][K|V][head][half][m2][D] -> staging [K|V][head][chunk][m2][D] in token order: chunk r <- rank r's first half,
+            # chunk 2N-1-r <- its second half (rows >= n are padding, never read)
+            X = xall[:, : 2 * kv_bytes].view(self.dtype).view(N, 2, self.hkv, 2, m2, D)
+            stage6[:, :, :N].copy_(X[:, :, :, 0].permute(1, 2, 0, 3, 4))
+            stage6[:, :, N:].copy_(X.index_select(0, rev)[:, :, :, 1].permute(1, 2, 0, 3, 4))
             att = self.b_att[:ml]
             past_attn = past if (cfg.adaptive_local_attention or not prune) else 0
-            ops.prefill_attn(q, self.arena.k(l), self.arena.v(l), self.arena.head_stride, past_attn, kn, vn, new_stride, n, self.hq,
-                             self.hkv, D, scale, att, q_row0=lo, nq=ml)
+            for (q0, lo_, hi_) in ((a0, 0, nA), (b0, nA, ml)):               # the two row chunks of this rank
+                if hi_ > lo_:
+                    ops.prefill_attn(q[lo_:hi_], self.arena.k(l), self.arena.v(l), self.arena.head_stride, past_attn, kn, vn, new_stride,
+                                     n, self.hq, self.hkv, D, scale, att[lo_:hi_], q_row0=q0, nq=hi_ - lo_)
             o = self.b_o[:ml]
             torch.mm(att.view(ml, self.hq * D), lw.w_o.t(), out=o)
             if k_keep is not None:
-                ss_all = xall[:, 2 * kv_bytes:].view(torch.float32).view(N, self.hkv, m).permute(1, 0, 2).reshape(self.hkv, N * m)[:, :n].contiguous()
+                S = xall[:, 2 * kv_bytes:].view(torch.float32).view(N, self.hkv, 2, m2)
+                ss_all = torch.cat([S[:, :, 0].permute(1, 0, 2), S.index_select(0, rev)[:, :, 1].permute(1, 0, 2)], 1).reshape(self.hkv, N * m)[:, :n].contiguous()
                 idx = self.b_idx[:k_keep]
                 ops.prune_staged(ss_all, self.hkv, n, k_keep, kn, vn, new_stride, self.hkv, D, self.arena.k(l), self.arena.v(l),
                                  self.arena.head_stride, past, idx)
