@@ -87,7 +87,9 @@ def gen_q(b):
         el_stage(p, sc, gp)
     p.emit("PIN();")
     for g in range(16):
-        p.emit(f"S6_WAIT({p.wait_for(('k', g))}); PIN(); S6_QK({g % RING}, {g >> 1}, {sn}[{g & 1}]); PIN();")
+        if g % 2 == 0:                        # one counted wait releases two fragments (they were issued 4 and 3 gaps ago)
+            p.emit(f"S6_WAIT({p.wait_for(('k', g + 1))}); PIN();")
+        p.emit(f"S6_QK({g % RING}, {g >> 1}, {sn}[{g & 1}]); PIN();")
         if g + RING < 16:
             kread(g + RING)
         else:
@@ -111,7 +113,9 @@ def gen_p(b):
     kb_w = K_BASE[1 - b]                      # order B: this part opens the NEXT step (tile t+1, parity 1-b): its K DMA goes to K[1-b]
     for g in range(16, 32):
         m = g - 16
-        p.emit(f"S6_WAIT({p.wait_for(('v', m))}); PIN(); S6_PV({m % RING}, {m >> 2}, {m & 3}); PIN();")
+        if m % 2 == 0:
+            p.emit(f"S6_WAIT({p.wait_for(('v', m + 1))}); PIN();")
+        p.emit(f"S6_PV({m % RING}, {m >> 2}, {m & 3}); PIN();")
         if m + RING < 16:
             vread(p, m + RING, "vrd_main")
         if m < 8:
