@@ -83,8 +83,10 @@ int qp_prefill_attn_rows(qp_ctx* ctx, const void* q, const void* k_prefix, const
                          int64_t new_head_stride, int64_t n, int64_t q_row0, int64_t nq, int n_q_heads, int n_kv_heads,
                          int head_dim, float scale, void* out, void* workspace, size_t workspace_bytes, void* stream);
 /* Scratch for the kv-split partial results (work items of a ragged last round are cut along KV and merged by a combine
- * kernel so every CU stays busy; small grids — few heads x few query blocks — are split the same way).  workspace may
- * be NULL: the launch then runs unsplit. */
+ * kernel so every CU stays busy; small grids — few heads x few query blocks — are split the same way).  `n` = number of
+ * query rows of the launch (nq for qp_prefill_attn_rows) and `prefix_len` = keys every query sees before its own block
+ * (prefix_len + q_row0 for a sub-range): the same pair the launch plans with.  workspace may be NULL: the launch then runs
+ * unsplit. */
 size_t qp_attn_workspace_bytes(const qp_ctx* ctx, int64_t n, int64_t prefix_len, int n_q_heads, int n_kv_heads);
 
 /* ---- seam 1: key-norm scoring, k-smallest select, compaction  (utils.py:133-136, 266-342) ---- */
