@@ -31,7 +31,7 @@ from quickvideo_amd import planner  # noqa: E402
 from quickvideo_amd.engine import QuickPrefillEngine, sp_row_ranges  # noqa: E402
 from quickvideo_amd.lvu_config import LVUConfig, effective_k  # noqa: E402
 from quickvideo_amd.spec import PRESETS  # noqa: E402
-from quickvideo_amd.weights import DecoderWeights  # noqa: E402
+from quickvideo_amd.weights import DecoderWeights, pp_layer_split  # noqa: E402
 
 CONFIGS = {
     # name: (model, frames, frame_h, frame_w, group_size, rho, prefix, tail)
@@ -81,11 +81,14 @@ def build_workload(name, device, rank, world, seed=0, parallel="sp"):
     pos, delta = planner.mrope_positions(prefix, (frames // 2, gh, gw), tail, temporal_scale=spec.temporal_scale)
     cfg = LVUConfig(model, top_p=rho, video_group_size=gs, num_frames=frames)
     tp = parallel == "tp" and world > 1
-    weights = DecoderWeights.synthetic(spec, device, seed=seed, tp_rank=rank if tp else 0, tp_size=world if tp else 1)
+    pp = parallel == "pp" and world > 1
+    weights = DecoderWeights.synthetic(spec, device, seed=seed, tp_rank=rank if tp else 0, tp_size=world if tp else 1,
+                                       layer_range=pp_layer_split(spec.n_layers, world, rank) if pp else None)
     kept = sum(effective_k(n, cfg, 0, spec.n_layers) or n for n in plan.tokens)
     cap = kept + plan.tail_len + 64
     eng = QuickPrefillEngine(weights, cfg, capacity=cap, max_group_tokens=max(plan.tokens + [plan.tail_len]), device=device,
-                             sp_rank=0 if tp else rank, sp_size=1 if tp else world)
+                             sp_rank=rank if parallel == "sp" else 0, sp_size=world if parallel == "sp" else 1,
+                             pp_rank=rank if pp else 0, pp_size=world if pp else 1)
     g = torch.Generator(device=device); g.manual_seed(1234)      # same embeddings on every TP rank
     # synthetic ViT output / text embeddings: N(0, 1) scaled like embedding rows (the ViT front end is bench'd separately)
     embeds = (torch.randn(T, spec.hidden, generator=g, device=device, dtype=torch.float32) * 0.5).to(torch.bfloat16)
@@ -100,7 +103,10 @@ def run_step(eng, plan, embeds, pos):
         eng.prefill_group(embeds[start:start + n], pos[:, start:start + n])
         start += n
     logits = eng.prefill_tail(embeds[start:], pos[:, start:])
-    return torch.argmax(logits)          # first generated token id (stays on device; .item() would be the TTFT point)
+    tok = torch.argmax(logits) if logits is not None else torch.zeros((), dtype=torch.int64, device=embeds.device)
+    if eng.pp_size > 1:                  # layer pipeline: the last stage holds the logits; the token returns to every stage
+        torch.distributed.broadcast(tok, src=eng.pp_size - 1, group=eng.pp_group)
+    return tok                           # first generated token id (stays on device; .item() would be the TTFT point)
 
 
 def flops_and_bytes(spec, cfg, plan, tp_size):
@@ -206,9 +212,11 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true")
     ap.add_argument("--no-ttft", action="store_true", help="skip the extra step that times prefill -> first token id on the host")
-    ap.add_argument("--parallel", default="sp", choices=["sp", "tp"],
-                    help="N>1: sp = group-token parallel (replicated weights/KV, one K/V all-gather per layer; default), "
-                         "tp = tensor parallel over heads / MLP columns (two [n,d] all-reduces per layer)")
+    ap.add_argument("--parallel", default="auto", choices=["auto", "sp", "tp", "pp"],
+                    help="N>1: sp = group-token parallel (replicated weights/KV, one K/V all-gather per layer), "
+                         "tp = tensor parallel over heads / MLP columns (two [n,d] all-reduces per layer), "
+                         "pp = layer pipeline (each rank holds L/N layers and their KV; one [n,d] hand-off per group and stage); "
+                         "auto = pp when the video has >= 4*N groups (the pipeline stays full), else sp")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -232,9 +240,14 @@ def main():
             torch.distributed.init_process_group("nccl", device_id=device)    # nccl == RCCL over xGMI on ROCm
         tp_group = torch.distributed.group.WORLD
 
+    if args.parallel == "auto":               # long videos keep a layer pipeline full; short ones split each group's tokens
+        _, frames_, _, _, gs_, _, _, _ = CONFIGS[args.config]
+        args.parallel = "pp" if world > 1 and -(-frames_ // gs_) >= 4 * world else "sp"
     spec, cfg, plan, eng, embeds, pos, T = build_workload(args.config, device, rank, world, parallel=args.parallel)
     if args.parallel == "tp":
         eng.tp_group = tp_group
+    elif args.parallel == "pp":
+        eng.pp_group = tp_group
     else:
         eng.sp_group = tp_group
     tokens = sum(plan.tokens)                 # tokens prefetched in the group loop (the reference's total_prefill span)
@@ -277,6 +290,9 @@ def main():
         tot = timed.totals_ms()
         att_ms, att_n = tot["prefill_attn"]
         att_local = att / world                                  # tp: heads sharded; sp: query rows sharded (zigzag chunks)
+        if world > 1 and args.parallel == "pp":                  # this stage's layers only
+            l0_, l1_ = pp_layer_split(spec.n_layers, world, rank)
+            att_local = att * (l1_ - l0_) / spec.n_layers
         if world > 1 and args.parallel == "sp":
             att_local, Pp = 0.0, 0
             for n in plan.tokens:

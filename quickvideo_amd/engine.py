@@ -56,7 +56,7 @@ class KVArena:
 
 class QuickPrefillEngine:
     def __init__(self, weights: DecoderWeights, cfg: LVUConfig, capacity: int, max_group_tokens: int, device=None, ops=None,
-                 tp_group=None, sp_group=None, sp_rank: int = 0, sp_size: int = 1):
+                 tp_group=None, sp_group=None, sp_rank: int = 0, sp_size: int = 1, pp_group=None, pp_rank: int = 0, pp_size: int = 1):
         self.w, self.spec, self.cfg = weights, weights.spec, cfg
         self.device = torch.device(device if device is not None else weights.embed.device)
         if ops is None:
@@ -71,6 +71,13 @@ class QuickPrefillEngine:
         # (+ key sums) once per layer — ~14x fewer bytes on xGMI than the two [n, d] all-reduces of tensor parallelism.
         self.sp_group, self.sp_rank, self.sp_size = sp_group, sp_rank, sp_size
         assert not (self.sp_size > 1 and self.tp_size > 1), "choose tensor parallel OR group-token parallel"
+        # layer-pipeline parallelism ("pp"): rank r holds a contiguous slice of the layers (weights AND their KV), receives a group's
+        # hidden rows from rank r-1, runs its layers and hands the rows to rank r+1.  No collective: one [n, d] point-to-point
+        # hand-off per group and stage.  Groups flow through the stages back to back, so a video of G groups keeps
+        # G / (G + N - 1) of the machine busy — the mode for long videos (cfg4: G = 450); short ones (cfg2: G = 4) use "sp".
+        self.pp_group, self.pp_rank, self.pp_size = pp_group, pp_rank, pp_size
+        assert not (self.pp_size > 1 and (self.sp_size > 1 or self.tp_size > 1)), "layer pipeline is not combined with tp/sp"
+        self.l0, self.n_layers_total = weights.layer0, weights.n_layers_total
         s = self.spec
         self.hq, self.hkv, self.li = weights.local_q_heads, weights.local_kv_heads, weights.local_inter
         self.D = s.head_dim
@@ -127,8 +134,10 @@ class QuickPrefillEngine:
         assert n <= self.n_max, f"group of {n} tokens exceeds max_group_tokens={self.n_max}"
         if self.sp_size > 1 and n >= 64 * self.sp_size:
             return self._forward_segment_sp(embeds, pos, prune)
-        L = len(self.w.layers)
+        L = self.n_layers_total                      # effective_k's decay uses the GLOBAL layer index / count
         cos, sin = ops.mrope_table(pos.contiguous(), s.mrope_section, s.rope_theta, D)
+        if self.pp_size > 1 and prune and cfg.enable and isinstance(cfg.prefill_prune_starting_layer, int) and cfg.prefill_prune_starting_layer >= 0:
+            raise NotImplementedError("hidden-state pruning (prefill_prune_starting_layer) is not combined with the layer pipeline")
         hbufs, hsel = (self.b_h, self.b_h2), 0
         h = hbufs[0][:n]
         h.copy_(embeds)
@@ -140,7 +149,7 @@ class QuickPrefillEngine:
             ops.add_rmsnorm(h, delta, lw.ln1, x, s.rms_eps)                  # h += delta; x = RMSNorm(h)   (qwen25_lvu.py:167-169)
             qkv = self.b_qkv[:n]
             torch.addmm(lw.b_qkv, x, lw.w_qkv.t(), out=qkv)                  # q/k/v proj + bias             (:42-44)
-            k_keep = effective_k(n, cfg, l, L) if prune else None            # utils.py:231-255
+            k_keep = effective_k(n, cfg, self.l0 + l, L) if prune else None  # utils.py:231-255
             past = self.arena.len[l]
             assert past + (k_keep if k_keep is not None else n) <= self.arena.capacity, "KV arena overflow"
             q = self.b_q[:n]
@@ -218,7 +227,7 @@ class QuickPrefillEngine:
         m = 2 * m2                                   # rows per rank slot in the exchange buffers
         nA, nB = a1 - a0, b1 - b0
         ml = nA + nB                                 # local rows: [chunk r | chunk 2N-1-r]; nA == m2 whenever nB > 0
-        L = len(self.w.layers)
+        L = self.n_layers_total                      # effective_k's decay uses the GLOBAL layer index / count
         rows = torch.cat([torch.arange(a0, a1, device=self.device), torch.arange(b0, b1, device=self.device)])
         cos, sin = ops.mrope_table(pos.index_select(1, rows).contiguous(), s.mrope_section, s.rope_theta, D)
         h = self.b_h[:ml]
@@ -242,7 +251,7 @@ class QuickPrefillEngine:
             ops.add_rmsnorm(h, delta, lw.ln1, x, s.rms_eps)
             qkv = self.b_qkv[:ml]
             torch.addmm(lw.b_qkv, x, lw.w_qkv.t(), out=qkv)
-            k_keep = effective_k(n, cfg, l, L) if prune else None
+            k_keep = effective_k(n, cfg, self.l0 + l, L) if prune else None
             past = self.arena.len[l]
             assert past + (k_keep if k_keep is not None else n) <= self.arena.capacity, "KV arena overflow"
             q = self.b_q[:ml]
@@ -290,18 +299,50 @@ class QuickPrefillEngine:
         return h
 
     # ------------------------------------------------------------------ public steps of the group loop
+    # layer-pipeline hand-off: stage r > 0 receives the segment's hidden rows from stage r-1, the last stage keeps its output
+    def _pp_peer(self, r: int) -> int:
+        return torch.distributed.get_global_rank(self.pp_group, r) if self.pp_group is not None else r
+
+    def _pp_host_staged(self, t: torch.Tensor) -> bool:
+        # gloo moves device tensors without ordering against the compute stream: stage through the host (developer runs of
+        # several ranks on one GPU; RCCL point-to-point is stream-ordered and takes the device buffer directly)
+        return t.is_cuda and torch.distributed.get_backend(self.pp_group) == "gloo"
+
+    def _pp_in(self, embeds: torch.Tensor) -> torch.Tensor:
+        if self.pp_size == 1 or self.pp_rank == 0:
+            return embeds
+        buf = self.b_h2[: embeds.shape[0]]
+        if self._pp_host_staged(buf):
+            host = torch.empty(buf.shape, dtype=buf.dtype)
+            torch.distributed.recv(host, src=self._pp_peer(self.pp_rank - 1), group=self.pp_group)
+            buf.copy_(host)
+        else:
+            torch.distributed.recv(buf, src=self._pp_peer(self.pp_rank - 1), group=self.pp_group)
+        return buf
+
+    def _pp_out(self, h: torch.Tensor):
+        if self.pp_size > 1 and self.pp_rank < self.pp_size - 1:
+            torch.distributed.send(h.cpu() if self._pp_host_staged(h) else h, dst=self._pp_peer(self.pp_rank + 1), group=self.pp_group)
+
+    @property
+    def is_last_stage(self) -> bool:
+        return self.pp_rank == self.pp_size - 1
+
     def prefill_group(self, embeds: torch.Tensor, pos: torch.Tensor):
         """One video group (qwen25_lvu.py:671-717): KV appended + pruned; hidden output is discarded like the
-        reference discards the group's logits (:697-699)."""
-        self.forward_segment(embeds, pos, prune=True)
+        reference discards the group's logits (:697-699).  (Layer pipeline: `embeds` only matters on stage 0.)"""
+        h = self.forward_segment(self._pp_in(embeds), pos, prune=True)
+        self._pp_out(h)
         self.seq_pos += embeds.shape[0]
 
-    def prefill_tail(self, embeds: torch.Tensor, pos: torch.Tensor) -> torch.Tensor:
+    def prefill_tail(self, embeds: torch.Tensor, pos: torch.Tensor) -> Optional[torch.Tensor]:
         """Prompt tail over the pruned cache, no pruning (qwen25_lvu.py:724-742, enable = do_top_k_for_query).
-        Returns fp32 logits [V] of the last position = distribution of the first generated token (TTFT point)."""
-        h = self.forward_segment(embeds, pos, prune=bool(self.cfg.do_top_k_for_query))
+        Returns fp32 logits [V] of the last position = distribution of the first generated token (TTFT point); None on
+        layer-pipeline stages other than the last."""
+        h = self.forward_segment(self._pp_in(embeds), pos, prune=bool(self.cfg.do_top_k_for_query))
+        self._pp_out(h)
         self.seq_pos += embeds.shape[0]
-        return self.logits_last(h)
+        return self.logits_last(h) if self.is_last_stage else None
 
     def logits_last(self, h: torch.Tensor) -> torch.Tensor:
         x = torch.empty(1, self.spec.hidden, dtype=self.dtype, device=self.device)
@@ -313,9 +354,10 @@ class QuickPrefillEngine:
         (HF generate with the caller-supplied cache_position, qwen25_lvu.py:445-464, 740)."""
         p = self.seq_pos + rope_delta
         pos = torch.full((3, 1), p, dtype=torch.int64, device=self.device)
-        h = self.forward_segment(token_embed.view(1, -1), pos, prune=bool(self.cfg.do_top_k_for_query))
+        h = self.forward_segment(self._pp_in(token_embed.view(1, -1)), pos, prune=bool(self.cfg.do_top_k_for_query))
+        self._pp_out(h)
         self.seq_pos += 1
-        return self.logits_last(h)
+        return self.logits_last(h) if self.is_last_stage else None
 
     def embed_tokens(self, ids: torch.Tensor) -> torch.Tensor:
         return self.w.embed.index_select(0, ids.to(self.device))

@@ -6,11 +6,18 @@ qkv / o_proj and its column slice of gate_up / down (quickvideo_amd/tp.py)."""
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Dict, List, Optional
+from typing import Dict, List, Optional, Tuple
 
 import torch
 
 from .spec import TextSpec
+
+
+def pp_layer_split(n_layers: int, world: int, rank: int) -> Tuple[int, int]:
+    """Layer-pipeline stage `rank` of `world`: contiguous layers [l0, l1); the first n_layers % world stages take one more."""
+    base, extra = divmod(n_layers, world)
+    l0 = rank * base + min(rank, extra)
+    return l0, l0 + base + (1 if rank < extra else 0)
 
 
 def tp_head_partition(hq: int, hkv: int, tp_rank: int, tp_size: int):
@@ -52,6 +59,12 @@ class DecoderWeights:
     lm_head: torch.Tensor    # [V, d]
     tp_rank: int = 0
     tp_size: int = 1
+    layer0: int = 0          # global index of layers[0] (layer-pipeline stages hold a contiguous slice)
+    n_layers_total: int = -1 # layers of the whole model (-1: len(layers))
+
+    def __post_init__(self):
+        if self.n_layers_total < 0:
+            self.n_layers_total = len(self.layers)
 
     @property
     def local_q_heads(self) -> int:
@@ -67,8 +80,9 @@ class DecoderWeights:
 
     @staticmethod
     def from_named(spec: TextSpec, sd: Dict[str, torch.Tensor], device, dtype=torch.bfloat16, tp_rank: int = 0,
-                   tp_size: int = 1) -> "DecoderWeights":
-        """Build from HF-style names ("layers.{i}.q_proj.weight" or "layers.{i}.self_attn.q_proj.weight", ...)."""
+                   tp_size: int = 1, layer_range: Optional[Tuple[int, int]] = None) -> "DecoderWeights":
+        """Build from HF-style names ("layers.{i}.q_proj.weight" or "layers.{i}.self_attn.q_proj.weight", ...).
+        layer_range = (l0, l1): only layers [l0, l1) (a layer-pipeline stage)."""
         def g(*names):
             for nm in names:
                 if nm in sd:
@@ -89,7 +103,8 @@ class DecoderWeights:
             return torch.cat(parts, 1)
         to = lambda t: t.to(device=device, dtype=dtype).contiguous()
         layers = []
-        for l in range(spec.n_layers):
+        l0, l1 = layer_range if layer_range is not None else (0, spec.n_layers)
+        for l in range(l0, l1):
             p = f"layers.{l}."
             a = lambda s: (p + s, p + "self_attn." + s)
             qw, kw, vw = g(*a("q_proj.weight")), g(*a("k_proj.weight")), g(*a("v_proj.weight"))
@@ -104,13 +119,14 @@ class DecoderWeights:
                 w_gate_up=to(torch.cat([gw[i_lo:i_lo + li], uw[i_lo:i_lo + li]], 0)), w_down=to(dw[:, i_lo:i_lo + li])))
         embed = to(g("embed_tokens.weight"))
         lm = embed if spec.tie_embeddings and "lm_head.weight" not in sd else to(g("lm_head.weight"))
-        return DecoderWeights(spec, embed, layers, to(g("norm.weight")), lm, tp_rank, tp_size)
+        return DecoderWeights(spec, embed, layers, to(g("norm.weight")), lm, tp_rank, tp_size, l0, spec.n_layers)
 
     @staticmethod
     def synthetic(spec: TextSpec, device, seed: int = 0, dtype=torch.bfloat16, std: float = 0.02, tp_rank: int = 0,
-                  tp_size: int = 1, n_layers: Optional[int] = None) -> "DecoderWeights":
+                  tp_size: int = 1, n_layers: Optional[int] = None, layer_range: Optional[Tuple[int, int]] = None) -> "DecoderWeights":
         """Seeded random weights at the real dims, generated on the device (no checkpoint offline).
-        Under TP every rank draws only its own shard (seeded by (seed, layer, rank))."""
+        Under TP every rank draws only its own shard (seeded by (seed, layer, rank)); a layer-pipeline stage draws only the
+        layers of layer_range = (l0, l1) (each layer has its own seed, so stages agree with the single-process model)."""
         D, hq, hkv, I, d = spec.head_dim, spec.n_heads, spec.n_kv_heads, spec.intermediate, spec.hidden
         assert I % tp_size == 0
         q_idx, _, lkv = tp_head_partition(hq, hkv, tp_rank, tp_size)
@@ -126,9 +142,11 @@ class DecoderWeights:
         lm_head = embed if spec.tie_embeddings else mat(spec.vocab, d)
         norm = torch.ones(d, device=device, dtype=dtype)
         layers = []
-        for l in range(spec.n_layers if n_layers is None else n_layers):
+        total = spec.n_layers if n_layers is None else n_layers
+        l0, l1 = layer_range if layer_range is not None else (0, total)
+        for l in range(l0, l1):
             gen.manual_seed(seed * 1_000_003 + l * 1009 + tp_rank + 1)
             layers.append(LayerWeights(
                 ln1=torch.ones(d, device=device, dtype=dtype), w_qkv=mat((lq + 2 * lkv) * D, d), b_qkv=mat((lq + 2 * lkv) * D),
                 w_o=mat(d, lq * D), ln2=torch.ones(d, device=device, dtype=dtype), w_gate_up=mat(2 * li, d), w_down=mat(d, li)))
-        return DecoderWeights(spec, embed, layers, norm, lm_head, tp_rank, tp_size)
+        return DecoderWeights(spec, embed, layers, norm, lm_head, tp_rank, tp_size, l0, total)

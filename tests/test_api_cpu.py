@@ -280,3 +280,79 @@ def test_group_token_parallel_gloo(world):
     assert same / tot >= 0.95
     assert np.max(np.abs(ret["logits0"] - ret["ref_logits"])) <= 4e-2
     assert np.max(np.abs(ret["k0_0"] - ret["ref_k0"])) <= 0.25                   # layer-0 keys: per-row GEMM rounding only
+
+
+# ---------------------------------------------------------------- layer pipeline over gloo (world_size 2 and 3)
+def _pp_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from quickvideo_amd.engine import QuickPrefillEngine
+    from quickvideo_amd.lvu_config import LVUConfig
+    from quickvideo_amd.spec import TextSpec
+    from quickvideo_amd.weights import DecoderWeights, pp_layer_split
+    L = 4
+    so = O.TextSpec(hidden=256, n_heads=4, n_kv_heads=2, head_dim=128, intermediate=256, n_layers=L, vocab=128)
+    spec = TextSpec(hidden=256, n_heads=4, n_kv_heads=2, head_dim=128, intermediate=256, n_layers=L, vocab=128)
+    w = {k: v.to(torch.bfloat16) for k, v in O.synthetic_text_weights(so, seed=7, norm_jitter=0.1).items()}
+    rs = np.random.RandomState(3)
+    groups = [37, 50, 41]
+    T = sum(groups) + 7
+    embeds = torch.from_numpy(rs.standard_normal((T, 256)).astype(np.float32) * 0.5).to(torch.bfloat16)
+    pos = torch.from_numpy(np.tile(np.arange(T, dtype=np.int64), (3, 1)))
+    cfg = LVUConfig("x", top_p=0.5, video_group_size=4, top_k_decay_type="linear", top_k_decay_factor=0.5)   # decay: global layer index matters
+
+    def run(eng):
+        eng.kept_trace = []
+        st = 0
+        for n in groups:
+            eng.prefill_group(embeds[st:st + n], pos[:, st:st + n]); st += n
+        logits = eng.prefill_tail(embeds[st:], pos[:, st:])
+        tok_in = torch.from_numpy(rs.standard_normal((1, 256)).astype(np.float32)).to(torch.bfloat16)
+        logits2 = eng.decode_step(tok_in, rope_delta=0)
+        return logits, logits2
+
+    l0, l1 = pp_layer_split(L, world, rank)
+    stage = QuickPrefillEngine(DecoderWeights.from_named(spec, w, "cpu", layer_range=(l0, l1)), cfg, capacity=T + 8, max_group_tokens=max(groups),
+                               device="cpu", ops=OracleOps(), pp_group=dist.group.WORLD, pp_rank=rank, pp_size=world)
+    logits, logits2 = run(stage)
+    ret[f"len{rank}"] = list(stage.arena.len)
+    ret[f"kept{rank}"] = [(l, None if k is None else k.numpy().copy()) for l, k in stage.kept_trace]
+    if rank == world - 1:
+        ret["logits"], ret["logits2"] = logits.numpy(), logits2.numpy()
+    else:
+        assert logits is None and logits2 is None
+    if rank == 0:                                             # the same model in one process
+        rs = np.random.RandomState(3); rs.standard_normal((T, 256))    # replay the decode embedding draw
+        full = QuickPrefillEngine(DecoderWeights.from_named(spec, w, "cpu"), cfg, capacity=T + 8, max_group_tokens=max(groups), device="cpu",
+                                  ops=OracleOps())
+        a, b = run(full)
+        ret["ref_logits"], ret["ref_logits2"], ret["ref_len"] = a.numpy(), b.numpy(), list(full.arena.len)
+        ret["ref_kept"] = [(l, None if k is None else k.numpy().copy()) for l, k in full.kept_trace]
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_layer_pipeline_gloo(world):
+    """Layer-pipeline stages reproduce the single-process engine exactly (same ops in the same order; the hand-off is a copy)."""
+    port = 35500 + os.getpid() % 2000 + world
+    ret = mp.Manager().dict()
+    mp.spawn(_pp_worker, args=(world, port, ret), nprocs=world, join=True)
+    from quickvideo_amd.weights import pp_layer_split
+    assert np.array_equal(ret["logits"], ret["ref_logits"]) and np.array_equal(ret["logits2"], ret["ref_logits2"])
+    lens = []
+    for r in range(world):
+        lens += ret[f"len{r}"]
+    assert lens == ret["ref_len"]
+    # kept indices per (segment, layer): stage r's local layer l is global layer l0 + l
+    ref = ret["ref_kept"]
+    L = 4
+    n_seg = len(ref) // L
+    for r in range(world):
+        l0, l1 = pp_layer_split(L, world, r)
+        mine = ret[f"kept{r}"]
+        assert len(mine) == n_seg * (l1 - l0)
+        for s in range(n_seg):
+            for l in range(l1 - l0):
+                a, b = mine[s * (l1 - l0) + l][1], ref[s * L + l0 + l][1]
+                assert (a is None) == (b is None) and (a is None or np.array_equal(a, b))
