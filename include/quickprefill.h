@@ -132,6 +132,14 @@ int qp_prune_tail(qp_ctx* ctx, void* k_cache, void* v_cache, int64_t head_stride
 int qp_gather_rows(qp_ctx* ctx, const void* src, const int32_t* idx, int64_t k, int64_t row_bytes, void* dst,
                    void* stream);
 
+/* Group-token parallel exchange, receive side (no reference counterpart: the reference is single-GPU; this is the multi-GPU
+ * form of cache.update, qwen25_lvu.py:56-58).  `gathered` = the all-gather of every rank's send block, [world][chunk]:
+ * chunk = K bf16 [n_kv][2*m2][head_dim] | V same | key sums fp32 [n_kv][2*m2]; rank r's rows are the two zigzag chunks
+ * r and 2*world-1-r of the group's n tokens (m2 = ceil(n / (2*world)) rows each).  Writes K/V rows in TOKEN order to
+ * k_stage/v_stage[h*stage_head_stride + t*head_dim ...] and the sums to sumsq_out[h*n + t], t < n. */
+int qp_sp_unpack(qp_ctx* ctx, const void* gathered, int world, int n_kv_heads, int64_t m2, int head_dim, int64_t n,
+                 void* k_stage, void* v_stage, int64_t stage_head_stride, float* sumsq_out, void* stream);
+
 /* ---- glue of the patched decoder layer (qwen25_lvu.py:166-198) [transformers Qwen2RMSNorm/MLP] -- */
 /* if delta != NULL: h = bf16(h + delta) (written back);  out = w * bf16(h * rsqrt(mean(h^2) + eps)). */
 int qp_add_rmsnorm(qp_ctx* ctx, void* h, const void* delta, const void* w, void* out, int64_t n, int hidden,

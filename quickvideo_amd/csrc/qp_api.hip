@@ -215,6 +215,19 @@ int qp_prune_tail(qp_ctx* ctx, void* k_cache, void* v_cache, int64_t head_stride
   return qp_launch_copy_rows_kv(kt, vt, k * head_dim, k, n_kv_heads, k_cache, v_cache, head_stride, past_len, s);
 }
 
+int qp_sp_unpack(qp_ctx* ctx, const void* gathered, int world, int n_kv_heads, int64_t m2, int head_dim, int64_t n, void* k_stage,
+                 void* v_stage, int64_t stage_head_stride, float* sumsq_out, void* stream) {
+  QP_REQUIRE(ctx && gathered && k_stage && v_stage && sumsq_out, QP_ERR_INVALID, "qp_sp_unpack: NULL argument");
+  QP_REQUIRE(head_dim == 128, QP_ERR_UNSUPPORTED, "qp_sp_unpack: head_dim=%d (only 128)", head_dim);
+  QP_REQUIRE(world >= 1 && n_kv_heads >= 1 && m2 >= 1 && n >= 0 && n <= 2 * (int64_t)world * m2, QP_ERR_INVALID,
+             "qp_sp_unpack: n=%lld does not fit 2*world*m2=%lld rows", (long long)n, (long long)(2 * (int64_t)world * m2));
+  QP_REQUIRE(stage_head_stride >= n * head_dim && stage_head_stride % 8 == 0, QP_ERR_INVALID, "qp_sp_unpack: stage_head_stride");
+  QP_REQUIRE(aligned16(gathered) && aligned16(k_stage) && aligned16(v_stage), QP_ERR_INVALID, "qp_sp_unpack: alignment");
+  QP_REQUIRE(((int64_t)n_kv_heads * 2 * m2 * 4) % 16 == 0, QP_ERR_INVALID, "qp_sp_unpack: per-rank block must be a multiple of 16 B");
+  if (n == 0) return QP_OK;
+  return qp_launch_sp_unpack(gathered, world, n_kv_heads, m2, n, k_stage, v_stage, stage_head_stride, sumsq_out, (hipStream_t)stream);
+}
+
 int qp_gather_rows(qp_ctx* ctx, const void* src, const int32_t* idx, int64_t k, int64_t row_bytes, void* dst, void* stream) {
   QP_REQUIRE(ctx && src && idx && dst, QP_ERR_INVALID, "qp_gather_rows: NULL argument");
   QP_REQUIRE(k >= 0 && row_bytes > 0 && row_bytes % 16 == 0, QP_ERR_INVALID, "qp_gather_rows: row_bytes=%lld must be a multiple of 16",

@@ -48,6 +48,8 @@ int qp_launch_select(const float* head_sumsq, int n_heads, int64_t n, int64_t k,
 int qp_launch_gather_kv(const void* k_src, const void* v_src, int64_t src_head_stride, const int32_t* idx, int64_t k,
                         int hkv, void* k_dst, void* v_dst, int64_t dst_head_stride, int64_t dst_row0, hipStream_t s);
 int qp_launch_gather_rows(const void* src, const int32_t* idx, int64_t k, int64_t row_bytes, void* dst, hipStream_t s);
+int qp_launch_sp_unpack(const void* gathered, int world, int hkv, int64_t m2, int64_t n, void* k_stage, void* v_stage,
+                        int64_t stage_head_stride, float* sumsq_out, hipStream_t s);
 int qp_launch_copy_rows_kv(const void* k_src, const void* v_src, int64_t src_head_stride, int64_t k, int hkv, void* k_dst,
                            void* v_dst, int64_t dst_head_stride, int64_t dst_row0, hipStream_t s);
 int qp_launch_add_rmsnorm(void* h, const void* delta, const void* w, void* out, int64_t n, int hidden, float eps,

@@ -360,3 +360,44 @@ int qp_launch_gather_rows(const void* src, const int32_t* idx, int64_t k, int64_
   gather_rows_kernel<<<(int)blocks, 256, 0, s>>>((const uint4*)src, idx, k, row_bytes / 16, (uint4*)dst);
   return qp_check_launch("gather_rows");
 }
+
+// ------------------------------------------------------------------------------------------------
+// Group-token parallel receive side: all-gathered [rank][K | V | sums] blocks -> staging block in token order.
+// One thread per 16 B of a K/V row (256-B rows: 16 threads per row); the last grid rows carry the key sums.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sp_unpack_kernel(const unsigned char* __restrict__ g, int world, int hkv, int m2, int64_t n,
+                                                        uint4* __restrict__ ks, uint4* __restrict__ vs, int64_t stage_hs16,
+                                                        float* __restrict__ ss) {
+  const int64_t m = 2 * (int64_t)m2;
+  const int64_t kv_bytes = (int64_t)hkv * m * 256, chunk = 2 * kv_bytes + (int64_t)hkv * m * 4;
+  const int64_t row = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);          // (kv, head, token)
+  const int slot = threadIdx.x & 15;
+  const int64_t rows_total = 2 * (int64_t)hkv * n;
+  if (row < rows_total) {
+    const int kv = (int)(row / (hkv * n));
+    const int64_t rem = row - (int64_t)kv * hkv * n;
+    const int h = (int)(rem / n);
+    const int64_t t = rem - (int64_t)h * n;
+    const int c = (int)(t / m2);                                              // zigzag chunk of the token
+    const int r = c < world ? c : 2 * world - 1 - c, half = c < world ? 0 : 1;
+    const int64_t srow = (int64_t)h * m + half * m2 + (t - (int64_t)c * m2);
+    const uint4 v = *reinterpret_cast<const uint4*>(g + r * chunk + kv * kv_bytes + srow * 256 + slot * 16);
+    (kv ? vs : ks)[(int64_t)h * stage_hs16 + t * 16 + slot] = v;
+  }
+  // key sums: threads of the whole grid stride over [hkv][n]
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (int64_t)hkv * n; i += (int64_t)gridDim.x * 256) {
+    const int h = (int)(i / n);
+    const int64_t t = i - (int64_t)h * n;
+    const int c = (int)(t / m2);
+    const int r = c < world ? c : 2 * world - 1 - c, half = c < world ? 0 : 1;
+    ss[i] = *reinterpret_cast<const float*>(g + r * chunk + 2 * kv_bytes + ((int64_t)h * m + half * m2 + (t - (int64_t)c * m2)) * 4);
+  }
+}
+
+int qp_launch_sp_unpack(const void* gathered, int world, int hkv, int64_t m2, int64_t n, void* k_stage, void* v_stage,
+                        int64_t stage_head_stride, float* sumsq_out, hipStream_t s) {
+  const int64_t rows = 2 * (int64_t)hkv * n;
+  sp_unpack_kernel<<<(unsigned)((rows + 15) / 16), 256, 0, s>>>((const unsigned char*)gathered, world, hkv, (int)m2, n, (uint4*)k_stage,
+                                                              (uint4*)v_stage, stage_head_stride / 8, sumsq_out);
+  return qp_check_launch("sp_unpack");
+}

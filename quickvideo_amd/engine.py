@@ -240,12 +240,9 @@ class QuickPrefillEngine:
         send_v = self.b_xsend[kv_bytes:2 * kv_bytes].view(self.dtype).view(self.hkv, m, D)
         send_ss = self.b_xsend[2 * kv_bytes:2 * kv_bytes + self.hkv * m * 4].view(torch.float32).view(self.hkv, m)
         chunk = 2 * kv_bytes + self.hkv * m * 4
-        xall = self.b_xall[: N * chunk].view(N, chunk)
         stage = self.b_stage.view(-1)[: 2 * self.hkv * N * m * D].view(2, self.hkv, N * m, D)
-        stage6 = stage.view(2, self.hkv, 2 * N, m2, D)
         kn, vn, new_stride = stage[0], stage[1], N * m * D
         ss_loc = self.b_ss.view(-1)[: self.hkv * ml].view(self.hkv, ml)
-        rev = torch.arange(N - 1, -1, -1, device=self.device)
         for l, lw in enumerate(self.w.layers):
             x = self.b_x[:ml]
             ops.add_rmsnorm(h, delta, lw.ln1, x, s.rms_eps)
@@ -255,14 +252,15 @@ class QuickPrefillEngine:
             past = self.arena.len[l]
             assert past + (k_keep if k_keep is not None else n) <= self.arena.capacity, "KV arena overflow"
             q = self.b_q[:ml]
-            ops.rope_append(qkv, cos, sin, self.hq, self.hkv, D, q, send_k, send_v, m * D, 0, ss_loc)
-            send_ss[:, :ml].copy_(ss_loc)
+            if ml == m:                                                      # sums straight into the send block
+                ops.rope_append(qkv, cos, sin, self.hq, self.hkv, D, q, send_k, send_v, m * D, 0, send_ss)
+            else:
+                ops.rope_append(qkv, cos, sin, self.hq, self.hkv, D, q, send_k, send_v, m * D, 0, ss_loc)
+                send_ss[:, :ml].copy_(ss_loc)
             torch.distributed.all_gather_into_tensor(self.b_xall[: N * chunk], self.b_xsend[:chunk], group=self.sp_group)
-            # [rank][K|V][head][half][m2][D] -> staging [K|V][head][chunk][m2][D] in token order: chunk r <- rank r's first half,
-            # chunk 2N-1-r <- its second half (rows >= n are padding, never read)
-            X = xall[:, : 2 * kv_bytes].view(self.dtype).view(N, 2, self.hkv, 2, m2, D)
-            stage6[:, :, :N].copy_(X[:, :, :, 0].permute(1, 2, 0, 3, 4))
-            stage6[:, :, N:].copy_(X.index_select(0, rev)[:, :, :, 1].permute(1, 2, 0, 3, 4))
+            # [rank][K | V | sums] with each rank's two zigzag chunks -> staging block + key sums in token order (one launch)
+            ss_all = self.b_ss.view(-1)[: self.hkv * n].view(self.hkv, n)
+            ops.sp_unpack(self.b_xall, N, self.hkv, m2, D, n, kn, vn, new_stride, ss_all)
             att = self.b_att[:ml]
             past_attn = past if (cfg.adaptive_local_attention or not prune) else 0
             for (q0, lo_, hi_) in ((a0, 0, nA), (b0, nA, ml)):               # the two row chunks of this rank
@@ -272,8 +270,6 @@ class QuickPrefillEngine:
             o = self.b_o[:ml]
             torch.mm(att.view(ml, self.hq * D), lw.w_o.t(), out=o)
             if k_keep is not None:
-                S = xall[:, 2 * kv_bytes:].view(torch.float32).view(N, self.hkv, 2, m2)
-                ss_all = torch.cat([S[:, :, 0].permute(1, 0, 2), S.index_select(0, rev)[:, :, 1].permute(1, 0, 2)], 1).reshape(self.hkv, N * m)[:, :n].contiguous()
                 idx = self.b_idx[:k_keep]
                 ops.prune_staged(ss_all, self.hkv, n, k_keep, kn, vn, new_stride, self.hkv, D, self.arena.k(l), self.arena.v(l),
                                  self.arena.head_stride, past, idx)

@@ -51,6 +51,7 @@ SIGNATURES = {
     "qp_prune_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32]),
     "qp_prune_tail": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _vp, _vp, _sz, _vp]),
     "qp_gather_rows": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _vp]),
+    "qp_sp_unpack": (_i32, [_vp, _vp, _i32, _i32, _i64, _i32, _i64, _vp, _vp, _i64, _vp, _vp]),
     "qp_add_rmsnorm": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
     "qp_add_inplace": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "qp_swiglu": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp]),
@@ -177,6 +178,10 @@ class QuickPrefillOps:
         self._check(self.lib.qp_prune_tail(self.ctx, k_cache.data_ptr(), v_cache.data_ptr(), head_stride, past_len, n, k, n_kv,
                                            head_dim, kept_idx.data_ptr(), workspace.data_ptr(), workspace.numel() * workspace.element_size(),
                                            self._stream()))
+
+    def sp_unpack(self, gathered, world, n_kv, m2, head_dim, n, k_stage, v_stage, stage_head_stride, sumsq_out):
+        self._check(self.lib.qp_sp_unpack(self.ctx, gathered.data_ptr(), world, n_kv, m2, head_dim, n, k_stage.data_ptr(), v_stage.data_ptr(),
+                                          stage_head_stride, sumsq_out.data_ptr(), self._stream()))
 
     def gather_rows(self, src, idx, k, row_bytes, dst):
         self._check(self.lib.qp_gather_rows(self.ctx, src.data_ptr(), idx.data_ptr(), k, row_bytes, dst.data_ptr(), self._stream()))

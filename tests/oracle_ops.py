@@ -75,6 +75,21 @@ class OracleOps:
         self.select_k_smallest(head_sumsq, n_heads_total, n, k, kept_idx)
         self.gather_kv(k_src, v_src, src_head_stride, kept_idx, k, n_kv, D, k_dst, v_dst, dst_head_stride, dst_row0)
 
+    def sp_unpack(self, gathered, world, n_kv, m2, head_dim, n, k_stage, v_stage, stage_head_stride, sumsq_out):
+        m = 2 * m2
+        kv_bytes = n_kv * m * head_dim * 2
+        chunk = 2 * kv_bytes + n_kv * m * 4
+        g = gathered.view(torch.uint8)[: world * chunk].view(world, chunk)
+        X = g[:, : 2 * kv_bytes].view(k_stage.dtype).view(world, 2, n_kv, 2, m2, head_dim)
+        S = g[:, 2 * kv_bytes:].view(torch.float32).view(world, n_kv, 2, m2)
+        rev = torch.arange(world - 1, -1, -1)
+        full = torch.cat([X[:, :, :, 0].permute(1, 2, 0, 3, 4), X[rev][:, :, :, 1].permute(1, 2, 0, 3, 4)], 2).reshape(2, n_kv, 2 * world * m2, head_dim)
+        ks = k_stage.view(-1)[: n_kv * stage_head_stride].view(n_kv, stage_head_stride // head_dim, head_dim)
+        vs = v_stage.view(-1)[: n_kv * stage_head_stride].view(n_kv, stage_head_stride // head_dim, head_dim)
+        ks[:, :n].copy_(full[0, :, :n]); vs[:, :n].copy_(full[1, :, :n])
+        ss = torch.cat([S[:, :, 0].permute(1, 0, 2), S[rev][:, :, 1].permute(1, 0, 2)], 1).reshape(n_kv, 2 * world * m2)[:, :n]
+        sumsq_out.view(-1)[: n_kv * n].view(n_kv, n).copy_(ss)
+
     def gather_rows(self, src, idx, k, row_bytes, dst):
         dst[:k].copy_(src[idx[:k].long()])
 

@@ -470,3 +470,28 @@ def test_prefill_attn_forms_agree_at_full_size(ops, monkeypatch):
     for a, b in (("4", "7"), ("4", "8")):
         d = (outs[a] - outs[b]).abs()
         assert d.max().item() <= 4e-3 and d.mean().item() < 1e-4, (a, b, d.max().item(), d.mean().item())   # ~1 bf16 ulp of the outputs
+
+
+@pytest.mark.parametrize("world,hkv,n", [(2, 4, 5760), (8, 4, 5775), (3, 2, 200), (8, 1, 1024)])
+def test_sp_unpack_matches_host_permutation(ops, world, hkv, n):
+    """Receive side of the group-token parallel exchange: all-gathered per-rank blocks -> staging rows and key sums in token
+    order (a pure permutation: bit-exact against the torch formulation the CPU double uses)."""
+    from oracle_ops import OracleOps
+    m2 = -(-n // (2 * world)); m = 2 * m2
+    kv_bytes = hkv * m * D * 2
+    chunk = 2 * kv_bytes + hkv * m * 4
+    g = torch.Generator(device="cuda"); g.manual_seed(world * 1000 + n)
+    gathered = torch.randint(0, 255, (world * chunk,), generator=g, device="cuda", dtype=torch.uint8)
+    stride = (2 * world * m2) * D
+    out = {}
+    for name, o in (("hip", ops), ("ref", OracleOps())):
+        ks = torch.zeros(hkv, 2 * world * m2, D, dtype=torch.bfloat16, device="cuda"); vs = torch.zeros_like(ks)
+        ss = torch.zeros(hkv, n, dtype=torch.float32, device="cuda")
+        gg = gathered if name == "hip" else gathered.cpu()
+        if name == "ref":
+            ks, vs, ss = ks.cpu(), vs.cpu(), ss.cpu()
+        o.sp_unpack(gg, world, hkv, m2, D, n, ks, vs, stride, ss)
+        out[name] = (ks.cpu().view(torch.int16)[:, :n], vs.cpu().view(torch.int16)[:, :n], ss.cpu().view(torch.int32))
+    torch.cuda.synchronize()
+    for a, b in zip(out["hip"], out["ref"]):
+        assert torch.equal(a, b)
