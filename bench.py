@@ -71,7 +71,24 @@ class TimedOps:
         return {n: (sum(s.elapsed_time(e) for s, e in ev), len(ev)) for n, ev in self.events.items()}
 
 
-def build_workload(name, device, rank, world, seed=0, parallel="sp"):
+def choose_layout(n_groups, world):
+    """(pp, sp) with pp * sp == world for `--parallel auto`: a layer pipeline of pp stages, each a group-token parallel group of
+    sp ranks.  Model: the pipe is busy G / (G + pp - 1) of the time; an sp group of s ranks runs at EFF_SP[s] of a single GPU
+    (GEMMs at M = n/s, exchange, replicated prune; measured / estimated at cfg2 sizes)."""
+    EFF_SP = {1: 1.0, 2: 0.92, 4: 0.75, 8: 0.5}
+    best, best_eff = (1, world), -1.0
+    pp = 1
+    while pp <= world:
+        sp = world // pp
+        if pp * sp == world and sp in EFF_SP:
+            eff = n_groups / (n_groups + pp - 1) * EFF_SP[sp]
+            if eff > best_eff + 1e-9:
+                best, best_eff = (pp, sp), eff
+        pp *= 2
+    return best
+
+
+def build_workload(name, device, rank, world, seed=0, parallel="sp", layout=None):
     model, frames, fh, fw, gs, rho, prefix, tail = CONFIGS[name]
     spec = PRESETS[model]
     gh, gw = fh // 14, fw // 14
@@ -81,14 +98,15 @@ def build_workload(name, device, rank, world, seed=0, parallel="sp"):
     pos, delta = planner.mrope_positions(prefix, (frames // 2, gh, gw), tail, temporal_scale=spec.temporal_scale)
     cfg = LVUConfig(model, top_p=rho, video_group_size=gs, num_frames=frames)
     tp = parallel == "tp" and world > 1
-    pp = parallel == "pp" and world > 1
+    pp_n, sp_n = layout if layout is not None else (1, 1)
+    stage, sp_rank = rank // sp_n, rank % sp_n                                   # ranks of a stage are consecutive
     weights = DecoderWeights.synthetic(spec, device, seed=seed, tp_rank=rank if tp else 0, tp_size=world if tp else 1,
-                                       layer_range=pp_layer_split(spec.n_layers, world, rank) if pp else None)
+                                       layer_range=pp_layer_split(spec.n_layers, pp_n, stage) if pp_n > 1 else None)
     kept = sum(effective_k(n, cfg, 0, spec.n_layers) or n for n in plan.tokens)
     cap = kept + plan.tail_len + 64
     eng = QuickPrefillEngine(weights, cfg, capacity=cap, max_group_tokens=max(plan.tokens + [plan.tail_len]), device=device,
-                             sp_rank=rank if parallel == "sp" else 0, sp_size=world if parallel == "sp" else 1,
-                             pp_rank=rank if pp else 0, pp_size=world if pp else 1)
+                             sp_rank=sp_rank, sp_size=sp_n, pp_rank=stage, pp_size=pp_n,
+                             pp_peers=[s * sp_n + sp_rank for s in range(pp_n)] if pp_n > 1 else None)
     g = torch.Generator(device=device); g.manual_seed(1234)      # same embeddings on every TP rank
     # synthetic ViT output / text embeddings: N(0, 1) scaled like embedding rows (the ViT front end is bench'd separately)
     embeds = (torch.randn(T, spec.hidden, generator=g, device=device, dtype=torch.float32) * 0.5).to(torch.bfloat16)
@@ -105,7 +123,7 @@ def run_step(eng, plan, embeds, pos):
     logits = eng.prefill_tail(embeds[start:], pos[:, start:])
     tok = torch.argmax(logits) if logits is not None else torch.zeros((), dtype=torch.int64, device=embeds.device)
     if eng.pp_size > 1:                  # layer pipeline: the last stage holds the logits; the token returns to every stage
-        torch.distributed.broadcast(tok, src=eng.pp_size - 1, group=eng.pp_group)
+        torch.distributed.broadcast(tok, src=torch.distributed.get_world_size() - 1)
     return tok                           # first generated token id (stays on device; .item() would be the TTFT point)
 
 
@@ -240,16 +258,25 @@ def main():
             torch.distributed.init_process_group("nccl", device_id=device)    # nccl == RCCL over xGMI on ROCm
         tp_group = torch.distributed.group.WORLD
 
-    if args.parallel == "auto":               # long videos keep a layer pipeline full; short ones split each group's tokens
-        _, frames_, _, _, gs_, _, _, _ = CONFIGS[args.config]
-        args.parallel = "pp" if world > 1 and -(-frames_ // gs_) >= 4 * world else "sp"
-    spec, cfg, plan, eng, embeds, pos, T = build_workload(args.config, device, rank, world, parallel=args.parallel)
+    # layout = (pp stages) x (sp ranks per stage); auto picks it from the number of groups (long videos keep a layer pipeline full,
+    # short ones split each group's tokens); "sp" / "pp" force the pure forms, "tp" is tensor parallel
+    _, frames_, _, _, gs_, _, _, _ = CONFIGS[args.config]
+    n_groups_ = -(-frames_ // gs_)
+    layout = (1, 1)
+    if world > 1:
+        layout = {"auto": choose_layout(n_groups_, world), "sp": (1, world), "pp": (world, 1), "tp": (1, 1)}[args.parallel]
+    if args.parallel != "tp":
+        args.parallel = "single" if world == 1 else ("sp" if layout[0] == 1 else "pp" if layout[1] == 1 else "ppsp")
+    spec, cfg, plan, eng, embeds, pos, T = build_workload(args.config, device, rank, world, parallel=args.parallel, layout=layout)
     if args.parallel == "tp":
         eng.tp_group = tp_group
-    elif args.parallel == "pp":
-        eng.pp_group = tp_group
-    else:
-        eng.sp_group = tp_group
+    elif world > 1:
+        pp_n, sp_n = layout
+        if sp_n == world:
+            eng.sp_group = tp_group
+        elif sp_n > 1:                        # every rank creates every stage's group, in the same order
+            stage_groups = [torch.distributed.new_group(ranks=list(range(s * sp_n, (s + 1) * sp_n))) for s in range(pp_n)]
+            eng.sp_group = stage_groups[rank // sp_n]
     tokens = sum(plan.tokens)                 # tokens prefetched in the group loop (the reference's total_prefill span)
 
     def barrier():
@@ -289,20 +316,19 @@ def main():
         eng.ops = real_ops
         tot = timed.totals_ms()
         att_ms, att_n = tot["prefill_attn"]
-        att_local = att / world                                  # tp: heads sharded; sp: query rows sharded (zigzag chunks)
-        if world > 1 and args.parallel == "pp":                  # this stage's layers only
-            l0_, l1_ = pp_layer_split(spec.n_layers, world, rank)
-            att_local = att * (l1_ - l0_) / spec.n_layers
-        if world > 1 and args.parallel == "sp":
+        att_local = att / world                                  # tp: heads sharded
+        if world > 1 and args.parallel != "tp":                  # rank 0: its stage's layers x its zigzag query rows
+            pp_n, sp_n = layout
+            l0_, l1_ = pp_layer_split(spec.n_layers, pp_n, rank // sp_n)
             att_local, Pp = 0.0, 0
             for n in plan.tokens:
-                if n >= 64 * world:
-                    for lo, hi in sp_row_ranges(n, world, rank):     # this rank's two zigzag chunks
+                if sp_n > 1 and n >= 64 * sp_n:
+                    for lo, hi in sp_row_ranges(n, sp_n, rank % sp_n):
                         att_local += 4.0 * spec.n_layers * spec.n_heads * spec.head_dim * sum(Pp + i + 1 for i in range(lo, hi))
                 else:
                     att_local += spec.attn_flops(n, Pp)
                 Pp += effective_k(n, cfg, 0, spec.n_layers) or n
-            att_local += spec.attn_flops(plan.tail_len, Pp)
+            att_local = (att_local + spec.attn_flops(plan.tail_len, Pp)) * (l1_ - l0_) / spec.n_layers
         ach = att_local / (att_ms * 1e-3) / 1e12
         traffic = None            # HBM bytes per launch from the committed rocprofv3 PMC passes (tools/profile_bench.sh), same command
         tpath = os.path.join(ROOT, "profiles", "attn_pmc_traffic_latest.json")
@@ -334,7 +360,8 @@ def main():
                                    f"{CONFIGS[args.config][2]}x{CONFIGS[args.config][3]}, group_size {CONFIGS[args.config][4]}, "
                                    f"key-norm rho={CONFIGS[args.config][5]}",
                        "groups": len(plan.tokens), "tokens_per_group": plan.tokens[-1], "prefill_tokens": tokens,
-                       "tail_tokens": plan.tail_len, "layers": spec.n_layers, "parallelism": (f"{args.parallel}{world}" if world > 1 else "single"),
+                       "tail_tokens": plan.tail_len, "layers": spec.n_layers, "parallelism": ("single" if world == 1 else f"tp{world}" if args.parallel == "tp" else
+                                                                                   f"pp{layout[0]}xsp{layout[1]}"),
                        "vit": "excluded (synthetic ViT-output embeddings resident in HBM)",
                        "weights": "seeded random at real dims"},
             "ttft_ms_prefill_leg": None if ttft_ms is None else round(ttft_ms, 3), "first_token": first,

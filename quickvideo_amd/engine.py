@@ -56,7 +56,8 @@ class KVArena:
 
 class QuickPrefillEngine:
     def __init__(self, weights: DecoderWeights, cfg: LVUConfig, capacity: int, max_group_tokens: int, device=None, ops=None,
-                 tp_group=None, sp_group=None, sp_rank: int = 0, sp_size: int = 1, pp_group=None, pp_rank: int = 0, pp_size: int = 1):
+                 tp_group=None, sp_group=None, sp_rank: int = 0, sp_size: int = 1, pp_group=None, pp_rank: int = 0, pp_size: int = 1,
+                 pp_peers: Optional[List[int]] = None):
         self.w, self.spec, self.cfg = weights, weights.spec, cfg
         self.device = torch.device(device if device is not None else weights.embed.device)
         if ops is None:
@@ -76,7 +77,10 @@ class QuickPrefillEngine:
         # hand-off per group and stage.  Groups flow through the stages back to back, so a video of G groups keeps
         # G / (G + N - 1) of the machine busy — the mode for long videos (cfg4: G = 450); short ones (cfg2: G = 4) use "sp".
         self.pp_group, self.pp_rank, self.pp_size = pp_group, pp_rank, pp_size
-        assert not (self.pp_size > 1 and (self.sp_size > 1 or self.tp_size > 1)), "layer pipeline is not combined with tp/sp"
+        # pp_peers[s] = global rank of this rank's counterpart in stage s.  A stage may itself be a group-token parallel ("sp") group:
+        # its ranks own the same zigzag rows in every stage, so each hands its own rows to its counterpart (no re-shuffle).
+        self.pp_peers = pp_peers
+        assert not (self.pp_size > 1 and self.tp_size > 1), "layer pipeline is not combined with tensor parallelism"
         self.l0, self.n_layers_total = weights.layer0, weights.n_layers_total
         s = self.spec
         self.hq, self.hkv, self.li = weights.local_q_heads, weights.local_kv_heads, weights.local_inter
@@ -128,12 +132,14 @@ class QuickPrefillEngine:
 
     # ------------------------------------------------------------------ one segment through all layers
     def forward_segment(self, embeds: torch.Tensor, pos: torch.Tensor, prune: bool) -> torch.Tensor:
-        """embeds [n, d] (device, engine dtype), pos int64 [3, n].  Returns the final hidden rows [n', d] (pre-norm)."""
+        """embeds [n, d] (device, engine dtype), pos int64 [3, n].  Returns the final hidden rows [n', d] (pre-norm)
+        (group-token parallel segments: this rank's rows only)."""
         s, ops, cfg, D = self.spec, self.ops, self.cfg, self.D
-        n = embeds.shape[0]
+        n = pos.shape[1]                             # embeds may hold only this rank's rows (sp stage behind another stage)
         assert n <= self.n_max, f"group of {n} tokens exceeds max_group_tokens={self.n_max}"
-        if self.sp_size > 1 and n >= 64 * self.sp_size:
+        if self._sp_active(n):
             return self._forward_segment_sp(embeds, pos, prune)
+        assert embeds.shape[0] == n
         L = self.n_layers_total                      # effective_k's decay uses the GLOBAL layer index / count
         cos, sin = ops.mrope_table(pos.contiguous(), s.mrope_section, s.rope_theta, D)
         if self.pp_size > 1 and prune and cfg.enable and isinstance(cfg.prefill_prune_starting_layer, int) and cfg.prefill_prune_starting_layer >= 0:
@@ -219,7 +225,7 @@ class QuickPrefillEngine:
         attention work (an early, cheap chunk plus a late, expensive one).
         Returns this rank's hidden rows (callers only need them for the replicated prompt tail)."""
         s, ops, cfg, D, N, r = self.spec, self.ops, self.cfg, self.D, self.sp_size, self.sp_rank
-        n = embeds.shape[0]
+        n = pos.shape[1]
         if cfg.enable and isinstance(cfg.prefill_prune_starting_layer, int) and cfg.prefill_prune_starting_layer >= 0 and prune:
             raise NotImplementedError("hidden-state pruning (prefill_prune_starting_layer) is not combined with group-token parallelism")
         (a0, a1), (b0, b1) = sp_row_ranges(n, N, r)
@@ -231,8 +237,12 @@ class QuickPrefillEngine:
         rows = torch.cat([torch.arange(a0, a1, device=self.device), torch.arange(b0, b1, device=self.device)])
         cos, sin = ops.mrope_table(pos.index_select(1, rows).contiguous(), s.mrope_section, s.rope_theta, D)
         h = self.b_h[:ml]
-        h[:nA].copy_(embeds[a0:a1])
-        h[nA:].copy_(embeds[b0:b1])
+        if self.pp_size > 1 and self.pp_rank > 0:    # rows handed over by the same sp rank of the previous pipeline stage
+            assert embeds.shape[0] == ml
+            h.copy_(embeds)
+        else:
+            h[:nA].copy_(embeds[a0:a1])
+            h[nA:].copy_(embeds[b0:b1])
         delta = None
         scale = D ** -0.5
         kv_bytes = self.hkv * m * D * 2
@@ -296,29 +306,44 @@ class QuickPrefillEngine:
 
     # ------------------------------------------------------------------ public steps of the group loop
     # layer-pipeline hand-off: stage r > 0 receives the segment's hidden rows from stage r-1, the last stage keeps its output
+    def _sp_active(self, n: int) -> bool:
+        return self.sp_size > 1 and n >= 64 * self.sp_size
+
+    def _pp_rows(self, n: int) -> int:
+        """Rows of an n-token segment that travel between this rank and its pipeline counterparts."""
+        if not self._sp_active(n):
+            return n
+        (a0, a1), (b0, b1) = sp_row_ranges(n, self.sp_size, self.sp_rank)
+        return (a1 - a0) + (b1 - b0)
+
+    def _pp_p2p_group(self):
+        return None if self.pp_peers is not None else self.pp_group      # explicit peers are global ranks of the default group
+
     def _pp_peer(self, r: int) -> int:
+        if self.pp_peers is not None:
+            return self.pp_peers[r]
         return torch.distributed.get_global_rank(self.pp_group, r) if self.pp_group is not None else r
 
     def _pp_host_staged(self, t: torch.Tensor) -> bool:
         # gloo moves device tensors without ordering against the compute stream: stage through the host (developer runs of
         # several ranks on one GPU; RCCL point-to-point is stream-ordered and takes the device buffer directly)
-        return t.is_cuda and torch.distributed.get_backend(self.pp_group) == "gloo"
+        return t.is_cuda and torch.distributed.get_backend(self._pp_p2p_group()) == "gloo"
 
     def _pp_in(self, embeds: torch.Tensor) -> torch.Tensor:
         if self.pp_size == 1 or self.pp_rank == 0:
             return embeds
-        buf = self.b_h2[: embeds.shape[0]]
+        buf = self.b_h2[: self._pp_rows(embeds.shape[0])]
         if self._pp_host_staged(buf):
             host = torch.empty(buf.shape, dtype=buf.dtype)
-            torch.distributed.recv(host, src=self._pp_peer(self.pp_rank - 1), group=self.pp_group)
+            torch.distributed.recv(host, src=self._pp_peer(self.pp_rank - 1), group=self._pp_p2p_group())
             buf.copy_(host)
         else:
-            torch.distributed.recv(buf, src=self._pp_peer(self.pp_rank - 1), group=self.pp_group)
+            torch.distributed.recv(buf, src=self._pp_peer(self.pp_rank - 1), group=self._pp_p2p_group())
         return buf
 
     def _pp_out(self, h: torch.Tensor):
         if self.pp_size > 1 and self.pp_rank < self.pp_size - 1:
-            torch.distributed.send(h.cpu() if self._pp_host_staged(h) else h, dst=self._pp_peer(self.pp_rank + 1), group=self.pp_group)
+            torch.distributed.send(h.cpu() if self._pp_host_staged(h) else h, dst=self._pp_peer(self.pp_rank + 1), group=self._pp_p2p_group())
 
     @property
     def is_last_stage(self) -> bool:

@@ -356,3 +356,52 @@ def test_layer_pipeline_gloo(world):
             for l in range(l1 - l0):
                 a, b = mine[s * (l1 - l0) + l][1], ref[s * L + l0 + l][1]
                 assert (a is None) == (b is None) and (a is None or np.array_equal(a, b))
+
+
+# ---------------------------------------------------------------- layer pipeline of group-token parallel stages (pp2 x sp2)
+def _ppsp_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from quickvideo_amd.engine import QuickPrefillEngine
+    from quickvideo_amd.lvu_config import LVUConfig
+    from quickvideo_amd.spec import TextSpec
+    from quickvideo_amd.weights import DecoderWeights, pp_layer_split
+    pp, sp = 2, 2
+    stage, sp_rank = rank // sp, rank % sp
+    groups_ = [dist.new_group(ranks=list(range(s * sp, (s + 1) * sp))) for s in range(pp)]     # every rank creates every group
+    L = 4
+    so = O.TextSpec(hidden=256, n_heads=4, n_kv_heads=2, head_dim=128, intermediate=256, n_layers=L, vocab=128)
+    spec = TextSpec(hidden=256, n_heads=4, n_kv_heads=2, head_dim=128, intermediate=256, n_layers=L, vocab=128)
+    w = {k: v.to(torch.bfloat16) for k, v in O.synthetic_text_weights(so, seed=11, norm_jitter=0.1).items()}
+    rs = np.random.RandomState(4)
+    groups = [64 * sp + 9, 64 * sp + 40]
+    T = sum(groups) + 8
+    embeds = torch.from_numpy(rs.standard_normal((T, 256)).astype(np.float32) * 0.5).to(torch.bfloat16)
+    pos = np.tile(np.arange(T, dtype=np.int64), (3, 1))
+    post = torch.from_numpy(pos)
+    cfg = LVUConfig("x", top_p=0.5, video_group_size=4)
+    eng = QuickPrefillEngine(DecoderWeights.from_named(spec, w, "cpu", layer_range=pp_layer_split(L, pp, stage)), cfg, capacity=T + 4,
+                             max_group_tokens=max(groups), device="cpu", ops=OracleOps(), sp_group=groups_[stage], sp_rank=sp_rank, sp_size=sp,
+                             pp_rank=stage, pp_size=pp, pp_peers=[s * sp + sp_rank for s in range(pp)])
+    st = 0
+    for n in groups:
+        eng.prefill_group(embeds[st:st + n], post[:, st:st + n]); st += n
+    logits = eng.prefill_tail(embeds[st:], post[:, st:])
+    ret[f"len{rank}"] = list(eng.arena.len)
+    ret[f"logits{rank}"] = None if logits is None else logits.numpy()
+    if rank == 0:
+        ref = O.group_prefill(w, so, embeds, pos, groups, O.PruneCfg(top_p=0.5))
+        ret["ref_logits"], ret["ref_len"] = ref["logits"].numpy(), ref["cache_len"]
+    dist.destroy_process_group()
+
+
+def test_layer_pipeline_of_group_token_parallel_stages_gloo():
+    world = 4
+    port = 36500 + os.getpid() % 2000
+    ret = mp.Manager().dict()
+    mp.spawn(_ppsp_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert ret["logits0"] is None and ret["logits1"] is None                    # stage 0 has no logits
+    assert np.array_equal(ret["logits2"], ret["logits3"])                        # both sp ranks of the last stage agree exactly
+    assert np.max(np.abs(ret["logits2"] - ret["ref_logits"])) <= 4e-2
+    assert ret["len0"] + ret["len2"] == ret["ref_len"] and ret["len1"] == ret["len0"] and ret["len3"] == ret["len2"]
