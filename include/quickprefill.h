@@ -95,6 +95,13 @@ size_t qp_attn_workspace_bytes(const qp_ctx* ctx, int64_t n, int64_t prefix_len,
 int qp_key_sumsq(qp_ctx* ctx, const void* k, int64_t head_stride, int64_t row0, int64_t n, int n_kv_heads,
                  int head_dim, float* head_sumsq, void* stream);
 
+/* Which rows the select keeps — the reference's norm-based `top_k_predict_type`s (utils.py:117-136):
+ *   "key_norms_small" (default) = source 0, order 0;  "key_norms" = 0, 1;  "vector_norms_small" = 1, 0;  "vector_norms" = 1, 1.
+ * norm_source: 0 = key rows, 1 = value rows (only qp_prune_tail reads it: the other entry points take the sums from the
+ * caller, who computes them over the rows of its choice with qp_key_sumsq).  order: 0 = k smallest norms (argsort ascending),
+ * 1 = k largest (argsort descending); ties always resolve to the lowest index.  Applies to subsequent calls on this ctx. */
+int qp_set_prune_mode(qp_ctx* ctx, int norm_source, int order);
+
 size_t qp_select_workspace_bytes(int64_t n);
 
 /* head_sumsq fp32 [n_heads_total][n] (all KV heads of the layer, ascending head order; under tensor

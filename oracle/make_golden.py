@@ -138,6 +138,33 @@ def gen_select(ref):
     json.dump(meta, open(os.path.join(OUT, "gv1_select.json"), "w"), indent=1)
 
 
+MODE_CASES = [0, 1, 3, 5, 9, 10, 12, 14, 16]      # SELECT_CASES indices re-used for the other norm-based predict types
+
+
+def gen_select_modes(ref):
+    """GV1b: kept indices of the reference for predict_type in {key_norms, vector_norms, vector_norms_small}
+    (utils.py:117-131) — argsort forced stable (ties -> lowest index), same input recipe as GV1.  For the vector_* modes the
+    seeded tensor is passed as `values` (and zeros as keys)."""
+    U = ref["utils"]
+    out, meta = {}, []
+    for ci in MODE_CASES:
+        dist, hkv, n, k = SELECT_CASES[ci]
+        x = make_keys(dist, hkv, n, 1000 + ci)
+        zeros = torch.zeros_like(x)
+        hid = torch.zeros(1, n, 8)
+        for mode in ("key_norms", "vector_norms", "vector_norms_small"):
+            keys, vals = (x, zeros) if mode == "key_norms" else (zeros, x)
+            with force_stable_argsort():
+                mask = U.get_top_k_mask_to_predict(None, keys, vals, hid, top_k=k, predict_type=mode)
+            idx = torch.nonzero(mask[0], as_tuple=True)[0].numpy().astype(np.int32)
+            assert len(idx) == k
+            out[f"c{ci}_{mode}"] = idx
+        meta.append(dict(case=ci, dist=dist, hkv=hkv, n=n, k=k, seed=1000 + ci))
+    np.savez_compressed(os.path.join(OUT, "gv1b_select_modes.npz"), **out)
+    json.dump(meta, open(os.path.join(OUT, "gv1b_select_modes.json"), "w"), indent=1)
+    print("gv1b:", len(out), "index lists")
+
+
 def gen_effective_k(ref):
     U, C = ref["utils"], ref["lvu_config"]
     rows = []
@@ -313,8 +340,9 @@ def gen_rope_index():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     ref = load_reference()
-    which = sys.argv[1:] or ["select", "effk", "compact", "e2e", "rope"]
+    which = sys.argv[1:] or ["select", "modes", "effk", "compact", "e2e", "rope"]
     if "select" in which: gen_select(ref)
+    if "modes" in which: gen_select_modes(ref)
     if "effk" in which: gen_effective_k(ref)
     if "compact" in which: gen_compaction(ref)
     if "e2e" in which: gen_e2e(ref)

@@ -149,6 +149,18 @@ def select_k_smallest(norm_bits: np.ndarray, k: int) -> np.ndarray:
     return np.sort(order).astype(np.int32)
 
 
+def select_k_largest(norm_bits: np.ndarray, k: int) -> np.ndarray:
+    """Ascending int32 indices of the k LARGEST norms, ties -> lowest index first (the reference's ``key_norms`` /
+    ``vector_norms``: utils.py:117-131 ``argsort(descending=True)[:k]`` in its stable form, then mask -> nonzero)."""
+    keys = (0xFFFF - norm_bits.astype(np.int64)) if norm_bits.dtype == np.uint16 else -norm_bits
+    order = np.argsort(keys, kind="stable")[:k]
+    return np.sort(order).astype(np.int32)
+
+
+# norm-based predict types (utils.py:117-136): name -> (norm source: 0 key rows / 1 value rows, order: 0 smallest / 1 largest)
+NORM_PRUNE_MODES = {"key_norms_small": (0, 0), "key_norms": (0, 1), "vector_norms_small": (1, 0), "vector_norms": (1, 1)}
+
+
 def select_threshold(norm_bits: np.ndarray, k: int) -> Tuple[int, int, int]:
     """(tau, n_less, n_equal): k-th smallest pattern, #patterns < tau, #patterns == tau."""
     srt = np.sort(norm_bits.astype(np.int64))
@@ -293,6 +305,7 @@ class PruneCfg:
     enable: bool = True
     prefill_prune_starting_layer: Optional[int] = None
     top_k_starting_layer: Optional[int] = None
+    top_k_predict_type: str = "key_norms_small"       # or key_norms / vector_norms_small / vector_norms (utils.py:117-136)
 
 
 def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
@@ -376,7 +389,7 @@ def _norm_keys_of(k_new: torch.Tensor) -> np.ndarray:
 
 def decoder_layer(h: torch.Tensor, w: dict, layer: int, spec: TextSpec, cache: OracleCache,
                   cos: torch.Tensor, sin: torch.Tensor, k_keep: Optional[int],
-                  prune_hidden: bool = False, trace: Optional[dict] = None):
+                  prune_hidden: bool = False, trace: Optional[dict] = None, predict_type: str = "key_norms_small"):
     """One patched decoder layer (qwen25_lvu.py:122-212) on h [n, d].
 
     Returns (h_out, kept_idx or None).  When ``prune_hidden`` (prune_for_next_layer,
@@ -399,8 +412,9 @@ def decoder_layer(h: torch.Tensor, w: dict, layer: int, spec: TextSpec, cache: O
     kept = None
     if k_keep is not None:                                  # post_process_kv_cache, utils.py:257-342
         past = k_all.shape[1] - n
-        norms = _norm_keys_of(k_all[:, past:])
-        kept = select_k_smallest(norms, k_keep)
+        source, order = NORM_PRUNE_MODES[predict_type]
+        norms = _norm_keys_of((v_all if source else k_all)[:, past:])
+        kept = select_k_largest(norms, k_keep) if order else select_k_smallest(norms, k_keep)
         ti = torch.from_numpy(kept.astype(np.int64))
         cache.k[layer] = torch.cat([k_all[:, :past], k_all[:, past:][:, ti]], dim=1)
         cache.v[layer] = torch.cat([v_all[:, :past], v_all[:, past:][:, ti]], dim=1)
@@ -442,7 +456,8 @@ def group_prefill(w: dict, spec: TextSpec, embeds: torch.Tensor, pos: np.ndarray
                                                       cfg.top_k_starting_layer)
             ph = (not is_tail and cfg.enable and isinstance(cfg.prefill_prune_starting_layer, int)
                   and cfg.prefill_prune_starting_layer >= 0 and l >= cfg.prefill_prune_starting_layer)
-            h, kept, cos, sin = decoder_layer(h, w, l, spec, cache, cos, sin, k_keep, prune_hidden=ph)
+            h, kept, cos, sin = decoder_layer(h, w, l, spec, cache, cos, sin, k_keep, prune_hidden=ph,
+                                              predict_type=cfg.top_k_predict_type)
             kept_g.append(kept)
         kept_all.append(kept_g)
         start += n

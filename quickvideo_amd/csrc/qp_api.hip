@@ -46,6 +46,7 @@ int qp_create(qp_ctx** out, int device) {
   c->device = device;
   c->cus = prop.multiProcessorCount;
   c->lds_per_cu = (int)prop.sharedMemPerBlock;
+  c->norm_source = 0; c->order = 0;            // key_norms_small
   *out = c;
   return QP_OK;
 }
@@ -128,6 +129,14 @@ int qp_key_sumsq(qp_ctx* ctx, const void* k, int64_t head_stride, int64_t row0, 
   return qp_launch_key_sumsq(k, head_stride, row0, n, n_kv_heads, head_sumsq, (hipStream_t)stream);
 }
 
+int qp_set_prune_mode(qp_ctx* ctx, int norm_source, int order) {
+  QP_REQUIRE(ctx, QP_ERR_INVALID, "qp_set_prune_mode: NULL ctx");
+  QP_REQUIRE((norm_source == 0 || norm_source == 1) && (order == 0 || order == 1), QP_ERR_INVALID,
+             "qp_set_prune_mode: norm_source=%d order=%d (each 0 or 1)", norm_source, order);
+  ctx->norm_source = norm_source; ctx->order = order;
+  return QP_OK;
+}
+
 size_t qp_select_workspace_bytes(int64_t n) { return n > 65536 ? (size_t)n * 2 + 256 : 256; }
 
 int qp_select_k_smallest(qp_ctx* ctx, const float* head_sumsq, int n_heads_total, int64_t n, int64_t k,
@@ -140,7 +149,7 @@ int qp_select_k_smallest(qp_ctx* ctx, const float* head_sumsq, int n_heads_total
   QP_REQUIRE(n < (1ll << 31), QP_ERR_UNSUPPORTED, "qp_select_k_smallest: n=%lld too large", (long long)n);
   QP_REQUIRE(n <= 65536 || (workspace != nullptr && workspace_bytes >= qp_select_workspace_bytes(n)), QP_ERR_WORKSPACE,
              "qp_select_k_smallest: n=%lld > 65536 needs a workspace of %zu bytes", (long long)n, qp_select_workspace_bytes(n));
-  return qp_launch_select(head_sumsq, n_heads_total, n, k, kept_idx_out, norm_bits_out, workspace, (hipStream_t)stream);
+  return qp_launch_select(head_sumsq, n_heads_total, n, k, kept_idx_out, norm_bits_out, workspace, ctx->order, (hipStream_t)stream);
 }
 
 int qp_gather_kv(qp_ctx* ctx, const void* k_src, const void* v_src, int64_t src_head_stride, const int32_t* idx, int64_t k,
@@ -171,9 +180,9 @@ int qp_prune_staged(qp_ctx* ctx, const float* head_sumsq, int n_heads_total, int
   QP_REQUIRE(aligned16(k_src) && aligned16(v_src) && aligned16(k_dst) && aligned16(v_dst), QP_ERR_INVALID, "qp_prune_staged: alignment");
   hipStream_t s = (hipStream_t)stream;
   int rc = qp_launch_prune_fused(head_sumsq, n_heads_total, n, k, k_src, v_src, src_head_stride, n_kv_heads, k_dst, v_dst,
-                                 dst_head_stride, dst_row0, kept_idx_out, norm_bits_out, ctx->cus, s);
+                                 dst_head_stride, dst_row0, kept_idx_out, norm_bits_out, ctx->cus, ctx->order, s);
   if (rc != 1) return rc;
-  rc = qp_launch_select(head_sumsq, n_heads_total, n, k, kept_idx_out, norm_bits_out, nullptr, s);     // large n: two launches
+  rc = qp_launch_select(head_sumsq, n_heads_total, n, k, kept_idx_out, norm_bits_out, nullptr, ctx->order, s);     // large n: two launches
   if (rc) return rc;
   return qp_launch_gather_kv(k_src, v_src, src_head_stride, kept_idx_out, k, n_kv_heads, k_dst, v_dst, dst_head_stride, dst_row0, s);
 }
@@ -201,9 +210,9 @@ int qp_prune_tail(qp_ctx* ctx, void* k_cache, void* v_cache, int64_t head_stride
   float* sumsq = (float*)ws;
   unsigned char* kt = ws + align256((size_t)n_kv_heads * n * 4);
   unsigned char* vt = kt + align256((size_t)n_kv_heads * k * head_dim * 2);
-  int rc = qp_launch_key_sumsq(k_cache, head_stride, past_len, n, n_kv_heads, sumsq, s);
+  int rc = qp_launch_key_sumsq(ctx->norm_source ? v_cache : k_cache, head_stride, past_len, n, n_kv_heads, sumsq, s);
   if (rc) return rc;
-  rc = qp_launch_select(sumsq, n_kv_heads, n, k, kept_idx_out, nullptr, nullptr, s);
+  rc = qp_launch_select(sumsq, n_kv_heads, n, k, kept_idx_out, nullptr, nullptr, ctx->order, s);
   if (rc) return rc;
   // gather the kept tail rows into the workspace, then copy them back contiguously (dst <= src row-wise, but
   // workgroups run in no defined order, so the in-place move goes through the scratch block)

@@ -9,6 +9,8 @@ struct qp_ctx {
   int device;
   int cus;
   int lds_per_cu;
+  int norm_source;   // qp_set_prune_mode: 0 = key rows, 1 = value rows (qp_prune_tail)
+  int order;         // 0 = k smallest norms, 1 = k largest
 };
 
 // thread-local error message (qp_api.cpp)
@@ -44,7 +46,7 @@ int qp_launch_rope_append(const void* qkv, const void* cos, const void* sin, int
 int qp_launch_key_sumsq(const void* k, int64_t head_stride, int64_t row0, int64_t n, int hkv, float* head_sumsq,
                         hipStream_t s);
 int qp_launch_select(const float* head_sumsq, int n_heads, int64_t n, int64_t k, int32_t* kept, uint16_t* norm_bits,
-                     void* ws, hipStream_t s);
+                     void* ws, int largest, hipStream_t s);
 int qp_launch_gather_kv(const void* k_src, const void* v_src, int64_t src_head_stride, const int32_t* idx, int64_t k,
                         int hkv, void* k_dst, void* v_dst, int64_t dst_head_stride, int64_t dst_row0, hipStream_t s);
 int qp_launch_gather_rows(const void* src, const int32_t* idx, int64_t k, int64_t row_bytes, void* dst, hipStream_t s);
@@ -67,4 +69,4 @@ int qp_launch_vit_rope(void* qkv, const float* cos_t, const float* sin_t, int64_
 int qp_launch_quick_gelu(const void* x, void* out, int64_t n_elems, hipStream_t s);
 int qp_launch_prune_fused(const float* head_sumsq, int n_heads, int64_t n, int64_t k, const void* k_src, const void* v_src,
                           int64_t src_head_stride, int hkv, void* k_dst, void* v_dst, int64_t dst_head_stride, int64_t dst_row0,
-                          int32_t* kept, uint16_t* norm_bits, int cus, hipStream_t s);
+                          int32_t* kept, uint16_t* norm_bits, int cus, int largest, hipStream_t s);

@@ -119,7 +119,7 @@ __device__ __forceinline__ void find_bucket_256(const unsigned* hist, int nh, in
 template <bool kLds>
 __global__ __launch_bounds__(1024) void select_kernel(const float* __restrict__ head_sumsq, int n_heads, int n, int k,
                                                       int32_t* __restrict__ kept, uint16_t* __restrict__ norm_bits_out,
-                                                      uint16_t* __restrict__ keys_glb) {
+                                                      uint16_t* __restrict__ keys_glb, int largest) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned* hist = (unsigned*)smem;            // 256
   unsigned* scan = hist + 256;                 // 256
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(1024) void select_kernel(const float* __restrict__ 
     float s = head_sumsq[t];
     for (int h = 1; h < n_heads; ++h) s = s + head_sumsq[(int64_t)h * n + t];
     uint16_t b = f32_to_bf16_bits(sqrt_rn_f32(s));
-    keys[t] = b;
+    keys[t] = largest ? (uint16_t)~b : b;          // k largest == k smallest of the complemented pattern (ties: lowest index)
     if (norm_bits_out) norm_bits_out[t] = b;
   }
   if (tid < 256) hist[tid] = 0;
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(1024) void prune_fused_kernel(const float* __restri
                                                            const uint4* __restrict__ k_src, const uint4* __restrict__ v_src,
                                                            int64_t src_hs16, int hkv, uint4* __restrict__ k_dst,
                                                            uint4* __restrict__ v_dst, int64_t dst_hs16, int64_t dst_row0,
-                                                           int32_t* __restrict__ kept, uint16_t* __restrict__ norm_bits_out) {
+                                                           int32_t* __restrict__ kept, uint16_t* __restrict__ norm_bits_out, int largest) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned* hist = (unsigned*)smem;            // 16 per-wave histograms x 257 (odd stride: waves hit different banks)
   unsigned* scan = hist + 16 * 257;            // 256
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(1024) void prune_fused_kernel(const float* __restri
     float s = head_sumsq[t];
     for (int h = 1; h < n_heads; ++h) s = s + head_sumsq[(int64_t)h * n + t];
     uint16_t b = f32_to_bf16_bits(sqrt_rn_f32(s));
-    keys[t] = b;
+    keys[t] = largest ? (uint16_t)~b : b;
     if (blockIdx.x == 0 && norm_bits_out) norm_bits_out[t] = b;
   }
   for (int i = tid; i < 16 * 257; i += 1024) hist[i] = 0;
@@ -246,7 +246,7 @@ static size_t prune_fused_smem(int64_t n, int64_t k) { return (16 * 257 + 256 + 
 
 int qp_launch_prune_fused(const float* head_sumsq, int n_heads, int64_t n, int64_t k, const void* k_src, const void* v_src,
                           int64_t src_head_stride, int hkv, void* k_dst, void* v_dst, int64_t dst_head_stride, int64_t dst_row0,
-                          int32_t* kept, uint16_t* norm_bits, int cus, hipStream_t s) {
+                          int32_t* kept, uint16_t* norm_bits, int cus, int largest, hipStream_t s) {
   const size_t smem = prune_fused_smem(n, k);
   if (smem > 150 * 1024) return 1;             // caller falls back to select + gather
   static bool attr_set = false;
@@ -261,17 +261,17 @@ int qp_launch_prune_fused(const float* head_sumsq, int n_heads, int64_t n, int64
   if (grid < 1) grid = 1;
   prune_fused_kernel<<<grid, 1024, smem, s>>>(head_sumsq, n_heads, (int)n, (int)k, (const uint4*)k_src, (const uint4*)v_src,
                                              src_head_stride / 8, hkv, (uint4*)k_dst, (uint4*)v_dst, dst_head_stride / 8, dst_row0,
-                                             kept, norm_bits);
+                                             kept, norm_bits, largest);
   return qp_check_launch("prune_fused");
 }
 
 static size_t select_smem_bytes(int64_t n) { return (256 + 256 + 16 + 4 + 4) * 4 + (size_t)((n + 7) / 8 * 8) * 2; }
 
 int qp_launch_select(const float* head_sumsq, int n_heads, int64_t n, int64_t k, int32_t* kept, uint16_t* norm_bits,
-                     void* ws, hipStream_t s) {
+                     void* ws, int largest, hipStream_t s) {
   if (n > 65536) {
     if (ws == nullptr) return qp_fail(QP_ERR_WORKSPACE, "select: n=%lld > 65536 needs a workspace of qp_select_workspace_bytes(n)", (long long)n);
-    select_kernel<false><<<1, 1024, select_smem_bytes(0), s>>>(head_sumsq, n_heads, (int)n, (int)k, kept, norm_bits, (uint16_t*)ws);
+    select_kernel<false><<<1, 1024, select_smem_bytes(0), s>>>(head_sumsq, n_heads, (int)n, (int)k, kept, norm_bits, (uint16_t*)ws, largest);
     return qp_check_launch("select(global keys)");
   }
   size_t smem = select_smem_bytes(n);
@@ -281,7 +281,7 @@ int qp_launch_select(const float* head_sumsq, int n_heads, int64_t n, int64_t k,
     if (e != hipSuccess) return qp_fail(QP_ERR_HIP, "hipFuncSetAttribute(select): %s", hipGetErrorString(e));
     attr_set = true;
   }
-  select_kernel<true><<<1, 1024, smem, s>>>(head_sumsq, n_heads, (int)n, (int)k, kept, norm_bits, nullptr);
+  select_kernel<true><<<1, 1024, smem, s>>>(head_sumsq, n_heads, (int)n, (int)k, kept, norm_bits, nullptr, largest);
   return qp_check_launch("select");
 }
 

@@ -21,7 +21,7 @@ from typing import List, Optional, Sequence
 
 import torch
 
-from .lvu_config import LVUConfig, effective_k
+from .lvu_config import LVUConfig, NORM_PRUNE_MODES, effective_k
 from .spec import TextSpec
 from .weights import DecoderWeights
 
@@ -104,6 +104,12 @@ class QuickPrefillEngine:
         self.b_ss_all = e(self.tp_size, self.hkv, n, dtype=torch.float32) if self.tp_size > 1 else None
         self.b_idx = e(n, dtype=torch.int32)
         self.b_h2 = e(n, d)
+        # norm-based predict type (utils.py:117-136): which rows are scored (keys / values) and which end is kept
+        if cfg.top_k_predict_type not in NORM_PRUNE_MODES:
+            raise ValueError(f"Unknown predict type: {cfg.top_k_predict_type} (the native engine implements the norm-based modes "
+                             f"{sorted(NORM_PRUNE_MODES)}; lvu/utils.py:117-136)")
+        self.norm_source, self.norm_order = NORM_PRUNE_MODES[cfg.top_k_predict_type]
+        self.ops.set_prune_mode(self.norm_source, self.norm_order)
         self.kept_trace: Optional[list] = None      # tests: set to [] to record kept indices per (group, layer)
         self.seq_pos = 0                            # tokens of the original sequence consumed so far
 
@@ -164,6 +170,8 @@ class QuickPrefillEngine:
                 vn = self.b_stage[1].view(-1)[: self.hkv * n * D].view(self.hkv, n, D)
                 ops.rope_append(qkv, cos, sin, self.hq, self.hkv, D, q, kn, vn, n * D, 0, self.b_ss)
                 new_stride = n * D
+                if self.norm_source == 1:                                    # vector_norms*: score the value rows (utils.py:117-126)
+                    ops.key_sumsq(vn, n * D, 0, n, self.hkv, D, self.b_ss)
             else:                                                            # append in place                (:56-58)
                 kc, vc = self.arena.k(l), self.arena.v(l)
                 ops.rope_append(qkv, cos, sin, self.hq, self.hkv, D, q, kc, vc, self.arena.head_stride, past, None)
@@ -271,6 +279,8 @@ class QuickPrefillEngine:
             # [rank][K | V | sums] with each rank's two zigzag chunks -> staging block + key sums in token order (one launch)
             ss_all = self.b_ss.view(-1)[: self.hkv * n].view(self.hkv, n)
             ops.sp_unpack(self.b_xall, N, self.hkv, m2, D, n, kn, vn, new_stride, ss_all)
+            if self.norm_source == 1 and k_keep is not None:                 # vector_norms*: every rank scores the gathered value rows
+                ops.key_sumsq(vn, new_stride, 0, n, self.hkv, D, ss_all)
             att = self.b_att[:ml]
             past_attn = past if (cfg.adaptive_local_attention or not prune) else 0
             for (q0, lo_, hi_) in ((a0, 0, nA), (b0, nA, ml)):               # the two row chunks of this rank

@@ -53,6 +53,10 @@ class LVULayerConfig:
         self.prune_for_next_layer = bool(isinstance(p, int) and p >= 0 and self.layer_idx >= p)
 
 
+# norm-based predict types (utils.py:117-136): name -> (norm source: 0 keys / 1 values, order: 0 k smallest / 1 k largest)
+NORM_PRUNE_MODES = {"key_norms_small": (0, 0), "key_norms": (0, 1), "vector_norms_small": (1, 0), "vector_norms": (1, 1)}
+
+
 def effective_k(q_len: int, cfg: LVUConfig, layer_idx: int, total_layers: int) -> Optional[int]:
     """How many of the group's q_len new tokens this layer keeps; None = this layer does not prune.
 

@@ -44,6 +44,7 @@ SIGNATURES = {
     "qp_prefill_attn_rows": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _f32, _vp, _vp, _sz, _vp]),
     "qp_attn_workspace_bytes": (_sz, [_vp, _i64, _i64, _i32, _i32]),
     "qp_key_sumsq": (_i32, [_vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _vp]),
+    "qp_set_prune_mode": (_i32, [_vp, _i32, _i32]),
     "qp_select_workspace_bytes": (_sz, [_i64]),
     "qp_select_k_smallest": (_i32, [_vp, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
     "qp_gather_kv": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _i64, _vp]),
@@ -178,6 +179,10 @@ class QuickPrefillOps:
         self._check(self.lib.qp_prune_tail(self.ctx, k_cache.data_ptr(), v_cache.data_ptr(), head_stride, past_len, n, k, n_kv,
                                            head_dim, kept_idx.data_ptr(), workspace.data_ptr(), workspace.numel() * workspace.element_size(),
                                            self._stream()))
+
+    def set_prune_mode(self, norm_source: int, order: int):
+        """0/0 = key_norms_small (default), 0/1 = key_norms, 1/0 = vector_norms_small, 1/1 = vector_norms (utils.py:117-136)."""
+        self._check(self.lib.qp_set_prune_mode(self.ctx, int(norm_source), int(order)))
 
     def sp_unpack(self, gathered, world, n_kv, m2, head_dim, n, k_stage, v_stage, stage_head_stride, sumsq_out):
         self._check(self.lib.qp_sp_unpack(self.ctx, gathered.data_ptr(), world, n_kv, m2, head_dim, n, k_stage.data_ptr(), v_stage.data_ptr(),

@@ -161,9 +161,6 @@ class PrefillPipeline:
     @torch.no_grad()
     def generate(self, question: str, video, max_new_tokens: int = 16, overlap: bool = True, eos_token_id: Optional[int] = None,
                  **unused) -> List[int]:
-        if self.cfg.top_k_predict_type != "key_norms_small":
-            raise ValueError(f"Unknown predict type: {self.cfg.top_k_predict_type} (the native engine implements key_norms_small, "
-                             f"lvu/utils.py:133-136; the reference's other ablation modes are out of scope)")
         tm = Timings()
         dev = self.model.device
         t_e2e = time.perf_counter()

@@ -58,10 +58,20 @@ class OracleOps:
             ks.append(torch.cat(parts_k)); vs.append(torch.cat(parts_v))
         out[:n].copy_(O.attention_bottom_right(q[:n].transpose(0, 1), torch.stack(ks), torch.stack(vs), scale))
 
+    order = 0            # qp_set_prune_mode: 0 = k smallest norms, 1 = k largest
+
+    def set_prune_mode(self, norm_source, order):
+        self.order = int(order)
+
+    def key_sumsq(self, k, head_stride, row0, n, n_kv, head_dim, head_sumsq):
+        rows = torch.stack([self._rows(k, h, head_stride, row0, n, head_dim) for h in range(n_kv)])
+        ss = O.key_sumsq_heads(O.torch_bf16_to_bits(rows.contiguous()))
+        head_sumsq.view(-1)[: n_kv * n].copy_(torch.from_numpy(ss).view(-1))
+
     def select_k_smallest(self, head_sumsq, n_heads_total, n, k, kept_idx, norm_bits=None):
         ss = head_sumsq.reshape(-1)[: n_heads_total * n].view(n_heads_total, n).numpy()
         nb = O.key_norms_bf16(ss)
-        kept_idx[:k].copy_(torch.from_numpy(O.select_k_smallest(nb, k)))
+        kept_idx[:k].copy_(torch.from_numpy(O.select_k_largest(nb, k) if self.order else O.select_k_smallest(nb, k)))
 
     def gather_kv(self, k_src, v_src, src_head_stride, idx, k, n_kv, D, k_dst, v_dst, dst_head_stride, dst_row0):
         ii = idx[:k].long()

@@ -143,3 +143,31 @@ def test_decode_step_positions_match_tail_prefill():
 
     a, b = run(False), run(True)
     assert torch.allclose(a, b, atol=2e-2) and int(a.argmax()) == int(b.argmax())
+
+
+@pytest.mark.parametrize("mode", ["key_norms", "vector_norms", "vector_norms_small"])
+def test_engine_equals_oracle_other_norm_modes(mode):
+    """The reference's other norm-based predict types (utils.py:117-131): the engine with the oracle-backed ops double equals
+    the composite oracle exactly (kept indices, cache contents, logits)."""
+    spec_o, w, plan, pos, delta, embeds = make_case(12, 8, 4, 4, 9, 6)
+    cfg = LVUConfig("x", top_p=0.5, video_group_size=4, top_k_predict_type=mode)
+    eng, logits = run_engine(w, plan, pos, embeds, cfg, OracleOps())
+    ref = O.group_prefill(w, spec_o, embeds, pos, plan.tokens, O.PruneCfg(top_p=0.5, top_k_predict_type=mode))
+    base = O.group_prefill(w, spec_o, embeds, pos, plan.tokens, O.PruneCfg(top_p=0.5))
+    assert eng.arena.len == ref["cache_len"]
+    flat_ref = [k for g in ref["kept"] for k in g]
+    flat_base = [k for g in base["kept"] for k in g]
+    differs = False
+    for (l, got), want, b in zip(eng.kept_trace, flat_ref, flat_base):
+        assert (got is None) == (want is None)
+        if want is not None:
+            assert np.array_equal(got.numpy(), want)
+            differs |= not np.array_equal(want, b)
+    assert differs                                     # the mode really selects other rows than key_norms_small
+    assert torch.equal(logits, ref["logits"])
+
+
+def test_unknown_predict_type_is_a_value_error():
+    spec_o, w, plan, pos, delta, embeds = make_case(12, 8, 4, 4, 9, 6)
+    with pytest.raises(ValueError, match="Unknown predict type"):          # lvu/utils.py:189
+        run_engine(w, plan, pos, embeds, LVUConfig("x", top_p=0.5, top_k_predict_type="salient_tokens"), OracleOps())

@@ -114,3 +114,23 @@ def test_lvu_generate_on_gpu(capsys):
         assert t.groups == 4 and t.ttft > 0 and t.vit > 0
     assert outs[0] == outs[1] and outs[0][0].count("<tok_") == 4
     assert "total time spent on prefill was" in capsys.readouterr().out
+
+
+@pytest.mark.parametrize("mode", ["key_norms", "vector_norms", "vector_norms_small"])
+def test_engine_other_norm_modes_vs_oracle(mode):
+    """qp_set_prune_mode through the engine: the other norm-based predict types against the composite oracle."""
+    spec_o, w, plan, pos, delta, embeds = make_case(24, 12, 16, 8, 15, 20)
+    cfg = LVUConfig("x", top_p=0.5, video_group_size=8, top_k_predict_type=mode)
+    eng, logits = run_gpu(TINY, w, plan, pos, embeds, cfg)
+    ref = O.group_prefill(w, spec_o, embeds, pos, plan.tokens, O.PruneCfg(top_p=0.5, top_k_predict_type=mode))
+    assert eng.arena.len == ref["cache_len"]
+    check_logits(logits.numpy(), ref["logits"].numpy())
+    flat_ref = [k for g in ref["kept"] for k in g]
+    tot = same = 0
+    for (l, got), want in zip(eng.kept_trace, flat_ref):
+        if want is not None:
+            g = got.cpu().numpy()
+            assert len(g) == len(want) and np.all(np.diff(g) > 0)
+            tot += len(want); same += len(set(g.tolist()) & set(want.tolist()))
+    assert same / tot >= 0.90, same / tot
+    eng.ops.set_prune_mode(0, 0)

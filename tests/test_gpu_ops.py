@@ -495,3 +495,31 @@ def test_sp_unpack_matches_host_permutation(ops, world, hkv, n):
     torch.cuda.synchronize()
     for a, b in zip(out["hip"], out["ref"]):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("mode", ["key_norms", "vector_norms", "vector_norms_small"])
+def test_select_other_norm_modes_bit_exact(ops, golden_dir, mode):
+    """qp_set_prune_mode: k largest / value rows — kept indices bit-exact vs the reference's golden lists (GV1b)."""
+    from oracle.make_golden import MODE_CASES
+    data = np.load(os.path.join(golden_dir, "gv1b_select_modes.npz"))
+    meta1 = json.load(open(os.path.join(golden_dir, "gv1_select.json")))
+    source, order = O.NORM_PRUNE_MODES[mode]
+    try:
+        ops.set_prune_mode(source, order)
+        for ci in MODE_CASES:
+            if meta1[ci]["norm_rows_differ"]:
+                continue                                      # the canonical norm differs from torch's by 1 ulp on one row there
+            dist, hkv, n, k = SELECT_CASES[ci]
+            rows = make_keys(dist, hkv, n, 1000 + ci)[0].cuda().contiguous()       # [hkv, n, D] scored rows
+            ss = torch.empty(hkv, n, dtype=torch.float32, device="cuda")
+            ops.key_sumsq(rows, n * D, 0, n, hkv, D, ss)
+            idx = torch.empty(k, dtype=torch.int32, device="cuda")
+            ops.select_k_smallest(ss, hkv, n, k, idx)
+            assert np.array_equal(idx.cpu().numpy(), data[f"c{ci}_{mode}"]), (mode, ci)
+            # fused select + gather keeps the same rows
+            kd = torch.zeros(hkv, k, D, dtype=torch.bfloat16, device="cuda"); vd = torch.zeros_like(kd)
+            idx2 = torch.empty(k, dtype=torch.int32, device="cuda")
+            ops.prune_staged(ss, hkv, n, k, rows, rows, n * D, hkv, D, kd, vd, k * D, 0, idx2)
+            assert torch.equal(idx2, idx) and torch.equal(kd, rows[:, idx.long()])
+    finally:
+        ops.set_prune_mode(0, 0)

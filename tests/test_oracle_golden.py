@@ -167,3 +167,25 @@ def test_e2e_composite_oracle(golden_dir, ci):
         assert np.max(np.abs(got - ref)) <= 3e-2, np.max(np.abs(got - ref))
         cos = float(np.dot(got, ref) / (np.linalg.norm(got) * np.linalg.norm(ref)))
         assert cos >= 0.999, cos
+
+
+# ---------------------------------------------------------------- GV1b: the other norm-based predict types
+@pytest.mark.parametrize("mode", ["key_norms", "vector_norms", "vector_norms_small"])
+def test_select_other_norm_modes_match_reference(golden_dir, gv1, mode):
+    """key_norms / vector_norms(_small) (utils.py:117-131): same norms, other end of the order and/or the value rows.
+    Indices from the reference import (stable argsort) must equal the oracle's select on the reference's own norm patterns,
+    and on the oracle's norms wherever the two norm computations agree (GV1 records the rare 1-ulp rows)."""
+    from oracle.make_golden import MODE_CASES
+    data = np.load(os.path.join(golden_dir, "gv1b_select_modes.npz"))
+    _, meta1 = gv1
+    source, order = O.NORM_PRUNE_MODES[mode]
+    sel = O.select_k_largest if order else O.select_k_smallest
+    for ci in MODE_CASES:
+        dist, hkv, n, k = SELECT_CASES[ci]
+        x = make_keys(dist, hkv, n, 1000 + ci)           # the scored rows (keys or values: same recipe)
+        tnorm = O.torch_bf16_to_bits(x[0].transpose(0, 1).flatten(1, 2).norm(2, dim=-1))
+        ref = data[f"c{ci}_{mode}"]
+        assert np.array_equal(sel(tnorm, k), ref), (mode, ci)
+        if meta1[ci]["norm_rows_differ"] == 0:
+            norms = O.key_norms_bf16(O.key_sumsq_heads(O.torch_bf16_to_bits(x[0])))
+            assert np.array_equal(sel(norms, k), ref), (mode, ci)
