@@ -34,7 +34,7 @@ Canonical definitions where the reference is under-specified (SURVEY.md §7 hard
 from __future__ import annotations
 
 import math
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np

@@ -17,12 +17,11 @@ GEMMs go through torch (hipBLASLt); everything else is libquickprefill.so via qu
 """
 from __future__ import annotations
 
-from typing import List, Optional, Sequence
+from typing import List, Optional
 
 import torch
 
 from .lvu_config import LVUConfig, NORM_PRUNE_MODES, effective_k
-from .spec import TextSpec
 from .weights import DecoderWeights
 
 
