@@ -263,60 +263,88 @@ def build_hf_tiny(dtype):
     return model.to(dtype), spec, w
 
 
-def gen_e2e(ref):
+def e2e_case(ref, name, dtn, frames, gh, gw, gs, prefix, tail, top_p, top_k, predict_type="key_norms_small"):
+    """One composite-oracle run: installed HF Qwen2-VL text stack on CPU + the REFERENCE's post_process_kv_cache hooked after every
+    attention.  Returns (final-position logits, per-layer cache lengths, meta)."""
     from transformers import DynamicCache
     U, C = ref["utils"], ref["lvu_config"]
-    out, meta = {}, []
-    for (name, dtn, frames, gh, gw, gs, prefix, tail, top_p, top_k) in E2E_CASES:
-        dtype = getattr(torch, dtn)
-        model, spec, w = build_hf_tiny(dtype)
-        lm = model.model.language_model
-        n_video = (frames // 2) * (gh // 2) * (gw // 2)
-        T = prefix + n_video + tail
-        plan = O.plan_groups(frames, gs, gh, gw, prefix, T)
-        pos, delta = O.mrope_positions(prefix, (frames // 2, gh, gw), tail)
-        rs = np.random.RandomState(4242)
-        embeds = torch.from_numpy(rs.standard_normal((T, spec.hidden)).astype(np.float32) * 0.5).to(dtype)
-        cfg = C.LVUConfig(model_name_or_path="x", top_k=top_k, top_p=top_p)
-        layer_cfgs = [C.LVULayerConfig(layer_idx=i, total_layers=spec.n_layers, lvu_config=cfg) for i in range(spec.n_layers)]
-        cache = DynamicCache(config=model.config.get_text_config())
-        kept_trace = []
+    dtype = getattr(torch, dtn)
+    model, spec, w = build_hf_tiny(dtype)
+    lm = model.model.language_model
+    n_video = (frames // 2) * (gh // 2) * (gw // 2)
+    T = prefix + n_video + tail
+    plan = O.plan_groups(frames, gs, gh, gw, prefix, T)
+    pos, delta = O.mrope_positions(prefix, (frames // 2, gh, gw), tail)
+    rs = np.random.RandomState(4242)
+    embeds = torch.from_numpy(rs.standard_normal((T, spec.hidden)).astype(np.float32) * 0.5).to(dtype)
+    cfg = C.LVUConfig(model_name_or_path="x", top_k=top_k, top_p=top_p, top_k_predict_type=predict_type)
+    layer_cfgs = [C.LVULayerConfig(layer_idx=i, total_layers=spec.n_layers, lvu_config=cfg) for i in range(spec.n_layers)]
+    cache = DynamicCache(config=model.config.get_text_config())
+    kept_trace = []
 
-        def make_hook(i):
-            def hook(mod, args, kwargs, output):
-                hs = kwargs["hidden_states"]
-                lay = cache.layers[i]
-                before = lay.keys.shape[2]
-                with force_stable_argsort():
-                    res = U.post_process_kv_cache(hs, None, None, None, None, None, (lay.keys, lay.values), layer_cfgs[i])
-                lay.keys, lay.values = res[5]
-                kept_trace.append((i, before, lay.keys.shape[2]))
-                return output
-            return hook
-        hooks = [l.self_attn.register_forward_hook(make_hook(i), with_kwargs=True) for i, l in enumerate(lm.layers)]
-        start = 0
-        segs = plan.tokens + [plan.tail_len]
-        post = torch.from_numpy(pos)
-        with torch.no_grad():
-            for gi, n in enumerate(segs):
-                if gi == len(segs) - 1:
-                    cfg.enable = False        # qwen25_lvu.py:737-738: no pruning for the prompt tail
-                pid = post[:, None, start:start + n]
-                past_seen = start
-                o = lm(inputs_embeds=embeds[None, start:start + n], position_ids=pid, past_key_values=cache, use_cache=True,
-                       cache_position=torch.arange(n) + past_seen)
-                start += n
-            logits = model.lm_head(o.last_hidden_state[:, -1]).float()[0]
-        for h in hooks:
-            h.remove()
-        out[f"{name}_logits"] = logits.numpy()
-        out[f"{name}_cache_len"] = np.array([cache.layers[i].keys.shape[2] for i in range(spec.n_layers)], dtype=np.int32)
-        meta.append(dict(name=name, dtype=dtn, frames=frames, grid_h=gh, grid_w=gw, group_size=gs, prefix=prefix, tail=tail,
-                         top_p=top_p, top_k=top_k, group_tokens=plan.tokens, tail_len=plan.tail_len, embed_seed=4242,
-                         weight_seed=7, trace=kept_trace))
-        print(name, plan.tokens, out[f"{name}_cache_len"], float(logits.abs().max()))
+    def make_hook(i):
+        def hook(mod, args, kwargs, output):
+            hs = kwargs["hidden_states"]
+            lay = cache.layers[i]
+            before = lay.keys.shape[2]
+            with force_stable_argsort():
+                res = U.post_process_kv_cache(hs, None, None, None, None, None, (lay.keys, lay.values), layer_cfgs[i])
+            lay.keys, lay.values = res[5]
+            kept_trace.append((i, before, lay.keys.shape[2]))
+            return output
+        return hook
+    hooks = [l.self_attn.register_forward_hook(make_hook(i), with_kwargs=True) for i, l in enumerate(lm.layers)]
+    start = 0
+    segs = plan.tokens + [plan.tail_len]
+    post = torch.from_numpy(pos)
+    with torch.no_grad():
+        for gi, n in enumerate(segs):
+            if gi == len(segs) - 1:
+                cfg.enable = False        # qwen25_lvu.py:737-738: no pruning for the prompt tail
+            pid = post[:, None, start:start + n]
+            past_seen = start
+            o = lm(inputs_embeds=embeds[None, start:start + n], position_ids=pid, past_key_values=cache, use_cache=True,
+                   cache_position=torch.arange(n) + past_seen)
+            start += n
+        logits = model.lm_head(o.last_hidden_state[:, -1]).float()[0]
+    for h in hooks:
+        h.remove()
+    cache_len = np.array([cache.layers[i].keys.shape[2] for i in range(spec.n_layers)], dtype=np.int32)
+    meta = dict(name=name, dtype=dtn, frames=frames, grid_h=gh, grid_w=gw, group_size=gs, prefix=prefix, tail=tail,
+                top_p=top_p, top_k=top_k, group_tokens=plan.tokens, tail_len=plan.tail_len, embed_seed=4242,
+                weight_seed=7, trace=kept_trace)
+    if predict_type != "key_norms_small":
+        meta["predict_type"] = predict_type
+    print(name, plan.tokens, cache_len, float(logits.abs().max()))
+    return logits.numpy(), cache_len, meta
+
+
+def gen_e2e(ref):
+    out, meta = {}, []
+    for case in E2E_CASES:
+        logits, cache_len, m = e2e_case(ref, *case)
+        out[f"{case[0]}_logits"], out[f"{case[0]}_cache_len"] = logits, cache_len
+        meta.append(m)
     np.savez_compressed(os.path.join(OUT, "gv5_e2e.npz"), **out)
     json.dump(meta, open(os.path.join(OUT, "gv5_e2e.json"), "w"), indent=1)
+
+
+E2E_MODE_CASES = [   # GV5b: the other norm-based predict types end to end (same tiny model / inputs as GV5)
+    ("fp32_key_norms", "float32", 8, 4, 6, 4, 5, 7, 0.5, None, "key_norms"),
+    ("fp32_vector_norms", "float32", 12, 8, 4, 2, 15, 9, 0.25, None, "vector_norms"),
+    ("bf16_vector_norms_small", "bfloat16", 8, 4, 6, 4, 5, 7, 0.5, None, "vector_norms_small"),
+    ("bf16_key_norms", "bfloat16", 12, 8, 4, 2, 15, 9, 0.25, None, "key_norms"),
+]
+
+
+def gen_e2e_modes(ref):
+    out, meta = {}, []
+    for case in E2E_MODE_CASES:
+        logits, cache_len, m = e2e_case(ref, *case)
+        out[f"{case[0]}_logits"], out[f"{case[0]}_cache_len"] = logits, cache_len
+        meta.append(m)
+    np.savez_compressed(os.path.join(OUT, "gv5b_e2e_modes.npz"), **out)
+    json.dump(meta, open(os.path.join(OUT, "gv5b_e2e_modes.json"), "w"), indent=1)
 
 
 def gen_rope_index():
@@ -340,10 +368,11 @@ def gen_rope_index():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     ref = load_reference()
-    which = sys.argv[1:] or ["select", "modes", "effk", "compact", "e2e", "rope"]
+    which = sys.argv[1:] or ["select", "modes", "effk", "compact", "e2e", "e2e_modes", "rope"]
     if "select" in which: gen_select(ref)
     if "modes" in which: gen_select_modes(ref)
     if "effk" in which: gen_effective_k(ref)
     if "compact" in which: gen_compaction(ref)
     if "e2e" in which: gen_e2e(ref)
+    if "e2e_modes" in which: gen_e2e_modes(ref)
     if "rope" in which: gen_rope_index()

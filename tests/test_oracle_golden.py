@@ -189,3 +189,32 @@ def test_select_other_norm_modes_match_reference(golden_dir, gv1, mode):
         if meta1[ci]["norm_rows_differ"] == 0:
             norms = O.key_norms_bf16(O.key_sumsq_heads(O.torch_bf16_to_bits(x[0])))
             assert np.array_equal(sel(norms, k), ref), (mode, ci)
+
+
+@pytest.mark.parametrize("ci", range(4))
+def test_e2e_composite_oracle_other_norm_modes(golden_dir, ci):
+    """GV5b: the oracle's key_norms / vector_norms(_small) paths end to end against transformers-5.15 Qwen2-VL + the reference's
+    post_process_kv_cache run with that top_k_predict_type (fp32: logits to 2e-5, i.e. the same rows were kept at every layer)."""
+    from oracle.make_golden import E2E_MODE_CASES
+    data = np.load(os.path.join(golden_dir, "gv5b_e2e_modes.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "gv5b_e2e_modes.json")))[ci]
+    name, dtn, frames, gh, gw, gs, prefix, tail, top_p, top_k, mode = E2E_MODE_CASES[ci]
+    assert meta["name"] == name and meta["predict_type"] == mode
+    dtype = getattr(torch, dtn)
+    spec = O.TextSpec(**TINY)
+    w = {k: v.to(dtype) for k, v in O.synthetic_text_weights(spec, seed=meta["weight_seed"], norm_jitter=0.1).items()}
+    T = prefix + (frames // 2) * (gh // 2) * (gw // 2) + tail
+    plan = O.plan_groups(frames, gs, gh, gw, prefix, T)
+    pos, _ = O.mrope_positions(prefix, (frames // 2, gh, gw), tail)
+    rs = np.random.RandomState(meta["embed_seed"])
+    embeds = torch.from_numpy(rs.standard_normal((T, spec.hidden)).astype(np.float32) * 0.5).to(dtype)
+    out = O.group_prefill(w, spec, embeds, pos, plan.tokens, O.PruneCfg(top_k=top_k, top_p=top_p, top_k_predict_type=mode))
+    assert out["cache_len"] == list(data[f"{name}_cache_len"])
+    got, ref = out["logits"].numpy(), data[f"{name}_logits"]
+    if dtype == torch.float32:
+        assert np.max(np.abs(got - ref)) <= 2e-5, np.max(np.abs(got - ref))
+    else:
+        assert np.max(np.abs(got - ref)) <= 3e-2, np.max(np.abs(got - ref))
+        assert float(np.dot(got, ref) / (np.linalg.norm(got) * np.linalg.norm(ref))) >= 0.999
+    base = O.group_prefill(w, spec, embeds, pos, plan.tokens, O.PruneCfg(top_k=top_k, top_p=top_p))
+    assert np.max(np.abs(base["logits"].numpy() - ref)) > 1e-3          # the mode matters: default scoring gives other logits
