@@ -30,6 +30,8 @@ for (n, P, hq, hkv) in shapes:
     q = torch.randn(n, hq, D, generator=g, device="cuda").to(torch.bfloat16)
     k = torch.randn(hkv, P + n, D, generator=g, device="cuda").to(torch.bfloat16)
     v = torch.randn(hkv, P + n, D, generator=g, device="cuda").to(torch.bfloat16)
+    if os.environ.get("QP_ZERO") == "1":          # power probe: all-zero operands toggle far fewer bits (clock limited by power, not by the schedule)
+        q.zero_(); k.zero_(); v.zero_()
     out = torch.empty(n, hq, D, dtype=torch.bfloat16, device="cuda")
     fl = 4 * hq * D * (n * P + n * (n + 1) / 2)
     # reference: torch SDPA with an explicit bottom-right causal mask (fp32 math on a slice to bound memory)
