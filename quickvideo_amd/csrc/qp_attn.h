@@ -52,3 +52,5 @@ __device__ __forceinline__ float xhalf_sum(float x) {
 
 // qp_attn_s6.hip
 void qp_launch_attn_s6(const qpattn::AttnParams& p, bool xcd, unsigned per_kvh, hipStream_t s);   // p.qb_rows selects 4 or 8 waves
+// qp_attn_s7.hip (256-row items, 4 waves x 64 rows, one wave per SIMD)
+void qp_launch_attn_s7(const qpattn::AttnParams& p, bool xcd, unsigned per_kvh, hipStream_t s);

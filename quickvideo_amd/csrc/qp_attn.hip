@@ -575,7 +575,7 @@ int qp_launch_prefill_attn(const qp_ctx* ctx, const void* q, const void* k_prefi
   AttnPlan a;
   if (variant == 4) a = plan_cached(nq, prefix_len + q_row0, hq, hkv, ctx->cus, split_mode, 3, 128);
   else if (variant == 7) a = plan_cached(nq, prefix_len + q_row0, hq, hkv, ctx->cus, split_mode, 2, 128);
-  else if (variant == 8 || variant == 9) a = plan_cached(nq, prefix_len + q_row0, hq, hkv, ctx->cus, split_mode, 1, 256);
+  else if (variant == 8 || variant == 9 || variant == 10) a = plan_cached(nq, prefix_len + q_row0, hq, hkv, ctx->cus, split_mode, 1, 256);
   else {
     a = plan_cached(nq, prefix_len + q_row0, hq, hkv, ctx->cus, split_mode, 2, 128);
     const AttnPlan b = plan_cached(nq, prefix_len + q_row0, hq, hkv, ctx->cus, split_mode, 1, 256);
@@ -590,7 +590,9 @@ int qp_launch_prefill_attn(const qp_ctx* ctx, const void* q, const void* k_prefi
   }
   const int per_kvh = a.n_whole + (a.items - a.n_whole) * a.nsplit;
   const bool xcd = (hkv <= 8 && 8 % hkv == 0 && variant != 3);
-  if (variant != 4) {                                    // production: software-pipelined kernel (qp_attn_s6.hip); 4: s4
+  if (variant == 10) {                                   // experiment: one wave per SIMD, 64 rows per wave (qp_attn_s7.hip)
+    qp_launch_attn_s7(p, xcd, (unsigned)per_kvh, s);
+  } else if (variant != 4) {                             // production: software-pipelined kernel (qp_attn_s6.hip); 4: s4
     qp_launch_attn_s6(p, xcd, (unsigned)per_kvh, s);
   } else if (xcd) {
     const int G = 8 / hkv;

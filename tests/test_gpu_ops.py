@@ -427,10 +427,10 @@ def test_prefill_attn_query_subranges(ops, n, P, hq, hkv, parts):
         ops.prefill_attn(q[:10].contiguous(), k, v, (P + n) * D, P, k[:, P:], v[:, P:], (P + n) * D, n, hq, hkv, D, 1.0, full, q_row0=n - 5, nq=10)
 
 
-@pytest.mark.parametrize("variant", ["4", "7", "8", "2", "3", "9"])
+@pytest.mark.parametrize("variant", ["4", "7", "8", "2", "3", "9", "10"])
 def test_prefill_attn_every_kernel_form(ops, variant, monkeypatch):
     """The launch picks a kernel form per shape (s6 with 4- or 8-wave workgroups, planner-chosen kv-split); force each form
-    (QP_ATTN_VARIANT: 4 = s4, 7 / 8 = s6 4- / 8-wave, 2 = no kv split, 3 = plain 2-D grid, 9 = staggered 8-wave experiment) over ragged sizes, prefix lengths around the tile size,
+    (QP_ATTN_VARIANT: 4 = s4, 7 / 8 = s6 4- / 8-wave, 2 = no kv split, 3 = plain 2-D grid, 9 = staggered 8-wave experiment, 10 = s7: one wave per SIMD with asm-owned AGPR accumulators) over ragged sizes, prefix lengths around the tile size,
     single-tile and sub-range launches, and the rescale branch."""
     monkeypatch.setenv("QP_ATTN_VARIANT", variant)
     for (n, P, hq, hkv, staged) in [(1, 0, 2, 1, True), (31, 1, 2, 1, False), (64, 63, 4, 2, True), (65, 64, 2, 1, False),
