@@ -222,9 +222,18 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_s7(AttnParams p) {
   const int vdma_off = kVB + (1 - vi) * 16384;                                          \
   const unsigned vrd = voffv + kVB + vi * 16384;
 
+#ifdef QP_S7_TIMING
+  long long tacc[5] = {0, 0, 0, 0, 0}, tlast = __builtin_readcyclecounter();
+#define S7_STAMP(K) { const long long t_ = __builtin_readcyclecounter(); tacc[K] += t_ - tlast; tlast = t_; }
+#else
+#define S7_STAMP(K)
+#endif
 #define S7_STEP_END()                                                                   \
+  S7_STAMP(2);                                                                          \
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                      \
+  S7_STAMP(3);                                                                          \
   __builtin_amdgcn_s_barrier();                                                         \
+  S7_STAMP(4);                                                                          \
   vi = 1 - vi;
 
   int vi = 0;
@@ -234,9 +243,11 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_s7(AttnParams p) {
 #define S7_PART 0
 #include "qp_attn_s7_iter.inc"
 #undef S7_PART
+      S7_STAMP(0);
 #define S7_PART 2
 #include "qp_attn_s7_iter.inc"
 #undef S7_PART
+      S7_STAMP(1);
       if (t + 1 < ti_hi) { S7_UPDATE1(A) S7_UPDATE1(B) }
       S7_STEP_END()
     }
@@ -246,15 +257,22 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_kernel_s7(AttnParams p) {
 #define S7_PART 1
 #include "qp_attn_s7_iter.inc"
 #undef S7_PART
+      S7_STAMP(0);
 #define S7_PART 3
 #include "qp_attn_s7_iter.inc"
 #undef S7_PART
+      S7_STAMP(1);
       if (t + 2 < ti_hi) { S7_UPDATE1(A) S7_UPDATE1(B) }
       S7_STEP_END()
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // no LDS-DMA may outlive the workgroup
   S7_FENCE_O();
+#ifdef QP_S7_TIMING
+  if (blockIdx.x == 8 && lane == 0)
+    printf("wave %d tiles %d: Q part %lld  P part %lld  update %lld  dma-wait %lld  barrier %lld  (clk per step)\n", wave, ti_hi - ti_lo,
+           tacc[0] / (ti_hi - ti_lo), tacc[1] / (ti_hi - ti_lo), tacc[2] / (ti_hi - ti_lo), tacc[3] / (ti_hi - ti_lo), tacc[4] / (ti_hi - ti_lo));
+#endif
 
   // epilogue: q block A is 32-row block 2*wave of the item, B is block 2*wave+1 (same partial layout as the 8-wave s6 form)
 #define S7_STORE(ST, BLK, QI)                                                           \
