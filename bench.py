@@ -107,6 +107,7 @@ def build_workload(name, device, rank, world, seed=0, parallel="sp", layout=None
     eng = QuickPrefillEngine(weights, cfg, capacity=cap, max_group_tokens=max(plan.tokens + [plan.tail_len]), device=device,
                              sp_rank=sp_rank, sp_size=sp_n, pp_rank=stage, pp_size=pp_n,
                              pp_peers=[s * sp_n + sp_rank for s in range(pp_n)] if pp_n > 1 else None)
+    eng.rope_delta = int(delta)                                  # decode positions continue at sequence index + delta
     g = torch.Generator(device=device); g.manual_seed(1234)      # same embeddings on every TP rank
     # synthetic ViT output / text embeddings: N(0, 1) scaled like embedding rows (the ViT front end is bench'd separately)
     embeds = (torch.randn(T, spec.hidden, generator=g, device=device, dtype=torch.float32) * 0.5).to(torch.bfloat16)
@@ -125,6 +126,32 @@ def run_step(eng, plan, embeds, pos):
     if eng.pp_size > 1:                  # layer pipeline: the last stage holds the logits; the token returns to every stage
         torch.distributed.broadcast(tok, src=torch.distributed.get_world_size() - 1)
     return tok                           # first generated token id (stays on device; .item() would be the TTFT point)
+
+
+def decode_leg(eng, first_token: int, n_tokens: int = 32):
+    """Greedy decode after the prefill (a10): ms per token of the captured hipGraph step (quickvideo_amd/decode.py) and the HBM
+    stream it is bounded by (every decoder weight + lm_head once, every cached K/V row once per token)."""
+    from quickvideo_amd.decode import GraphDecoder
+    if not GraphDecoder.supported(eng):
+        return None
+    dec = GraphDecoder(eng)
+    len0, pos0 = list(eng.arena.len), eng.seq_pos
+    n_tokens = min(n_tokens, eng.arena.capacity - max(len0))
+    if n_tokens < 1:
+        return None
+    dec.generate(first_token, min(4, n_tokens), eng.rope_delta)          # capture + warm
+    eng.arena.len, eng.seq_pos = list(len0), pos0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    toks = dec.generate(first_token, n_tokens, eng.rope_delta)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / len(toks) * 1e3
+    eng.arena.len, eng.seq_pos = list(len0), pos0
+    wbytes = sum(t.numel() * 2 for lw in eng.w.layers for t in (lw.w_qkv, lw.w_o, lw.w_gate_up, lw.w_down)) + eng.w.lm_head.numel() * 2
+    kvbytes = sum(2 * eng.hkv * n * eng.D * 2 for n in len0)
+    tbs = (wbytes + kvbytes) / (ms * 1e-3) / 1e12
+    return {"ms_per_token": round(ms, 3), "tokens": len(toks), "mode": "hipGraph replay per token", "hbm_bytes_per_token": wbytes + kvbytes,
+            "achieved_tb_s": round(tbs, 2), "frac_of_hbm_peak": round(tbs / 8.0, 3), "kv_rows_per_layer": len0[0]}
 
 
 def flops_and_bytes(spec, cfg, plan, tp_size):
@@ -229,6 +256,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true")
+    ap.add_argument("--no-decode", action="store_true", help="skip the greedy-decode leg (hipGraph step, ms per token)")
     ap.add_argument("--no-ttft", action="store_true", help="skip the extra step that times prefill -> first token id on the host")
     ap.add_argument("--parallel", default="auto", choices=["auto", "sp", "tp", "pp"],
                     help="N>1: sp = group-token parallel (replicated weights/KV, one K/V all-gather per layer), "
@@ -306,6 +334,10 @@ def main():
         first = int(run_step(eng, plan, embeds, pos).item())
         ttft_ms = (time.perf_counter() - t1) * 1e3
 
+    decode = None
+    if world == 1 and not args.no_decode:
+        decode = decode_leg(eng, first)            # the engine holds the cache of the last step (prefill + tail)
+
     lin, att, prune_bytes = flops_and_bytes(spec, cfg, plan, world)
     roofline = None
     extra = {}
@@ -365,6 +397,7 @@ def main():
                        "vit": "excluded (synthetic ViT-output embeddings resident in HBM)",
                        "weights": "seeded random at real dims"},
             "ttft_ms_prefill_leg": None if ttft_ms is None else round(ttft_ms, 3), "first_token": first,
+            "decode": decode,
             "algorithmic_tflop_per_step": round((lin + att) / 1e12, 2),
             "mfma_frac_whole_step": round((lin + att) / world / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
             "roofline": roofline,

@@ -156,6 +156,36 @@ int qp_add_inplace(qp_ctx* ctx, void* h, const void* delta, int64_t n_elems, voi
 /* gate_up bf16 [n][2*inter] (gate columns then up columns) -> out[n][inter] = bf16(bf16(silu(g)) * u). */
 int qp_swiglu(qp_ctx* ctx, const void* gate_up, int64_t n, int inter, void* out, void* stream);
 
+/* ---- decode step over the pruned cache (qwen25_lvu.py:744-761: HF generate with the LVU cache) -------------------
+ * Every per-token scalar lives in a DEVICE state block  state int64[2] = { kv_len, rope_pos }  (rows already in every
+ * layer's cache; position id of the token being decoded, the same on all three M-RoPE streams), so a whole decode step has
+ * no host arguments that change between tokens: capture it once in a hipGraph and replay it per token.              */
+/* out[n_out] = epilogue(W[n_out][k] . x[k]) for ONE token (batch 1): the weight stream of the step, HBM-bound.
+ * W bf16 row-major [n_out][k] (a torch Linear weight), k % 8 == 0, k <= 24576.  If norm_w != NULL, x is the residual
+ * stream h and the kernel applies RMSNorm first (x = norm_w * bf16(h * rsqrt(mean(h^2) + eps)), same arithmetic as
+ * qp_add_rmsnorm).  mode QP_GEMV_BIAS: out = bf16(dot + bias) (bias may be NULL);  QP_GEMV_SWIGLU: W is [2*n_out][k]
+ * (gate rows then up rows), out = bf16(bf16(silu(bf16(g))) * bf16(u)) = qp_swiglu of the two projections;
+ * QP_GEMV_RESIDUAL: out = bf16(out + bf16(dot)) in place (the residual add of the layer). */
+enum { QP_GEMV_BIAS = 0, QP_GEMV_SWIGLU = 1, QP_GEMV_RESIDUAL = 2 };
+int qp_gemv(qp_ctx* ctx, const void* w, const void* x, const void* norm_w, float eps, const void* bias, void* out,
+            int64_t n_out, int64_t k, int mode, void* stream);
+/* M-RoPE of the token's q and k and append of its K/V at row state[0] of the cache.  cos/sin: the bf16 [64] table of the
+ * token's position from qp_mrope_table (computed once per token, shared by all layers; its `pos` argument is a device
+ * pointer, so it replays too), or both NULL: computed in the kernel with the same arithmetic at position state[1].
+ * qkv bf16 [(n_q+2*n_kv)*128]; q_out bf16 [n_q][128]. */
+int qp_decode_rope_append(qp_ctx* ctx, const void* qkv, const int64_t* state, const void* cos, const void* sin, float theta,
+                          int n_q_heads, int n_kv_heads, int head_dim, void* q_out, void* k_cache, void* v_cache,
+                          int64_t head_stride, void* stream);
+/* Single-query attention over cache rows [0, state[0]] (the token's own row included), GQA native (n_q/n_kv in
+ * {1,2,4,6,7,8}); fixed grid independent of the cache length.  out bf16 [n_q][128]. */
+size_t qp_decode_attn_workspace_bytes(const qp_ctx* ctx, int n_q_heads, int n_kv_heads);
+int qp_decode_attn(qp_ctx* ctx, const void* q, const void* k_cache, const void* v_cache, int64_t head_stride,
+                   const int64_t* state, int n_q_heads, int n_kv_heads, int head_dim, float scale, void* out,
+                   void* workspace, size_t workspace_bytes, void* stream);
+/* state[i] += 1 for i < n_values (end of the step; the state blocks of all layers are one array: layers may hold
+ * different numbers of rows under the decaying keep ratios, utils.py:231-251). */
+int qp_decode_advance(qp_ctx* ctx, int64_t* state, int64_t n_values, void* stream);
+
 /* ---- vision front end (transformers Qwen2VisionTransformerPretrainedModel [3P]) ---------------
  * The ViT tower itself runs on PyTorch-ROCm (quickvideo_amd/vit.py); these three entry points replace its non-GEMM ops.
  * qkv bf16 [n][3][heads][head_dim] = output of the fused qkv projection of one block (n = n_seq * S tokens).        */

@@ -296,4 +296,58 @@ int qp_quick_gelu(qp_ctx* ctx, const void* x, void* out, int64_t n_elems, void* 
   return qp_launch_quick_gelu(x, out, n_elems, (hipStream_t)stream);
 }
 
+// ---- decode step (qp_decode.hip) ------------------------------------------------------------------------------------
+int qp_gemv(qp_ctx* ctx, const void* w, const void* x, const void* norm_w, float eps, const void* bias, void* out,
+            int64_t n_out, int64_t k, int mode, void* stream) {
+  QP_REQUIRE(ctx && w && x && out, QP_ERR_INVALID, "qp_gemv: NULL argument");
+  QP_REQUIRE(mode >= QP_GEMV_BIAS && mode <= QP_GEMV_RESIDUAL, QP_ERR_INVALID, "qp_gemv: unknown mode %d", mode);
+  QP_REQUIRE(n_out > 0 && n_out < (1ll << 30) && k > 0 && k % 8 == 0 && k <= 24576, QP_ERR_INVALID,
+             "qp_gemv: n_out=%lld, k=%lld (k must be a multiple of 8, at most 24576)", (long long)n_out, (long long)k);
+  QP_REQUIRE(mode == QP_GEMV_BIAS || bias == nullptr, QP_ERR_INVALID, "qp_gemv: bias only with QP_GEMV_BIAS");
+  QP_REQUIRE(aligned16(w) && aligned16(x) && (!norm_w || aligned16(norm_w)), QP_ERR_INVALID, "qp_gemv: alignment");
+  return qp_launch_gemv(ctx, w, x, norm_w, eps, bias, out, n_out, k, mode, (hipStream_t)stream);
+}
+
+int qp_decode_rope_append(qp_ctx* ctx, const void* qkv, const int64_t* state, const void* cos, const void* sin, float theta,
+                          int n_q_heads, int n_kv_heads, int head_dim, void* q_out, void* k_cache, void* v_cache,
+                          int64_t head_stride, void* stream) {
+  QP_REQUIRE((cos == nullptr) == (sin == nullptr), QP_ERR_INVALID, "qp_decode_rope_append: cos and sin go together");
+  QP_REQUIRE(!cos || (aligned16(cos) && aligned16(sin)), QP_ERR_INVALID, "qp_decode_rope_append: table alignment");
+  QP_REQUIRE(ctx && qkv && state && q_out && k_cache && v_cache, QP_ERR_INVALID, "qp_decode_rope_append: NULL argument");
+  QP_REQUIRE(head_dim == 128, QP_ERR_UNSUPPORTED, "qp_decode_rope_append: head_dim=%d (only 128)", head_dim);
+  QP_REQUIRE(n_q_heads > 0 && n_kv_heads > 0 && head_stride >= 128 && head_stride % 8 == 0, QP_ERR_INVALID,
+             "qp_decode_rope_append: heads/stride");
+  QP_REQUIRE(aligned16(qkv) && aligned16(q_out) && aligned16(k_cache) && aligned16(v_cache), QP_ERR_INVALID,
+             "qp_decode_rope_append: alignment");
+  return qp_launch_decode_rope(qkv, state, cos, sin, theta, n_q_heads, n_kv_heads, q_out, k_cache, v_cache, head_stride,
+                               (hipStream_t)stream);
+}
+
+size_t qp_decode_attn_workspace_bytes(const qp_ctx* ctx, int n_q_heads, int n_kv_heads) {
+  if (!ctx || n_q_heads <= 0 || n_kv_heads <= 0) return 0;
+  return qp_decode_attn_workspace_bytes_impl(ctx, n_q_heads, n_kv_heads);
+}
+
+int qp_decode_attn(qp_ctx* ctx, const void* q, const void* k_cache, const void* v_cache, int64_t head_stride,
+                   const int64_t* state, int n_q_heads, int n_kv_heads, int head_dim, float scale, void* out,
+                   void* workspace, size_t workspace_bytes, void* stream) {
+  QP_REQUIRE(ctx && q && k_cache && v_cache && state && out && workspace, QP_ERR_INVALID, "qp_decode_attn: NULL argument");
+  QP_REQUIRE(head_dim == 128, QP_ERR_UNSUPPORTED, "qp_decode_attn: head_dim=%d (only 128)", head_dim);
+  QP_REQUIRE(n_q_heads > 0 && n_kv_heads > 0 && n_q_heads % n_kv_heads == 0, QP_ERR_INVALID,
+             "qp_decode_attn: n_q_heads=%d not a multiple of n_kv_heads=%d", n_q_heads, n_kv_heads);
+  QP_REQUIRE(head_stride >= 128 && head_stride % 8 == 0, QP_ERR_INVALID, "qp_decode_attn: head stride");
+  QP_REQUIRE(aligned16(q) && aligned16(k_cache) && aligned16(v_cache) && aligned16(workspace), QP_ERR_INVALID,
+             "qp_decode_attn: alignment");
+  const size_t need = qp_decode_attn_workspace_bytes_impl(ctx, n_q_heads, n_kv_heads);
+  if (workspace_bytes < need) return qp_fail(QP_ERR_WORKSPACE, "qp_decode_attn: workspace %zu < %zu bytes", workspace_bytes, need);
+  return qp_launch_decode_attn(ctx, q, k_cache, v_cache, head_stride, state, n_q_heads, n_kv_heads, scale, out, workspace,
+                               (hipStream_t)stream);
+}
+
+int qp_decode_advance(qp_ctx* ctx, int64_t* state, int64_t n_values, void* stream) {
+  QP_REQUIRE(ctx && state, QP_ERR_INVALID, "qp_decode_advance: NULL argument");
+  QP_REQUIRE(n_values > 0 && n_values <= (1 << 20), QP_ERR_INVALID, "qp_decode_advance: n_values=%lld", (long long)n_values);
+  return qp_launch_decode_advance(state, (int)n_values, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -56,6 +56,11 @@ SIGNATURES = {
     "qp_add_rmsnorm": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
     "qp_add_inplace": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "qp_swiglu": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp]),
+    "qp_gemv": (_i32, [_vp, _vp, _vp, _vp, _f32, _vp, _vp, _i64, _i64, _i32, _vp]),
+    "qp_decode_rope_append": (_i32, [_vp, _vp, _vp, _vp, _vp, _f32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _vp]),
+    "qp_decode_attn_workspace_bytes": (_sz, [_vp, _i32, _i32]),
+    "qp_decode_attn": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _sz, _vp]),
+    "qp_decode_advance": (_i32, [_vp, _vp, _i64, _vp]),
     "qp_vit_rope": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "qp_vit_attn": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _f32, _vp, _vp]),
     "qp_quick_gelu": (_i32, [_vp, _vp, _vp, _i64, _vp]),
@@ -203,6 +208,33 @@ class QuickPrefillOps:
     def swiglu(self, gate_up, out):
         n, two_i = gate_up.shape
         self._check(self.lib.qp_swiglu(self.ctx, gate_up.data_ptr(), n, two_i // 2, out.data_ptr(), self._stream()))
+
+    # -- decode step (device-resident state int64[2] = {kv_len, rope_pos}; graph-capturable)
+    GEMV_BIAS, GEMV_SWIGLU, GEMV_RESIDUAL = 0, 1, 2
+
+    def gemv(self, w, x, out, mode=0, bias=None, norm_w=None, eps=0.0):
+        """out[n_out] = epilogue(w[n_out(*2 for SwiGLU)][k] . x[k]); x = RMSNorm(x) * norm_w first when norm_w is given."""
+        k = w.shape[1]
+        n_out = w.shape[0] // 2 if mode == self.GEMV_SWIGLU else w.shape[0]
+        assert w.is_contiguous() and x.numel() == k and out.numel() == n_out
+        self._check(self.lib.qp_gemv(self.ctx, w.data_ptr(), x.data_ptr(), _ptr(norm_w), float(eps), _ptr(bias), out.data_ptr(),
+                                     n_out, k, mode, self._stream()))
+
+    def decode_rope_append(self, qkv, state, theta, n_q, n_kv, D, q_out, k_cache, v_cache, head_stride, cos=None, sin=None):
+        self._check(self.lib.qp_decode_rope_append(self.ctx, qkv.data_ptr(), state.data_ptr(), _ptr(cos), _ptr(sin), float(theta), n_q, n_kv, D,
+                                                   q_out.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), head_stride, self._stream()))
+
+    def decode_attn_workspace(self, n_q, n_kv):
+        nbytes = int(self.lib.qp_decode_attn_workspace_bytes(self.ctx, n_q, n_kv))
+        return torch.empty(nbytes // 4, dtype=torch.float32, device=self.device)
+
+    def decode_attn(self, q, k_cache, v_cache, head_stride, state, n_q, n_kv, D, scale, out, workspace):
+        self._check(self.lib.qp_decode_attn(self.ctx, q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), head_stride, state.data_ptr(),
+                                            n_q, n_kv, D, float(scale), out.data_ptr(), workspace.data_ptr(), workspace.numel() * 4,
+                                            self._stream()))
+
+    def decode_advance(self, state):
+        self._check(self.lib.qp_decode_advance(self.ctx, state.data_ptr(), state.numel(), self._stream()))
 
     # -- vision front end
     def vit_rope(self, qkv, cos, sin, heads, head_dim):

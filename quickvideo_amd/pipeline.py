@@ -20,6 +20,7 @@ import torch
 
 from . import planner
 from .engine import QuickPrefillEngine
+from .decode import GraphDecoder
 from .frames import open_video, smart_nframes
 from .lvu_config import LVUConfig, effective_k
 from .spec import TextSpec
@@ -222,12 +223,17 @@ class PrefillPipeline:
         tok = int(torch.argmax(logits).item())                                # first token on the host = TTFT point
         tm.ttft = time.perf_counter() - t_e2e
         out = [tok]
-        for _ in range(max_new_tokens - 1):
-            if eos_token_id is not None and tok == eos_token_id:
-                break
-            logits = eng.decode_step(eng.embed_tokens(torch.tensor([tok], device=dev)), P["delta"])
-            tok = int(torch.argmax(logits).item())
-            out.append(tok)
+        if GraphDecoder.supported(eng):                                       # one hipGraph replay per token (decode.py)
+            if getattr(eng, "_graph_decoder", None) is None:
+                eng._graph_decoder = GraphDecoder(eng)
+            out += eng._graph_decoder.generate(tok, max_new_tokens - 1, P["delta"], eos_token_id)
+        else:                                                                 # per-op path (CPU test doubles, parallel engines)
+            for _ in range(max_new_tokens - 1):
+                if eos_token_id is not None and tok == eos_token_id:
+                    break
+                logits = eng.decode_step(eng.embed_tokens(torch.tensor([tok], device=dev)), P["delta"])
+                tok = int(torch.argmax(logits).item())
+                out.append(tok)
         sync()
         tm.decode = time.perf_counter() - t_dec
         tm.e2e = time.perf_counter() - t_e2e
