@@ -263,9 +263,12 @@ def build_hf_tiny(dtype):
     return model.to(dtype), spec, w
 
 
-def e2e_case(ref, name, dtn, frames, gh, gw, gs, prefix, tail, top_p, top_k, predict_type="key_norms_small"):
+def e2e_case(ref, name, dtn, frames, gh, gw, gs, prefix, tail, top_p, top_k, predict_type="key_norms_small", decode_steps=0):
     """One composite-oracle run: installed HF Qwen2-VL text stack on CPU + the REFERENCE's post_process_kv_cache hooked after every
-    attention.  Returns (final-position logits, per-layer cache lengths, meta)."""
+    attention.  Returns (final-position logits, per-layer cache lengths, meta).
+    decode_steps > 0: continues with that many greedy decode steps over the pruned cache (qwen25_lvu.py:744-761: pruning stays
+    off, positions = sequence index + rope_delta on all three streams) and returns (logits, cache_len, meta, decode_logits
+    [steps, V]); meta["decode_tokens"] = the token FED at each step (first = argmax of the tail logits)."""
     from transformers import DynamicCache
     U, C = ref["utils"], ref["lvu_config"]
     dtype = getattr(torch, dtn)
@@ -307,6 +310,22 @@ def e2e_case(ref, name, dtn, frames, gh, gw, gs, prefix, tail, top_p, top_k, pre
                    cache_position=torch.arange(n) + past_seen)
             start += n
         logits = model.lm_head(o.last_hidden_state[:, -1]).float()[0]
+        dec_tokens, dec_logits = [], []
+        tok = int(torch.argmax(logits))
+        if decode_steps:
+            # the synthetic embedding table has std 0.02 while the synthetic prompt/video rows have std 0.5: bring the decode
+            # tokens' rows to the same scale, otherwise their hidden state is all rounding-sensitive layer output and the bf16
+            # cases compare HF-eager vs flash-style rounding rather than the decode logic (the fp32 case pins the logic either way)
+            lm.embed_tokens.weight.data.mul_(DECODE_EMBED_SCALE)
+        for i in range(decode_steps):
+            dec_tokens.append(tok)
+            emb = lm.embed_tokens(torch.tensor([[tok]]))
+            pid = torch.full((3, 1, 1), T + delta + i, dtype=torch.long)
+            o = lm(inputs_embeds=emb.to(dtype), position_ids=pid, past_key_values=cache, use_cache=True,
+                   cache_position=torch.tensor([T + i]))
+            lg = model.lm_head(o.last_hidden_state[:, -1]).float()[0]
+            dec_logits.append(lg.numpy())
+            tok = int(torch.argmax(lg))
     for h in hooks:
         h.remove()
     cache_len = np.array([cache.layers[i].keys.shape[2] for i in range(spec.n_layers)], dtype=np.int32)
@@ -316,6 +335,9 @@ def e2e_case(ref, name, dtn, frames, gh, gw, gs, prefix, tail, top_p, top_k, pre
     if predict_type != "key_norms_small":
         meta["predict_type"] = predict_type
     print(name, plan.tokens, cache_len, float(logits.abs().max()))
+    if decode_steps:
+        meta["decode_tokens"], meta["rope_delta"], meta["decode_embed_scale"] = dec_tokens, int(delta), DECODE_EMBED_SCALE
+        return logits.numpy(), cache_len, meta, np.stack(dec_logits)
     return logits.numpy(), cache_len, meta
 
 
@@ -347,6 +369,22 @@ def gen_e2e_modes(ref):
     json.dump(meta, open(os.path.join(OUT, "gv5b_e2e_modes.json"), "w"), indent=1)
 
 
+E2E_DECODE_CASES = [E2E_CASES[1], E2E_CASES[4], E2E_CASES[5]]      # fp32_rho05, bf16_rho05, bf16_rho025_g2
+DECODE_STEPS = 4
+DECODE_EMBED_SCALE = 25.0
+
+
+def gen_e2e_decode(ref):
+    """GV7: the composite reference run continued by greedy decode steps (a10)."""
+    out, meta = {}, []
+    for case in E2E_DECODE_CASES:
+        logits, cache_len, m, dec = e2e_case(ref, *case, decode_steps=DECODE_STEPS)
+        out[f"{case[0]}_logits"], out[f"{case[0]}_cache_len"], out[f"{case[0]}_decode_logits"] = logits, cache_len, dec
+        meta.append(m)
+    np.savez_compressed(os.path.join(OUT, "gv7_e2e_decode.npz"), **out)
+    json.dump(meta, open(os.path.join(OUT, "gv7_e2e_decode.json"), "w"), indent=1)
+
+
 def gen_rope_index():
     """GV6: installed transformers' Qwen2-VL get_rope_index (5.15) on grids where it agrees with the
     4.50.0 rule (text after the video resumes at max(position)+1; 5.15 uses max(h,w)//merge, equal
@@ -368,11 +406,12 @@ def gen_rope_index():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     ref = load_reference()
-    which = sys.argv[1:] or ["select", "modes", "effk", "compact", "e2e", "e2e_modes", "rope"]
+    which = sys.argv[1:] or ["select", "modes", "effk", "compact", "e2e", "e2e_modes", "e2e_decode", "rope"]
     if "select" in which: gen_select(ref)
     if "modes" in which: gen_select_modes(ref)
     if "effk" in which: gen_effective_k(ref)
     if "compact" in which: gen_compaction(ref)
     if "e2e" in which: gen_e2e(ref)
     if "e2e_modes" in which: gen_e2e_modes(ref)
+    if "e2e_decode" in which: gen_e2e_decode(ref)
     if "rope" in which: gen_rope_index()

@@ -171,3 +171,28 @@ def test_unknown_predict_type_is_a_value_error():
     spec_o, w, plan, pos, delta, embeds = make_case(12, 8, 4, 4, 9, 6)
     with pytest.raises(ValueError, match="Unknown predict type"):          # lvu/utils.py:189
         run_engine(w, plan, pos, embeds, LVUConfig("x", top_p=0.5, top_k_predict_type="salient_tokens"), OracleOps())
+
+
+@pytest.mark.parametrize("ci", [1, 2])
+def test_engine_decode_vs_reference_golden(golden_dir, ci):
+    """GV7 (the bf16 cases: the engine computes in bf16): the engine (host logic + oracle-backed ops double) decoding the reference's own greedy tokens reproduces the
+    composite reference's per-step logits, next tokens and final cache lengths."""
+    from tests.test_oracle_golden import gv7_case
+    c = gv7_case(golden_dir, ci)
+    dw = DecoderWeights.from_named(TINY, c["w"], "cpu")
+    cfg = LVUConfig("x", top_p=c["top_p"], top_k=c["top_k"], video_group_size=c["gs"])
+    eng = QuickPrefillEngine(dw, cfg, capacity=c["T"] + 8, max_group_tokens=max(c["plan"].tokens + [c["plan"].tail_len]), device="cpu",
+                             ops=OracleOps())
+    post, st = torch.from_numpy(c["pos"]), 0
+    for n in c["plan"].tokens:
+        eng.prefill_group(c["embeds"][st:st + n], post[:, st:st + n]); st += n
+    logits = eng.prefill_tail(c["embeds"][st:], post[:, st:])
+    tol = 3e-2                                            # stated bf16 tolerance of the GV5 / GV7 oracle tests
+    assert np.max(np.abs(logits.numpy() - c["tail_logits"])) <= tol
+    tok = int(torch.argmax(logits))
+    for i, fed in enumerate(c["tokens"]):
+        assert tok == fed
+        lg = eng.decode_step(eng.embed_tokens(torch.tensor([fed])), c["delta"])
+        assert np.max(np.abs(lg.numpy() - c["decode_logits"][i])) <= tol
+        tok = int(torch.argmax(lg))
+    assert eng.arena.len == c["cache_len"]

@@ -244,3 +244,31 @@ def test_graph_decoder_capacity_is_checked():
     assert len(toks) == room
     with pytest.raises(RuntimeError):
         dec.step(0)
+
+
+@pytest.mark.parametrize("ci", [1, 2])
+def test_graph_decode_vs_reference_golden(golden_dir, ci):
+    """GV7 (bf16 cases): prefill + greedy decode on the HIP library against the composite reference run (HF Qwen2-VL + the
+    reference's prune hook): same greedy tokens, per-step logits within the stated bf16 tolerance of test_gpu_engine (4e-2 abs,
+    cosine >= 0.999; |logit| ~ 1), same final cache lengths — for the captured graph and for the eager path."""
+    from quickvideo_amd.spec import TINY
+    from tests.test_gpu_engine import check_logits as check_tiny
+    from tests.test_oracle_golden import gv7_case
+    c = gv7_case(golden_dir, ci)
+    cfg = LVUConfig("x", top_p=c["top_p"], top_k=c["top_k"], video_group_size=c["gs"])
+    for mode in ("graph", "eager"):
+        eng, logits = run_gpu(TINY, c["w"], c["plan"], c["pos"], c["embeds"], cfg)
+        check_tiny(logits.numpy(), c["tail_logits"])
+        tok = int(torch.argmax(logits))
+        dec = GraphDecoder(eng) if mode == "graph" else None
+        if dec:
+            dec.begin(c["delta"])
+        for i, fed in enumerate(c["tokens"]):
+            assert tok == fed, (mode, i)
+            if dec:
+                lg = dec.step(fed).float().cpu()
+            else:
+                lg = eng.decode_step(eng.embed_tokens(torch.tensor([fed], device="cuda")), c["delta"]).cpu()
+            check_tiny(lg.numpy(), c["decode_logits"][i])
+            tok = int(torch.argmax(lg))
+        assert eng.arena.len == c["cache_len"]

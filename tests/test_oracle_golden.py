@@ -169,6 +169,53 @@ def test_e2e_composite_oracle(golden_dir, ci):
         assert cos >= 0.999, cos
 
 
+# ---------------------------------------------------------------- GV7: greedy decode after the prompt tail
+def gv7_case(golden_dir, ci):
+    from oracle.make_golden import E2E_DECODE_CASES
+    data = np.load(os.path.join(golden_dir, "gv7_e2e_decode.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "gv7_e2e_decode.json")))[ci]
+    name, dtn, frames, gh, gw, gs, prefix, tail, top_p, top_k = E2E_DECODE_CASES[ci]
+    assert meta["name"] == name
+    dtype = getattr(torch, dtn)
+    spec = O.TextSpec(**TINY)
+    w = {k: v.to(dtype) for k, v in O.synthetic_text_weights(spec, seed=meta["weight_seed"], norm_jitter=0.1).items()}
+    w["embed_tokens.weight"] = (w["embed_tokens.weight"] * meta["decode_embed_scale"]).to(dtype)     # make_golden.e2e_case
+    n_video = (frames // 2) * (gh // 2) * (gw // 2)
+    T = prefix + n_video + tail
+    plan = O.plan_groups(frames, gs, gh, gw, prefix, T)
+    pos, delta = O.mrope_positions(prefix, (frames // 2, gh, gw), tail)
+    assert delta == meta["rope_delta"]
+    rs = np.random.RandomState(meta["embed_seed"])
+    embeds = torch.from_numpy(rs.standard_normal((T, spec.hidden)).astype(np.float32) * 0.5).to(dtype)
+    return dict(name=name, dtype=dtype, spec=spec, w=w, plan=plan, pos=pos, delta=delta, embeds=embeds, T=T, top_p=top_p, top_k=top_k, gs=gs,
+                tokens=meta["decode_tokens"], tail_logits=data[f"{name}_logits"], decode_logits=data[f"{name}_decode_logits"],
+                cache_len=list(data[f"{name}_cache_len"]))
+
+
+@pytest.mark.parametrize("ci", range(3))
+def test_e2e_decode_composite_oracle(golden_dir, ci):
+    """a10: the reference run (HF Qwen2-VL + the reference's prune hook) continued by greedy decode steps over the pruned cache.
+    The oracle states decode as PREFILL of the sequence extended by the fed tokens (no pruning for tail segments): its
+    last-position logits must reproduce every decode step's logits and greedy token."""
+    c = gv7_case(golden_dir, ci)
+    steps = len(c["tokens"])
+    assert int(np.argmax(c["tail_logits"])) == c["tokens"][0]
+    for i in range(steps):
+        ext = torch.cat([c["embeds"], c["w"]["embed_tokens.weight"][torch.tensor(c["tokens"][:i + 1])]], 0)
+        pos_ext = np.concatenate([c["pos"], np.tile(np.arange(c["T"] + c["delta"], c["T"] + c["delta"] + i + 1, dtype=np.int64), (3, 1))], 1)
+        out = O.group_prefill(c["w"], c["spec"], ext, pos_ext, c["plan"].tokens, O.PruneCfg(top_k=c["top_k"], top_p=c["top_p"]))
+        got, ref = out["logits"].numpy(), c["decode_logits"][i]
+        if c["dtype"] == torch.float32:
+            assert np.max(np.abs(got - ref)) <= 2e-5, np.max(np.abs(got - ref))
+        else:
+            assert np.max(np.abs(got - ref)) <= 3e-2, np.max(np.abs(got - ref))
+            assert float(np.dot(got, ref) / (np.linalg.norm(got) * np.linalg.norm(ref))) >= 0.999
+        if i + 1 < steps:
+            assert int(np.argmax(got)) == c["tokens"][i + 1]
+        if i == steps - 1:
+            assert out["cache_len"] == c["cache_len"]
+
+
 # ---------------------------------------------------------------- GV1b: the other norm-based predict types
 @pytest.mark.parametrize("mode", ["key_norms", "vector_norms", "vector_norms_small"])
 def test_select_other_norm_modes_match_reference(golden_dir, gv1, mode):
