@@ -182,6 +182,11 @@ size_t qp_decode_attn_workspace_bytes(const qp_ctx* ctx, int n_q_heads, int n_kv
 int qp_decode_attn(qp_ctx* ctx, const void* q, const void* k_cache, const void* v_cache, int64_t head_stride,
                    const int64_t* state, int n_q_heads, int n_kv_heads, int head_dim, float scale, void* out,
                    void* workspace, size_t workspace_bytes, void* stream);
+/* qp_decode_rope_append + qp_decode_attn in ONE launch (every kernel boundary costs ~4 us of a ~3.4 ms step): qkv is the RAW fused
+ * projection, cos/sin the token's qp_mrope_table; the new K/V row is written to the cache by the workgroup that reads it. */
+int qp_decode_attn_fused(qp_ctx* ctx, const void* qkv, const void* cos, const void* sin, const int64_t* state, void* k_cache,
+                         void* v_cache, int64_t head_stride, int n_q_heads, int n_kv_heads, int head_dim, float scale, void* out,
+                         void* workspace, size_t workspace_bytes, void* stream);
 /* state[i] += 1 for i < n_values (end of the step; the state blocks of all layers are one array: layers may hold
  * different numbers of rows under the decaying keep ratios, utils.py:231-251). */
 int qp_decode_advance(qp_ctx* ctx, int64_t* state, int64_t n_values, void* stream);

@@ -344,6 +344,25 @@ int qp_decode_attn(qp_ctx* ctx, const void* q, const void* k_cache, const void* 
                                (hipStream_t)stream);
 }
 
+int qp_decode_attn_fused(qp_ctx* ctx, const void* qkv, const void* cos, const void* sin, const int64_t* state, void* k_cache,
+                         void* v_cache, int64_t head_stride, int n_q_heads, int n_kv_heads, int head_dim, float scale, void* out,
+                         void* workspace, size_t workspace_bytes, void* stream) {
+  QP_REQUIRE(ctx && qkv && cos && sin && state && k_cache && v_cache && out && workspace, QP_ERR_INVALID,
+             "qp_decode_attn_fused: NULL argument");
+  QP_REQUIRE(head_dim == 128, QP_ERR_UNSUPPORTED, "qp_decode_attn_fused: head_dim=%d (only 128)", head_dim);
+  QP_REQUIRE(n_q_heads > 0 && n_kv_heads > 0 && n_q_heads % n_kv_heads == 0, QP_ERR_INVALID,
+             "qp_decode_attn_fused: n_q_heads=%d not a multiple of n_kv_heads=%d", n_q_heads, n_kv_heads);
+  QP_REQUIRE(n_q_heads / n_kv_heads <= 8, QP_ERR_UNSUPPORTED, "qp_decode_attn_fused: at most 8 query heads per kv head (got %d)",
+             n_q_heads / n_kv_heads);
+  QP_REQUIRE(head_stride >= 128 && head_stride % 8 == 0, QP_ERR_INVALID, "qp_decode_attn_fused: head stride");
+  QP_REQUIRE(aligned16(qkv) && aligned16(cos) && aligned16(sin) && aligned16(k_cache) && aligned16(v_cache) && aligned16(workspace),
+             QP_ERR_INVALID, "qp_decode_attn_fused: alignment");
+  const size_t need = qp_decode_attn_workspace_bytes_impl(ctx, n_q_heads, n_kv_heads);
+  if (workspace_bytes < need) return qp_fail(QP_ERR_WORKSPACE, "qp_decode_attn_fused: workspace %zu < %zu bytes", workspace_bytes, need);
+  return qp_launch_decode_attn_fused(ctx, qkv, cos, sin, k_cache, v_cache, head_stride, state, n_q_heads, n_kv_heads, scale, out,
+                                     workspace, (hipStream_t)stream);
+}
+
 int qp_decode_advance(qp_ctx* ctx, int64_t* state, int64_t n_values, void* stream) {
   QP_REQUIRE(ctx && state, QP_ERR_INVALID, "qp_decode_advance: NULL argument");
   QP_REQUIRE(n_values > 0 && n_values <= (1 << 20), QP_ERR_INVALID, "qp_decode_advance: n_values=%lld", (long long)n_values);

@@ -77,4 +77,7 @@ int qp_launch_decode_rope(const void* qkv, const int64_t* state, const void* cos
 size_t qp_decode_attn_workspace_bytes_impl(const qp_ctx* ctx, int hq, int hkv);
 int qp_launch_decode_attn(const qp_ctx* ctx, const void* q, const void* k_cache, const void* v_cache, int64_t head_stride,
                           const int64_t* state, int hq, int hkv, float scale, void* out, void* workspace, hipStream_t s);
+int qp_launch_decode_attn_fused(const qp_ctx* ctx, const void* qkv, const void* cos_t, const void* sin_t, void* k_cache, void* v_cache,
+                                int64_t head_stride, const int64_t* state, int hq, int hkv, float scale, void* out, void* workspace,
+                                hipStream_t s);
 int qp_launch_decode_advance(int64_t* state, int n, hipStream_t s);

@@ -14,9 +14,15 @@
 //                        once for the whole q-head group; partial (m, l, o) per split, merged by decode_combine_kernel.
 //   decode_advance_kernel  state += 1 (the per-layer state blocks of a model are one array).
 #include <cstdlib>
-#include "qp_common.h"
+#include "qp_attn.h"
 
 namespace {
+
+using qpattn::lds_read_b128;
+using qpattn::lds_read_tr16;
+using qpattn::s16x8_t;
+using qpattn::xhalf_max;
+using qpattn::xhalf_sum;
 
 __device__ __forceinline__ float dot8(uint4 w, uint4 x, float acc) {
   const unsigned ww[4] = {w.x, w.y, w.z, w.w}, xw[4] = {x.x, x.y, x.z, x.w};
@@ -340,6 +346,186 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const uint4* __restric
   }
 }
 
+// MFMA form of the single-query attention (same partial format and combine kernel as decode_attn_kernel): the G query heads
+// of a kv head are the first G of the 32 "query columns" of v_mfma_f32_32x32x16_bf16 (the rest are zero: the matrix pipe has
+// 20x the throughput this needs, what matters is that one K/V row costs no VALU work).  Every WAVE walks its own 32-key tiles:
+// coalesced 16-B global loads -> the K / V LDS images of the prefill kernels (K row-major with XOR-swizzled 16-B slots, V as
+// [key/4][d/32][key%4][32] for ds_read_b64_tr_b16) in a wave-private 16 KB region (no workgroup barrier in the loop) ->
+// S^T = K.Q^T, online softmax with the lane owning one head, O^T += V^T.P exactly like attn_fwd_kernel_s4.
+//
+// kFused: the kernel also does the M-RoPE + KV append of the token (one launch less per layer).  `q` is then the RAW fused
+// projection [(hq + 2 hkv)][128]; every workgroup rotates the G query heads of its kv head into an LDS tile (the arithmetic
+// of decode_rope_kernel with the per-token cos/sin table), and the workgroup whose key range holds row state[0] rotates and
+// stores the new K row and copies the V row into the cache before anyone reads it (workgroup-scope fence + barrier; no
+// other workgroup touches that row).
+template <bool kFused>
+__global__ __launch_bounds__(256, 2) void decode_attn_mfma_kernel(const uint4* __restrict__ q, const uint4* __restrict__ cos_t,
+                                                                  const uint4* __restrict__ sin_t, uint4* k_cache, uint4* v_cache,
+                                                                  int64_t hs16, const int64_t* __restrict__ state, int hq, int hkv,
+                                                                  float c, float* __restrict__ ws) {
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[4 * 16384];
+  __shared__ float lds_m[32], lds_l[32], lds_M[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5, l31 = lane & 31;
+  const int split = blockIdx.x, nsplit = gridDim.x, kvh = blockIdx.y, G = hq / hkv;
+  const int64_t row_new = state[0];
+  const int64_t L = row_new + 1;                               // the token's own K/V row counts (appended here or by the caller)
+  int64_t chunk = (L + nsplit - 1) / nsplit;
+  chunk = (chunk + 31) & ~(int64_t)31;
+  const int64_t k0 = (int64_t)split * chunk;
+  int64_t k1 = k0 + chunk;
+  if (k1 > L) k1 = L;
+  unsigned char* kl = lds + wave * 16384;
+  unsigned char* vl = kl + 8192;
+  bf16x8_t qf[8];
+  if (kFused) {
+    // 16 lanes per head row: rows 0..G-1 = the query heads, row 8 = the key head, row 9 = the value head of this kv head
+    const int r = tid >> 4, cc = tid & 15;
+    const bool is_q = r < G, is_k = r == 8, is_v = r == 9;
+    const int src = is_q ? kvh * G + r : (is_k ? hq + kvh : hq + hkv + kvh);
+    uint4 x = make_uint4(0, 0, 0, 0);
+    if (is_q || is_k || is_v) x = q[src * 16 + cc];
+    const uint4 ct = cos_t[cc & 7], st = sin_t[cc & 7];
+    uint4 pr;
+    pr.x = __shfl_xor((int)x.x, 8, 16); pr.y = __shfl_xor((int)x.y, 8, 16);
+    pr.z = __shfl_xor((int)x.z, 8, 16); pr.w = __shfl_xor((int)x.w, 8, 16);
+    const float sign = (cc < 8) ? -1.f : 1.f;
+    const unsigned xw[4] = {x.x, x.y, x.z, x.w}, pw[4] = {pr.x, pr.y, pr.z, pr.w}, cw[4] = {ct.x, ct.y, ct.z, ct.w},
+                   sw[4] = {st.x, st.y, st.z, st.w};
+    unsigned short o8[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int w = e >> 1, sh = (e & 1) * 16;
+      const float xv = bf16_bits_to_f32((unsigned short)(xw[w] >> sh)), pv = bf16_bits_to_f32((unsigned short)(pw[w] >> sh));
+      const float cv = bf16_bits_to_f32((unsigned short)(cw[w] >> sh)), sv = bf16_bits_to_f32((unsigned short)(sw[w] >> sh));
+      o8[e] = f32_to_bf16_bits(round_bf16(xv * cv) + round_bf16((sign * pv) * sv));
+    }
+    uint4 rot;
+    rot.x = o8[0] | ((unsigned)o8[1] << 16); rot.y = o8[2] | ((unsigned)o8[3] << 16);
+    rot.z = o8[4] | ((unsigned)o8[5] << 16); rot.w = o8[6] | ((unsigned)o8[7] << 16);
+    uint4* qt = reinterpret_cast<uint4*>(lds);                 // query tile [32 rows][16 x 16 B], rows >= G zero
+    qt[r * 16 + cc] = is_q ? rot : make_uint4(0, 0, 0, 0);
+    qt[(16 + r) * 16 + cc] = make_uint4(0, 0, 0, 0);
+    if (row_new >= k0 && row_new < k1) {                       // this workgroup owns the new row (workgroup-uniform)
+      if (is_k) k_cache[(int64_t)kvh * hs16 + row_new * 16 + cc] = rot;
+      if (is_v) v_cache[(int64_t)kvh * hs16 + row_new * 16 + cc] = x;
+      __threadfence_block();
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) qf[kk] = lds_read_b128(lds, l31 * 256 + (kk * 2 + hi) * 16);
+    __syncthreads();                                           // the tile regions alias the query tile
+  } else {
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      uint4 x = make_uint4(0, 0, 0, 0);
+      if (l31 < G) x = q[(kvh * G + l31) * 16 + kk * 2 + hi];
+      qf[kk] = __builtin_bit_cast(bf16x8_t, x);
+    }
+  }
+  const int r4 = lane >> 4, slot16 = lane & 15;
+  int koff[8];
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) koff[kk] = l31 * 256 + (((kk * 2 + hi) ^ (l31 & 15)) << 4);
+  const int voff = (((lane & 15) >> 2) << 6) + (((lane >> 4) & 1) << 5) + ((lane & 3) << 3) + (hi << 10);
+  f32x16_t o[4];
+#pragma unroll
+  for (int db = 0; db < 4; ++db) o[db] = (f32x16_t){0};
+  float m_run = -1e30f, l_run = 0.f;
+  const uint4* kb = k_cache + (int64_t)kvh * hs16;
+  const uint4* vb = v_cache + (int64_t)kvh * hs16;
+  for (int64_t t0 = k0 + wave * 32; t0 < k1; t0 += 128) {
+    uint4 kx[8], vx[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int64_t key = t0 + r4 + 4 * it;
+      kx[it] = vx[it] = make_uint4(0, 0, 0, 0);
+      if (key < k1) { kx[it] = kb[key * 16 + slot16]; vx[it] = vb[key * 16 + slot16]; }
+    }
+    __builtin_amdgcn_wave_barrier();                           // the previous tile's fragment reads stay ahead of these writes
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int row = r4 + 4 * it;
+      *reinterpret_cast<uint4*>(kl + row * 256 + ((slot16 ^ (row & 15)) << 4)) = kx[it];
+      *reinterpret_cast<uint4*>(vl + (((row >> 2) * 4 + (slot16 >> 2)) << 8) + ((row & 3) << 6) + ((slot16 & 3) << 4)) = vx[it];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    f32x16_t s = (f32x16_t){0};
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lds_read_b128(kl, koff[kk]), qf[kk], s, 0, 0, 0);
+    if (t0 + 32 > k1) {                                        // ragged last tile (wave-uniform)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t jk = t0 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+        s[r] = jk < k1 ? s[r] : -INFINITY;
+      }
+    }
+    float mx = s[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, s[r]);
+    mx = xhalf_max(mx);
+    if (!__all((mx - m_run) * c <= 8.0f)) {                    // deferred reference switch, as in the prefill kernels
+      const float m_new = fmaxf(m_run, mx);
+      const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int db = 0; db < 4; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+    }
+    const float mc = m_run * c;
+    float rs = 0.f;
+    bf16x8_t pf[2];
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float pe = __builtin_amdgcn_exp2f(__builtin_fmaf(s[cc * 8 + e], c, -mc));
+        rs += pe;
+        pf[cc][e] = (__bf16)pe;
+      }
+    l_run += xhalf_sum(rs);
+#pragma unroll
+    for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+        const int off = voff + (((cc * 4) * 4 + db) << 8);     // 4-key row group kq = cc*4 + hi (+2 for the second half)
+        const s16x4_t v0 = lds_read_tr16(vl, off);
+        const s16x4_t v1 = lds_read_tr16(vl, off + (2 * 4 << 8));
+        const s16x8_t av = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, av), pf[cc], o[db], 0, 0, 0);
+      }
+  }
+  // merge the four waves: one reference per head, rescaled results summed through LDS (the tile regions are free now)
+  if (l31 < G && hi == 0) lds_m[wave * 8 + l31] = m_run;
+  __syncthreads();
+  float* obuf = reinterpret_cast<float*>(lds);                 // [wave][8 heads][128]
+  if (l31 < G) {
+    const float M = fmaxf(fmaxf(lds_m[l31], lds_m[8 + l31]), fmaxf(lds_m[16 + l31], lds_m[24 + l31]));
+    const float a = __builtin_amdgcn_exp2f((m_run - M) * c);
+    if (hi == 0) { lds_l[wave * 8 + l31] = l_run * a; if (wave == 0) lds_M[l31] = M; }
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4)                           // d = db*32 + 8*q4 + 4*hi + j
+        *reinterpret_cast<float4*>(obuf + (wave * 8 + l31) * 128 + db * 32 + 8 * q4 + 4 * hi) =
+            make_float4(o[db][q4 * 4 + 0] * a, o[db][q4 * 4 + 1] * a, o[db][q4 * 4 + 2] * a, o[db][q4 * 4 + 3] * a);
+  }
+  __syncthreads();
+  for (int oi = tid; oi < G * 128; oi += 256) {
+    const int h = oi >> 7, d = oi & 127;
+    const float ot = (obuf[h * 128 + d] + obuf[(8 + h) * 128 + d]) + (obuf[(16 + h) * 128 + d] + obuf[(24 + h) * 128 + d]);
+    ws[((int64_t)(kvh * G + h) * nsplit + split) * kDecPartial + 2 + d] = ot;
+  }
+  if (tid < G) {
+    float* dst = ws + ((int64_t)(kvh * G + tid) * nsplit + split) * kDecPartial;
+    dst[0] = lds_M[tid];
+    dst[1] = (lds_l[tid] + lds_l[8 + tid]) + (lds_l[16 + tid] + lds_l[24 + tid]);
+  }
+}
+
 // grid hq, 256 threads: out[h][d] = sum_s o_s[d] 2^((m_s - M) c) / sum_s l_s 2^((m_s - M) c), rounded to bf16.
 // The split weights are computed once (thread s), then the two halves of the block sum the even / odd splits of dim d.
 __global__ __launch_bounds__(256) void decode_combine_kernel(const float* __restrict__ ws, int nsplit, float c_log2,
@@ -435,6 +621,15 @@ int qp_launch_decode_attn(const qp_ctx* ctx, const void* q, const void* k_cache,
   const dim3 grid((unsigned)ns, (unsigned)hkv);
   const uint4* Q = (const uint4*)q; const uint4* K = (const uint4*)k_cache; const uint4* V = (const uint4*)v_cache;
   float* ws = (float*)workspace;
+  static const bool use_valu = [] { const char* e = getenv("QP_DECODE_ATTN"); return e && e[0] == 'v'; }();   // developer A/B switch
+  if (!use_valu && G <= 8) {
+    decode_attn_mfma_kernel<false><<<grid, 256, 0, s>>>(Q, nullptr, nullptr, (uint4*)k_cache, (uint4*)v_cache, head_stride / 8, state,
+                                                        hq, hkv, c_log2, ws);
+    int rc = qp_check_launch("decode_attn");
+    if (rc) return rc;
+    decode_combine_kernel<<<hq, 256, 0, s>>>(ws, ns, c_log2, (uint16_t*)out);
+    return qp_check_launch("decode_attn(combine)");
+  }
   switch (G) {
     case 1: decode_attn_kernel<1><<<grid, 256, 0, s>>>(Q, K, V, head_stride / 8, state, c_log2, ws); break;
     case 2: decode_attn_kernel<2><<<grid, 256, 0, s>>>(Q, K, V, head_stride / 8, state, c_log2, ws); break;
@@ -448,6 +643,20 @@ int qp_launch_decode_attn(const qp_ctx* ctx, const void* q, const void* k_cache,
   if (rc) return rc;
   decode_combine_kernel<<<hq, 256, 0, s>>>(ws, ns, c_log2, (uint16_t*)out);
   return qp_check_launch("decode_attn(combine)");
+}
+
+int qp_launch_decode_attn_fused(const qp_ctx* ctx, const void* qkv, const void* cos_t, const void* sin_t, void* k_cache, void* v_cache,
+                                int64_t head_stride, const int64_t* state, int hq, int hkv, float scale, void* out, void* workspace,
+                                hipStream_t s) {
+  const int ns = qp_decode_nsplit(ctx, hkv);
+  const float c_log2 = scale * 1.4426950408889634f;
+  decode_attn_mfma_kernel<true><<<dim3((unsigned)ns, (unsigned)hkv), 256, 0, s>>>((const uint4*)qkv, (const uint4*)cos_t, (const uint4*)sin_t,
+                                                                                 (uint4*)k_cache, (uint4*)v_cache, head_stride / 8, state,
+                                                                                 hq, hkv, c_log2, (float*)workspace);
+  int rc = qp_check_launch("decode_attn_fused");
+  if (rc) return rc;
+  decode_combine_kernel<<<hq, 256, 0, s>>>((const float*)workspace, ns, c_log2, (uint16_t*)out);
+  return qp_check_launch("decode_attn_fused(combine)");
 }
 
 int qp_launch_decode_advance(int64_t* state, int n, hipStream_t s) {

@@ -5,11 +5,11 @@ A decode step is launch-bound when driven from the host (≈340 launches of a fe
 one pass over the weights (HBM-bound).  Here every kernel of the step reads its per-token scalars (cache rows in use, rotary
 position) from a device state block, so the step is captured once (`torch.cuda.CUDAGraph` = hipGraph on ROCm) and replayed:
 
-    embed(tok) -> [ gemv(RMSNorm + qkv + bias) -> M-RoPE + KV append -> single-query attention (+ combine)
+    embed(tok) -> [ gemv(RMSNorm + qkv + bias) -> M-RoPE + KV append + single-query attention (one MFMA kernel) -> combine
                     -> gemv(o_proj + residual) -> gemv(RMSNorm + gate/up + SwiGLU) -> gemv(down + residual) ] x L
                -> gemv(RMSNorm + lm_head) -> argmax -> tok ;  state += 1
 
-7 launches per layer (+ one M-RoPE table per token), all libquickprefill.so kernels (qp_decode.hip); arithmetic and bf16 rounding points are those of the
+6 launches per layer (+ one M-RoPE table per token), all libquickprefill.so kernels (qp_decode.hip); arithmetic and bf16 rounding points are those of the
 eager `QuickPrefillEngine.decode_step` path (same RMSNorm summation order, one rounding per torch op of the reference), only the
 fp32 accumulation order inside the matrix-vector products differs from hipBLASLt's.
 """
@@ -26,7 +26,7 @@ class GraphDecoder:
         """Single-GPU engines on the HIP library; the eager per-op path serves the rest (tensor / pipeline parallel decode,
         CPU test doubles, query-aware pruning during decode)."""
         return (eng.device.type == "cuda" and eng.tp_size == 1 and eng.pp_size == 1 and not eng.cfg.do_top_k_for_query
-                and eng.D == 128 and eng.hq // eng.hkv in (1, 2, 4, 6, 7, 8) and hasattr(eng.ops, "gemv")
+                and eng.D == 128 and eng.hq // eng.hkv <= 8 and hasattr(eng.ops, "gemv")
                 and eng.spec.hidden % 8 == 0 and eng.li % 8 == 0 and max(eng.spec.hidden, eng.li) <= 24576)
 
     def __init__(self, eng):
@@ -43,7 +43,7 @@ class GraphDecoder:
         self.tok = torch.zeros(1, dtype=torch.int64, device=dev)
         self.h = e(1, s.hidden)
         self.qkv = e((eng.hq + 2 * eng.hkv) * eng.D)
-        self.q, self.att = e(eng.hq, eng.D), e(eng.hq, eng.D)
+        self.att = e(eng.hq, eng.D)
         self.act = e(eng.li)
         self.logits = e(eng.w.lm_head.shape[0])
         self.ws = eng.ops.decode_attn_workspace(eng.hq, eng.hkv)
@@ -59,9 +59,8 @@ class GraphDecoder:
         for l, lw in enumerate(w.layers):
             st = self.state[l]
             ops.gemv(lw.w_qkv, h, self.qkv, ops.GEMV_BIAS, bias=lw.b_qkv, norm_w=lw.ln1, eps=s.rms_eps)      # qwen25_lvu.py:167-169, 42-44
-            ops.decode_rope_append(self.qkv, st, s.rope_theta, eng.hq, eng.hkv, D, self.q, eng.arena.k(l), eng.arena.v(l), hs,
-                                   cos=cos, sin=sin)                                                               # :46-58
-            ops.decode_attn(self.q, eng.arena.k(l), eng.arena.v(l), hs, st, eng.hq, eng.hkv, D, D ** -0.5, self.att, self.ws)  # :61-112
+            ops.decode_attn_fused(self.qkv, cos, sin, st, eng.arena.k(l), eng.arena.v(l), hs, eng.hq, eng.hkv, D, D ** -0.5,
+                                  self.att, self.ws)                         # M-RoPE + KV append + attention (:46-58, :61-112)
             ops.gemv(lw.w_o, self.att.view(-1), h, ops.GEMV_RESIDUAL)                                          # :114-115, :182
             ops.gemv(lw.w_gate_up, h, self.act, ops.GEMV_SWIGLU, norm_w=lw.ln2, eps=s.rms_eps)                # :195-197
             ops.gemv(lw.w_down, self.act, h, ops.GEMV_RESIDUAL)                                               # :197-198

@@ -60,6 +60,7 @@ SIGNATURES = {
     "qp_decode_rope_append": (_i32, [_vp, _vp, _vp, _vp, _vp, _f32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _vp]),
     "qp_decode_attn_workspace_bytes": (_sz, [_vp, _i32, _i32]),
     "qp_decode_attn": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i32, _i32, _i32, _f32, _vp, _vp, _sz, _vp]),
+    "qp_decode_attn_fused": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _vp, _vp, _sz, _vp]),
     "qp_decode_advance": (_i32, [_vp, _vp, _i64, _vp]),
     "qp_vit_rope": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "qp_vit_attn": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _f32, _vp, _vp]),
@@ -232,6 +233,11 @@ class QuickPrefillOps:
         self._check(self.lib.qp_decode_attn(self.ctx, q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), head_stride, state.data_ptr(),
                                             n_q, n_kv, D, float(scale), out.data_ptr(), workspace.data_ptr(), workspace.numel() * 4,
                                             self._stream()))
+
+    def decode_attn_fused(self, qkv, cos, sin, state, k_cache, v_cache, head_stride, n_q, n_kv, D, scale, out, workspace):
+        self._check(self.lib.qp_decode_attn_fused(self.ctx, qkv.data_ptr(), cos.data_ptr(), sin.data_ptr(), state.data_ptr(), k_cache.data_ptr(),
+                                                  v_cache.data_ptr(), head_stride, n_q, n_kv, D, float(scale), out.data_ptr(),
+                                                  workspace.data_ptr(), workspace.numel() * 4, self._stream()))
 
     def decode_advance(self, state):
         self._check(self.lib.qp_decode_advance(self.ctx, state.data_ptr(), state.numel(), self._stream()))

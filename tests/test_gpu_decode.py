@@ -147,6 +147,29 @@ def test_decode_attn_vs_oracle(ops, hq, hkv, L):
     assert (out.float() - out_p[0].float()).abs().max().item() <= 1.6e-2
 
 
+@pytest.mark.parametrize("hq,hkv,L", [(28, 4, 11534), (28, 4, 1), (12, 2, 257), (64, 8, 4000), (8, 8, 33), (3, 1, 700)])
+def test_decode_attn_fused_equals_rope_then_attn(ops, hq, hkv, L):
+    """One launch (M-RoPE + KV append + attention) vs the two separate entry points: the appended K/V rows and the attention
+    output must be the same bits (same arithmetic, same kernels downstream)."""
+    rs = np.random.RandomState(L + hq)
+    cap = L + 2
+    kc = bf16(rs.standard_normal((hkv, cap, D))).cuda(); vc = bf16(rs.standard_normal((hkv, cap, D))).cuda()
+    kc2, vc2 = kc.clone(), vc.clone()
+    qkv = bf16(rs.standard_normal((hq + 2 * hkv) * D)).cuda()
+    pos = 4321 + L
+    state = torch.tensor([L - 1, pos], dtype=torch.int64, device="cuda")
+    cos, sin = ops.mrope_table(torch.full((3, 1), pos, dtype=torch.int64, device="cuda"), (16, 24, 24), 1e6, D)
+    ws = ops.decode_attn_workspace(hq, hkv)
+    q = torch.empty(hq, D, dtype=torch.bfloat16, device="cuda")
+    out_a = torch.empty(hq, D, dtype=torch.bfloat16, device="cuda"); out_b = torch.empty_like(out_a)
+    ops.decode_rope_append(qkv, state, 1e6, hq, hkv, D, q, kc, vc, cap * D, cos=cos, sin=sin)
+    ops.decode_attn(q, kc, vc, cap * D, state, hq, hkv, D, D ** -0.5, out_a, ws)
+    ops.decode_attn_fused(qkv, cos, sin, state, kc2, vc2, cap * D, hq, hkv, D, D ** -0.5, out_b, ws)
+    torch.cuda.synchronize()
+    assert np.array_equal(bits(kc), bits(kc2)) and np.array_equal(bits(vc), bits(vc2))
+    assert np.array_equal(bits(out_a), bits(out_b))
+
+
 def test_decode_attn_workspace_is_checked(ops):
     q = torch.zeros(28, D, dtype=torch.bfloat16, device="cuda"); kv = torch.zeros(4, 8, D, dtype=torch.bfloat16, device="cuda")
     state = torch.zeros(2, dtype=torch.int64, device="cuda")
