@@ -176,8 +176,8 @@ int qp_gemv(qp_ctx* ctx, const void* w, const void* x, const void* norm_w, float
 int qp_decode_rope_append(qp_ctx* ctx, const void* qkv, const int64_t* state, const void* cos, const void* sin, float theta,
                           int n_q_heads, int n_kv_heads, int head_dim, void* q_out, void* k_cache, void* v_cache,
                           int64_t head_stride, void* stream);
-/* Single-query attention over cache rows [0, state[0]] (the token's own row included), GQA native (n_q/n_kv in
- * {1,2,4,6,7,8}); fixed grid independent of the cache length.  out bf16 [n_q][128]. */
+/* Single-query attention over cache rows [0, state[0]] (the token's own row included), GQA native (at most 8 query heads
+ * per kv head: they are the query columns of one MFMA tile); fixed grid independent of the cache length.  out bf16 [n_q][128]. */
 size_t qp_decode_attn_workspace_bytes(const qp_ctx* ctx, int n_q_heads, int n_kv_heads);
 int qp_decode_attn(qp_ctx* ctx, const void* q, const void* k_cache, const void* v_cache, int64_t head_stride,
                    const int64_t* state, int n_q_heads, int n_kv_heads, int head_dim, float scale, void* out,
