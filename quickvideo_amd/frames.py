@@ -63,21 +63,33 @@ class SyntheticVideoReader(VideoReaderBase):
         self.total = int(q.get("frames", 64))
         self.src_h, self.src_w = int(q.get("h", 1080)), int(q.get("w", 1920))
         self.fps, self.seed, self.pattern = float(q.get("fps", 2.0)), int(q.get("seed", 1)), q.get("pattern", "noise")
+        self._pool = None
 
     def __len__(self): return self.total
     def get_fps(self): return self.fps
 
+    def _frame(self, out, j, i, H, W):
+        if self.pattern == "gradient":
+            yy = (np.arange(H, dtype=np.uint32)[:, None] * 255 // max(H - 1, 1))
+            xx = (np.arange(W, dtype=np.uint32)[None, :] * 255 // max(W - 1, 1))
+            base = (yy + xx + 7 * int(i)) % 256
+            out[j] = np.stack([base, (base * 3 + 40) % 256, (255 - base)]).astype(np.uint8)
+        else:
+            out[j] = np.random.RandomState((self.seed * 1_000_003 + int(i)) % (2 ** 31)).randint(0, 256, (3, H, W), dtype=np.uint8)
+
     def _frames(self, idx):
         H, W = self.height or self.src_h, self.width or self.src_w
         out = np.empty((len(idx), 3, H, W), dtype=np.uint8)
-        for j, i in enumerate(idx):
-            if self.pattern == "gradient":
-                yy = (np.arange(H, dtype=np.uint32)[:, None] * 255 // max(H - 1, 1))
-                xx = (np.arange(W, dtype=np.uint32)[None, :] * 255 // max(W - 1, 1))
-                base = (yy + xx + 7 * int(i)) % 256
-                out[j] = np.stack([base, (base * 3 + 40) % 256, (255 - base)]).astype(np.uint8)
-            else:
-                out[j] = np.random.RandomState((self.seed * 1_000_003 + int(i)) % (2 ** 31)).randint(0, 256, (3, H, W), dtype=np.uint8)
+        if self.num_threads > 1 and len(idx) > 1 and H * W >= 1 << 16:
+            # like the reference's decoder pool (QUICKCODEC_CORES, qwen25_lvu_interleaved.py:385-396): frames of a group in parallel
+            # (numpy's generators release the GIL while they fill the buffer)
+            if self._pool is None:
+                from concurrent.futures import ThreadPoolExecutor
+                self._pool = ThreadPoolExecutor(max_workers=self.num_threads)
+            list(self._pool.map(lambda ji: self._frame(out, ji[0], ji[1], H, W), enumerate(idx)))
+        else:
+            for j, i in enumerate(idx):
+                self._frame(out, j, i, H, W)
         return out
 
 

@@ -59,9 +59,12 @@ class Timings:
 class _Producer(threading.Thread):
     """Frame groups -> pinned ring -> async H2D on `copy_stream`; bounded like the reference's Queue(maxsize=3)."""
 
-    def __init__(self, reader, n_groups, frames_per_group, device, depth=3):
+    def __init__(self, reader, n_groups, frames_per_group, device, depth=3, ring_cache=None):
         super().__init__(daemon=True)
         self.reader, self.n_groups, self.device, self.depth = reader, n_groups, device, depth
+        # pinned host slots + device slots are kept across videos by the owner of `ring_cache` (page-locking ~80 MB costs tens
+        # of ms: it would otherwise sit in front of the first group of every video)
+        self.ring_cache = ring_cache if ring_cache is not None else {}
         self.q: "queue.Queue" = queue.Queue(maxsize=depth)
         self.exc = None
         self.use_gpu = device.type == "cuda"
@@ -78,8 +81,12 @@ class _Producer(threading.Thread):
                 if self.use_gpu:
                     if self.ring is None:
                         shape = (self.fpg,) + tuple(frames.shape[1:])
-                        self.ring = [(torch.empty(shape, dtype=torch.uint8).pin_memory(), torch.empty(shape, dtype=torch.uint8, device=self.device))
-                                     for _ in range(self.depth)]
+                        key = (self.depth, shape, str(self.device))
+                        if key not in self.ring_cache:
+                            self.ring_cache.clear()                 # one video geometry at a time
+                            self.ring_cache[key] = [(torch.empty(shape, dtype=torch.uint8).pin_memory(),
+                                                     torch.empty(shape, dtype=torch.uint8, device=self.device)) for _ in range(self.depth)]
+                        self.ring = self.ring_cache[key]
                     host, dev = self.ring[g % self.depth]
                     host[: frames.shape[0]].copy_(frames)
                     with torch.cuda.stream(self.copy_stream):
@@ -177,7 +184,9 @@ class PrefillPipeline:
         prefix = torch.tensor(P["prompt"].prefix_ids, dtype=torch.long, device=dev)
         tail = torch.tensor(P["prompt"].tail_ids, dtype=torch.long, device=dev)
         # overlapped: bounded ring of 3 groups like the reference's Queue(maxsize=3); sequential: everything is fetched first
-        prod = _Producer(reader, len(plan.tokens), gs, dev, depth=3 if overlap else len(plan.tokens))
+        if not hasattr(self, "_ring_cache"):
+            self._ring_cache = {}
+        prod = _Producer(reader, len(plan.tokens), gs, dev, depth=3 if overlap else len(plan.tokens), ring_cache=self._ring_cache)
         if overlap:
             prod.start()
         else:
