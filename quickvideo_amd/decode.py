@@ -116,6 +116,8 @@ class GraphDecoder:
 
     def generate(self, first_token: int, max_new_tokens: int, rope_delta: int, eos_token_id: Optional[int] = None) -> List[int]:
         """Greedy continuation after `first_token` (the TTFT token): up to max_new_tokens further tokens."""
+        if max_new_tokens <= 0:
+            return []
         self.begin(rope_delta)
         out: List[int] = []
         tok = int(first_token)
