@@ -161,7 +161,7 @@ int qp_swiglu(qp_ctx* ctx, const void* gate_up, int64_t n, int inter, void* out,
  * layer's cache; position id of the token being decoded, the same on all three M-RoPE streams), so a whole decode step has
  * no host arguments that change between tokens: capture it once in a hipGraph and replay it per token.              */
 /* out[n_out] = epilogue(W[n_out][k] . x[k]) for ONE token (batch 1): the weight stream of the step, HBM-bound.
- * W bf16 row-major [n_out][k] (a torch Linear weight), k % 8 == 0, k <= 24576.  If norm_w != NULL, x is the residual
+ * W bf16 row-major [n_out][k] (a torch Linear weight), k % 8 == 0, k <= 32256 (x is staged in LDS).  If norm_w != NULL, x is the residual
  * stream h and the kernel applies RMSNorm first (x = norm_w * bf16(h * rsqrt(mean(h^2) + eps)), same arithmetic as
  * qp_add_rmsnorm).  mode QP_GEMV_BIAS: out = bf16(dot + bias) (bias may be NULL);  QP_GEMV_SWIGLU: W is [2*n_out][k]
  * (gate rows then up rows), out = bf16(bf16(silu(bf16(g))) * bf16(u)) = qp_swiglu of the two projections;

@@ -301,8 +301,9 @@ int qp_gemv(qp_ctx* ctx, const void* w, const void* x, const void* norm_w, float
             int64_t n_out, int64_t k, int mode, void* stream) {
   QP_REQUIRE(ctx && w && x && out, QP_ERR_INVALID, "qp_gemv: NULL argument");
   QP_REQUIRE(mode >= QP_GEMV_BIAS && mode <= QP_GEMV_RESIDUAL, QP_ERR_INVALID, "qp_gemv: unknown mode %d", mode);
-  QP_REQUIRE(n_out > 0 && n_out < (1ll << 30) && k > 0 && k % 8 == 0 && k <= 24576, QP_ERR_INVALID,
-             "qp_gemv: n_out=%lld, k=%lld (k must be a multiple of 8, at most 24576)", (long long)n_out, (long long)k);
+  QP_REQUIRE(n_out > 0 && n_out < (1ll << 30) && k > 0 && k % 8 == 0 && k <= 32256, QP_ERR_INVALID,
+             "qp_gemv: n_out=%lld, k=%lld (k must be a multiple of 8, at most 32256: x is staged in 63 KB of LDS)", (long long)n_out,
+             (long long)k);
   QP_REQUIRE(mode == QP_GEMV_BIAS || bias == nullptr, QP_ERR_INVALID, "qp_gemv: bias only with QP_GEMV_BIAS");
   QP_REQUIRE(aligned16(w) && aligned16(x) && (!norm_w || aligned16(norm_w)), QP_ERR_INVALID, "qp_gemv: alignment");
   return qp_launch_gemv(ctx, w, x, norm_w, eps, bias, out, n_out, k, mode, (hipStream_t)stream);

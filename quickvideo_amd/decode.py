@@ -27,7 +27,7 @@ class GraphDecoder:
         CPU test doubles, query-aware pruning during decode)."""
         return (eng.device.type == "cuda" and eng.tp_size == 1 and eng.pp_size == 1 and not eng.cfg.do_top_k_for_query
                 and eng.D == 128 and eng.hq // eng.hkv <= 8 and hasattr(eng.ops, "gemv")
-                and eng.spec.hidden % 8 == 0 and eng.li % 8 == 0 and max(eng.spec.hidden, eng.li) <= 24576)
+                and eng.spec.hidden % 8 == 0 and eng.li % 8 == 0 and max(eng.spec.hidden, eng.li) <= 32256)
 
     def __init__(self, eng):
         assert self.supported(eng)

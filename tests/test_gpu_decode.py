@@ -49,7 +49,8 @@ def close_bf16(got, ref, ulps=1.0, floor=2e-3):
     assert ((got - ref).abs() <= tol).all(), ((got - ref).abs() - tol).max().item()
 
 
-@pytest.mark.parametrize("n_out,k", [(4608, 3584), (3584, 3584), (3584, 18944), (1536, 1536), (152064, 3584), (40, 64), (7, 8)])
+@pytest.mark.parametrize("n_out,k", [(4608, 3584), (3584, 3584), (3584, 18944), (1536, 1536), (152064, 3584), (40, 64), (7, 8),
+                                     (8192, 29568), (10240, 8192)])
 def test_gemv_bias_and_residual(ops, n_out, k):
     rs = np.random.RandomState(n_out + k)
     w = bf16(rs.standard_normal((n_out, k)), 0.05).cuda()
@@ -69,7 +70,7 @@ def test_gemv_bias_and_residual(ops, n_out, k):
     assert ((h.float().cpu() - want).abs() <= tol).all()
 
 
-@pytest.mark.parametrize("inter,k", [(18944, 3584), (8960, 1536), (24, 64)])
+@pytest.mark.parametrize("inter,k", [(18944, 3584), (8960, 1536), (24, 64), (29568, 8192)])
 def test_gemv_swiglu_and_fused_norm(ops, inter, k):
     """RMSNorm prologue + gate/up + SwiGLU epilogue vs the unfused kernels (qp_add_rmsnorm -> torch.mm -> qp_swiglu)."""
     rs = np.random.RandomState(inter)
