@@ -153,10 +153,10 @@ class PrefillPipeline:
                                              vs.spatial_merge_size, spec.temporal_scale)
         return dict(nframes=nframes, H=H, W=W, idx=idx, prompt=prompt, plan=plan, pos=pos, delta=delta, T=T, gh=gh, gw=gw)
 
-    def _engine(self, plan, T) -> QuickPrefillEngine:
+    def _engine(self, plan, T, max_new_tokens: int = 0) -> QuickPrefillEngine:
         cfg, spec = self.cfg, self.model.spec
         kept = sum((effective_k(n, cfg, 0, spec.n_layers) or n) for n in plan.tokens)
-        need_cap = kept + plan.tail_len + 256
+        need_cap = kept + plan.tail_len + max(256, max_new_tokens + 8)        # room for every token that will be decoded
         n_max = max(plan.tokens + [plan.tail_len, 1])
         eng = self.model.engine
         if eng is None or eng.arena.capacity < need_cap or eng.n_max < n_max or eng.cfg is not cfg:
@@ -179,7 +179,7 @@ class PrefillPipeline:
         gs = plan.frames[0]
         reader.frame_iter = gs
         reader.process(P["idx"])                                      # decoding starts here (interleaved:438-442)
-        eng = self._engine(plan, P["T"])
+        eng = self._engine(plan, P["T"], max_new_tokens)
         self.model.rope_deltas = P["delta"]                           # qwen25_lvu.py:620
         prefix = torch.tensor(P["prompt"].prefix_ids, dtype=torch.long, device=dev)
         tail = torch.tensor(P["prompt"].tail_ids, dtype=torch.long, device=dev)
