@@ -200,6 +200,10 @@ int qp_vit_rope(qp_ctx* ctx, void* qkv, const float* cos, const float* sin, int6
  * reference), head_dim 80, MFMA kernel shared with qp_prefill_attn.  out bf16 [n][heads][80]. */
 int qp_vit_attn(qp_ctx* ctx, const void* qkv, int64_t n_seq, int64_t seq_len, int heads, int head_dim, float scale, void* out,
                 void* stream);
+/* Residual add of a vision block fused with the LayerNorm after it: if delta != NULL, x = bf16(x + delta) (written back);
+ * out = bf16((x - mean) * rstd * w + b) with fp32 statistics over the row (torch layer_norm).  x, delta, out bf16 [n][hidden]. */
+int qp_add_layernorm(qp_ctx* ctx, void* x, const void* delta, const void* w, const void* b, void* out, int64_t n, int hidden,
+                     float eps, void* stream);
 /* out = y * sigmoid(1.702 y) with torch's bf16 rounding steps (hidden_act = quick_gelu). */
 int qp_quick_gelu(qp_ctx* ctx, const void* x, void* out, int64_t n_elems, void* stream);
 

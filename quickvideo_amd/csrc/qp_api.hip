@@ -296,6 +296,16 @@ int qp_quick_gelu(qp_ctx* ctx, const void* x, void* out, int64_t n_elems, void* 
   return qp_launch_quick_gelu(x, out, n_elems, (hipStream_t)stream);
 }
 
+int qp_add_layernorm(qp_ctx* ctx, void* x, const void* delta, const void* w, const void* b, void* out, int64_t n, int hidden,
+                     float eps, void* stream) {
+  QP_REQUIRE(ctx && x && w && b && out, QP_ERR_INVALID, "qp_add_layernorm: NULL argument");
+  QP_REQUIRE(n >= 0 && hidden > 0 && hidden % 8 == 0 && hidden <= 4096, QP_ERR_INVALID,
+             "qp_add_layernorm: hidden=%d must be a multiple of 8, at most 4096", hidden);
+  QP_REQUIRE(aligned16(x) && aligned16(w) && aligned16(b) && aligned16(out) && (!delta || aligned16(delta)), QP_ERR_INVALID,
+             "qp_add_layernorm: alignment");
+  return qp_launch_add_layernorm(x, delta, w, b, out, n, hidden, eps, (hipStream_t)stream);
+}
+
 // ---- decode step (qp_decode.hip) ------------------------------------------------------------------------------------
 int qp_gemv(qp_ctx* ctx, const void* w, const void* x, const void* norm_w, float eps, const void* bias, void* out,
             int64_t n_out, int64_t k, int mode, void* stream) {

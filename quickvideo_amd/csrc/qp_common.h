@@ -67,6 +67,8 @@ int qp_launch_vit_attn(const qp_ctx* ctx, const void* qkv, int64_t n_seq, int64_
                        hipStream_t s);
 int qp_launch_vit_rope(void* qkv, const float* cos_t, const float* sin_t, int64_t n, int heads, int head_dim, hipStream_t s);
 int qp_launch_quick_gelu(const void* x, void* out, int64_t n_elems, hipStream_t s);
+int qp_launch_add_layernorm(void* x, const void* delta, const void* w, const void* b, void* out, int64_t n, int hidden, float eps,
+                            hipStream_t s);
 int qp_launch_prune_fused(const float* head_sumsq, int n_heads, int64_t n, int64_t k, const void* k_src, const void* v_src,
                           int64_t src_head_stride, int hkv, void* k_dst, void* v_dst, int64_t dst_head_stride, int64_t dst_row0,
                           int32_t* kept, uint16_t* norm_bits, int cus, int largest, hipStream_t s);

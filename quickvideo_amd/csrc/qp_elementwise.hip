@@ -187,3 +187,79 @@ int qp_launch_quick_gelu(const void* x, void* out, int64_t n_elems, hipStream_t 
   quick_gelu_kernel<<<(int)blocks, 256, 0, s>>>((const uint4*)x, (uint4*)out, n16);
   return qp_check_launch("quick_gelu");
 }
+
+// x = bf16(x + delta) (when delta != NULL, written back);  out = bf16((x - mean) * rstd * w + b)  — the residual add of a ViT
+// block fused with the LayerNorm that follows it (transformers Qwen2VLVisionBlock [3P]: x = x + attn(norm1(x)); x = x + mlp(norm2(x))).
+// One WAVE per row, the row stays in registers (hidden <= 4096): two-pass mean / variance in fp32 like torch's layer_norm.
+__global__ __launch_bounds__(256) void add_layernorm_kernel(uint4* __restrict__ x, const uint4* __restrict__ delta,
+                                                            const uint4* __restrict__ w, const uint4* __restrict__ b,
+                                                            uint4* __restrict__ out, int64_t n, int hidden16, float inv_hidden,
+                                                            float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const int64_t base = row * hidden16;
+  float v[8][8];
+  float sum = 0.f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int idx = lane + 64 * c;
+    if (idx < hidden16) {
+      uint4 xv = x[base + idx];
+      unsigned xw[4] = {xv.x, xv.y, xv.z, xv.w};
+      if (delta) {
+        const uint4 dv = delta[base + idx];
+        const unsigned dw[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float lo = __uint_as_float(xw[i] << 16) + __uint_as_float(dw[i] << 16);
+          const float hi = __uint_as_float(xw[i] & 0xffff0000u) + __uint_as_float(dw[i] & 0xffff0000u);
+          xw[i] = (unsigned)f32_to_bf16_bits(lo) | ((unsigned)f32_to_bf16_bits(hi) << 16);
+        }
+        x[base + idx] = make_uint4(xw[0], xw[1], xw[2], xw[3]);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        v[c][2 * i] = __uint_as_float(xw[i] << 16); v[c][2 * i + 1] = __uint_as_float(xw[i] & 0xffff0000u);
+        sum += v[c][2 * i] + v[c][2 * i + 1];
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+  const float mean = sum * inv_hidden;
+  float sq = 0.f;
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+    if (lane + 64 * c < hidden16) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[c][e] - mean; sq = __builtin_fmaf(d, d, sq); }
+    }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o, 64);
+  const float rstd = 1.0f / __fsqrt_rn(sq * inv_hidden + eps);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    const int idx = lane + 64 * c;
+    if (idx < hidden16) {
+      const uint4 wv = w[idx], bv = b[idx];
+      const unsigned ww[4] = {wv.x, wv.y, wv.z, wv.w}, bw[4] = {bv.x, bv.y, bv.z, bv.w};
+      unsigned o[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float lo = (v[c][2 * i] - mean) * rstd * __uint_as_float(ww[i] << 16) + __uint_as_float(bw[i] << 16);
+        const float hi = (v[c][2 * i + 1] - mean) * rstd * __uint_as_float(ww[i] & 0xffff0000u) + __uint_as_float(bw[i] & 0xffff0000u);
+        o[i] = (unsigned)f32_to_bf16_bits(lo) | ((unsigned)f32_to_bf16_bits(hi) << 16);
+      }
+      out[base + idx] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+  }
+}
+
+int qp_launch_add_layernorm(void* x, const void* delta, const void* w, const void* b, void* out, int64_t n, int hidden, float eps,
+                            hipStream_t s) {
+  if (n == 0) return QP_OK;
+  add_layernorm_kernel<<<(unsigned)((n + 3) / 4), 256, 0, s>>>((uint4*)x, (const uint4*)delta, (const uint4*)w, (const uint4*)b,
+                                                               (uint4*)out, n, hidden / 8, 1.0f / (float)hidden, eps);
+  return qp_check_launch("add_layernorm");
+}

@@ -65,6 +65,7 @@ SIGNATURES = {
     "qp_vit_rope": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "qp_vit_attn": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _f32, _vp, _vp]),
     "qp_quick_gelu": (_i32, [_vp, _vp, _vp, _i64, _vp]),
+    "qp_add_layernorm": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
 }
 
 
@@ -248,6 +249,11 @@ class QuickPrefillOps:
 
     def vit_attn(self, qkv, n_seq, seq_len, heads, head_dim, scale, out):
         self._check(self.lib.qp_vit_attn(self.ctx, qkv.data_ptr(), n_seq, seq_len, heads, head_dim, float(scale), out.data_ptr(), self._stream()))
+
+    def add_layernorm(self, x, delta, w, b, out, eps):
+        n, hidden = x.shape
+        self._check(self.lib.qp_add_layernorm(self.ctx, x.data_ptr(), _ptr(delta), w.data_ptr(), b.data_ptr(), out.data_ptr(), n, hidden,
+                                              float(eps), self._stream()))
 
     def quick_gelu(self, x, out):
         self._check(self.lib.qp_quick_gelu(self.ctx, x.data_ptr(), out.data_ptr(), x.numel(), self._stream()))

@@ -10,6 +10,7 @@ position embedding on (h, w), quick-GELU MLP, and the 2x2 PatchMerger MLP into t
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Tuple
 
@@ -185,8 +186,26 @@ class VisionTower:
         ops = self.ops
         if ops is not None:
             cos_h, sin_h = rot.cos().contiguous(), rot.sin().contiguous()                # fp32 [n, head_dim/2]
+        fused_ln = (ops is not None and hasattr(ops, "add_layernorm") and s.embed_dim % 8 == 0 and s.embed_dim <= 4096
+                    and os.environ.get("QP_VIT_FUSED_LN", "1") == "1")               # developer A/B switch (tools/bench_vit.py)
+        pend = None                                   # residual branch not yet added to x (fused into the next LayerNorm launch)
+        ybuf = torch.empty_like(x) if fused_ln else None
+
+        def norm(wt, bs):
+            """x += pending residual; LayerNorm(x)  (Qwen2VLVisionBlock: x = x + attn(norm1(x)); x = x + mlp(norm2(x)))"""
+            nonlocal x, pend
+            if fused_ln:
+                ops.add_layernorm(x, pend, wt, bs, ybuf, 1e-6)                           # one pass: residual add + LayerNorm
+                pend = None
+                return ybuf
+            if pend is not None:
+                x, pend = x + pend, None
+            return F.layer_norm(x, (s.embed_dim,), wt, bs, 1e-6)
+
+        if fused_ln:
+            x = x.contiguous()
         for b in w.blocks:
-            y = F.layer_norm(x, (s.embed_dim,), b.ln1_w, b.ln1_b, 1e-6)
+            y = norm(b.ln1_w, b.ln1_b)
             qkv = F.linear(y, b.qkv_w, b.qkv_b)                                          # [n, 3*H*hd]
             if ops is not None:
                 ops.vit_rope(qkv, cos_h, sin_h, H, hd)                                   # q, k rotated in place
@@ -201,15 +220,16 @@ class VisionTower:
                 q4, k4, v4 = (z.reshape(t, seq, H, hd).transpose(1, 2) for z in (q, k, v))   # [t, H, seq, hd]
                 a = F.scaled_dot_product_attention(q4, k4, v4, is_causal=False)
                 a = a.transpose(1, 2).reshape(n, H * hd)
-            x = x + F.linear(a, b.proj_w, b.proj_b)
-            y = F.layer_norm(x, (s.embed_dim,), b.ln2_w, b.ln2_b, 1e-6)
+            pend = F.linear(a, b.proj_w, b.proj_b)
+            y = norm(b.ln2_w, b.ln2_b)
             y = F.linear(y, b.fc1_w, b.fc1_b)
             if ops is not None:
                 ops.quick_gelu(y, y)
             else:
                 y = y * torch.sigmoid(1.702 * y)                                         # quick_gelu
-            x = x + F.linear(y, b.fc2_w, b.fc2_b)
-        y = F.layer_norm(x, (s.embed_dim,), w.ln_q_w, w.ln_q_b, 1e-6).view(-1, s.embed_dim * s.spatial_merge_size ** 2)
+            pend = F.linear(y, b.fc2_w, b.fc2_b)
+        x = norm(w.ln_q_w, w.ln_q_b)
+        y = x.view(-1, s.embed_dim * s.spatial_merge_size ** 2)
         y = F.gelu(F.linear(y, w.m1_w, w.m1_b))
         return F.linear(y, w.m2_w, w.m2_b)                                               # [n/4, out_hidden]
 

@@ -308,6 +308,22 @@ def test_vit_kernels_match_torch_path(ops):
     y = torch.from_numpy(rs.standard_normal((77, 5120)).astype(np.float32) * 3).to(torch.bfloat16).cuda()
     g = torch.empty_like(y); ops.quick_gelu(y, g)
     assert torch.equal(g, y * torch.sigmoid(1.702 * y))
+    # fused residual add + LayerNorm: the add is bit-exact, the norm within one bf16 ulp of torch's layer_norm
+    for n_, hid in ((77, 1280), (5, 64), (1, 4096), (1000, 1280)):
+        x0 = torch.from_numpy(rs.standard_normal((n_, hid)).astype(np.float32) * 2).to(torch.bfloat16).cuda()
+        d0 = torch.from_numpy(rs.standard_normal((n_, hid)).astype(np.float32)).to(torch.bfloat16).cuda()
+        wl = torch.from_numpy(1 + 0.2 * rs.standard_normal(hid).astype(np.float32)).to(torch.bfloat16).cuda()
+        bl = torch.from_numpy(0.3 * rs.standard_normal(hid).astype(np.float32)).to(torch.bfloat16).cuda()
+        for delta in (d0, None):
+            xb, o = x0.clone(), torch.empty_like(x0)
+            ops.add_layernorm(xb, delta, wl, bl, o, 1e-6)
+            xs = x0 + delta if delta is not None else x0
+            assert torch.equal(xb, xs)
+            ref = torch.nn.functional.layer_norm(xs.float(), (hid,), wl.float(), bl.float(), 1e-6)
+            err = (o.float() - ref).abs()
+            assert (err <= 2.0 ** -8 * ref.abs() + 1e-3).all(), err.max().item()
+    with pytest.raises(ValueError):
+        ops.add_layernorm(torch.zeros(2, 12, dtype=torch.bfloat16, device="cuda"), None, wl, bl, torch.zeros(2, 12, dtype=torch.bfloat16, device="cuda"), 1e-6)
 
 
 @pytest.mark.parametrize("n,P,hq,hkv", [(5760, 8647, 28, 4), (2240, 60000, 28, 4), (960, 7000, 8, 1), (5775, 0, 12, 2)])
