@@ -296,3 +296,38 @@ def test_graph_decode_vs_reference_golden(golden_dir, ci):
             check_tiny(lg.numpy(), c["decode_logits"][i])
             tok = int(torch.argmax(lg))
         assert eng.arena.len == c["cache_len"]
+
+
+def test_decode_full_size_properties(ops):
+    """BASELINE.json sizes, size-independent properties (no oracle at these sizes): (a) the matrix-vector product commutes with a
+    power-of-two scaling of x bit-for-bit (fp32 accumulation and bf16 rounding are both exact under x2) at the lm_head size;
+    (b) single-query attention over a 1-hour-video cache (504 k rows) is linear in V and invariant under a permutation of the
+    cache rows (softmax-weighted sum), within the attention tolerance."""
+    g = torch.Generator(device="cuda"); g.manual_seed(9)
+    w = (torch.randn(152064, 3584, generator=g, device="cuda") * 0.02).to(torch.bfloat16)
+    x = torch.randn(3584, generator=g, device="cuda").to(torch.bfloat16)
+    o1 = torch.empty(152064, dtype=torch.bfloat16, device="cuda"); o2 = torch.empty_like(o1)
+    ops.gemv(w, x, o1, ops.GEMV_BIAS)
+    ops.gemv(w, x * 2, o2, ops.GEMV_BIAS)
+    assert torch.equal(o2, o1 * 2) and torch.isfinite(o1.float()).all()
+    del w
+    hq, hkv, L = 28, 4, 504037
+    q = torch.randn(hq, D, generator=g, device="cuda").to(torch.bfloat16)
+    k = torch.randn(hkv, L, D, generator=g, device="cuda").to(torch.bfloat16)
+    v = torch.randn(hkv, L, D, generator=g, device="cuda").to(torch.bfloat16)
+    k[:, 1234] *= 3.0                                             # one dominant key so that the output is not ~0
+    state = torch.tensor([L - 1, 0], dtype=torch.int64, device="cuda")
+    ws = ops.decode_attn_workspace(hq, hkv)
+    run = lambda kk, vv: (lambda o: (ops.decode_attn(q, kk, vv, L * D, state, hq, hkv, D, D ** -0.5, o, ws), o)[1])(
+        torch.empty(hq, D, dtype=torch.bfloat16, device="cuda"))
+    a = run(k, v).float()
+    b = run(k, v * 2).float()
+    assert (b - 2 * a).abs().max().item() <= 2e-2
+    perm = torch.randperm(L, generator=g, device="cuda")
+    c = run(k[:, perm].contiguous(), v[:, perm].contiguous()).float()
+    assert (c - a).abs().max().item() <= 1.5e-2
+    # fp32 reference for one kv head
+    s = (q[:7].float() @ k[0].float().T) * D ** -0.5
+    ref = torch.softmax(s, -1) @ v[0].float()
+    err = (a[:7] - ref).abs()
+    assert (err <= 1.5e-2 + 1.5e-2 * ref.abs()).all(), err.max().item()
