@@ -277,9 +277,26 @@ class VisionTower:
         wmap = starts[:, None] + ar[None, :]
         wvalid = ar[None, :] < lens[:, None]
         wmap = torch.where(wvalid, wmap, torch.zeros_like(wmap))
-        rms = lambda z, g: (z.float() * torch.rsqrt(z.float().pow(2).mean(-1, keepdim=True) + 1e-6)).to(z.dtype) * g
+        rms_t = lambda z, g: (z.float() * torch.rsqrt(z.float().pow(2).mean(-1, keepdim=True) + 1e-6)).to(z.dtype) * g
+        fused = ops is not None and d % 8 == 0
+        pend = None                                   # residual branch not yet added to x (fused into the next RMSNorm launch)
+        ybuf = torch.empty(n, d, dtype=x.dtype, device=x.device) if fused else None
+        if fused:
+            x = x.contiguous()
+
+        def rms(g):
+            """x += pending residual; RMSNorm(x) * g   (one qp_add_rmsnorm launch on the GPU)"""
+            nonlocal x, pend
+            if fused:
+                ops.add_rmsnorm(x, pend, g, ybuf, 1e-6)
+                pend = None
+                return ybuf
+            if pend is not None:
+                x, pend = x + pend, None
+            return rms_t(x, g)
+
         for li, b in enumerate(w.blocks):
-            y = rms(x, b.n1)
+            y = rms(b.n1)
             qkv = F.linear(y, b.qkv_w, b.qkv_b)
             full = li in s.fullatt_blocks
             if ops is not None:
@@ -303,10 +320,10 @@ class VisionTower:
                     a = torch.empty(n, H, hd, dtype=x.dtype, device=x.device)
                     a[wmap[wvalid]] = o.transpose(1, 2)[wvalid]
                     a = a.reshape(n, H * hd)
-            x = x + F.linear(a, b.proj_w, b.proj_b)
-            y = rms(x, b.n2)
+            pend = F.linear(a, b.proj_w, b.proj_b)
+            y = rms(b.n2)
             y = F.silu(F.linear(y, b.gate_w, b.gate_b)) * F.linear(y, b.up_w, b.up_b)
-            x = x + F.linear(y, b.down_w, b.down_b)
-        y = rms(x, w.ln_q_w).view(-1, d * unit)
+            pend = F.linear(y, b.down_w, b.down_b)
+        y = rms(w.ln_q_w).view(-1, d * unit)
         y = F.linear(F.gelu(F.linear(y, w.m1_w, w.m1_b)), w.m2_w, w.m2_b)
         return y[torch.argsort(win)]                                                   # back to raster (t, h/2, w/2) order
