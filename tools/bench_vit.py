@@ -1,9 +1,9 @@
 """ViT front-end micro-benchmark (one cfg2 group: 16 frames 560x1008 -> 23040 patches -> 5760 tokens)."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from quickvideo_amd.vit import QWEN2_VL_VIT_7B, VisionTower, VisionWeights, patchify_frames
+from quickvideo_amd.vit import QWEN2_VL_VIT_7B, QWEN25_VL_VIT_7B, VisionTower, VisionWeights, patchify_frames
 dev = torch.device("cuda:0")
-w = VisionWeights.synthetic(QWEN2_VL_VIT_7B, dev)
+w = VisionWeights.synthetic(QWEN25_VL_VIT_7B if os.environ.get('QP_VIT_ARCH') == '2.5' else QWEN2_VL_VIT_7B, dev)
 from quickvideo_amd.native import QuickPrefillOps
 tower = VisionTower(w, ops=QuickPrefillOps(dev) if os.environ.get('QP_VIT_OPS','1')=='1' else None)
 frames = torch.randint(0, 256, (16, 3, 560, 1008), dtype=torch.uint8, device=dev)
