@@ -169,6 +169,10 @@ class PrefillPipeline:
     @torch.no_grad()
     def generate(self, question: str, video, max_new_tokens: int = 16, overlap: bool = True, eos_token_id: Optional[int] = None,
                  **unused) -> List[int]:
+        # decoding is greedy (what the reference's Qwen2-VL generation config amounts to: top_k = 1); anything else is refused
+        # rather than silently ignored
+        if (unused.get("do_sample") and unused.get("top_k") != 1) or unused.get("num_beams", 1) != 1:
+            raise NotImplementedError("the native engine decodes greedily: do_sample (other than top_k=1) and beam search are not implemented")
         tm = Timings()
         dev = self.model.device
         t_e2e = time.perf_counter()
