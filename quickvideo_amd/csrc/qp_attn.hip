@@ -242,19 +242,20 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel_s4(AttnParams p) {
   }
 }
 
-// merges the kv-split partials of one item: O = sum_s O_s 2^{(m_s-M)c} / sum_s l_s 2^{(m_s-M)c}.  Same thread geometry as the
-// producer (thread = (wave, lane) -> one query), 16-B loads; all (m, l) pairs are fetched first so the loads of every split
-// are independent.
+// merges the kv-split partials of one item: O = sum_s O_s 2^{(m_s-M)c} / sum_s l_s 2^{(m_s-M)c}.  One WAVE per (item, 32-row
+// slice, 32-wide d block): grid (kv head x split items, slices, d blocks) of 64 threads, thread = one query x half as in the
+// producer, 16-B loads; all (m, l) pairs are fetched first so the loads of every split are independent.  Slices past the last
+// query row exit at once (a 30-token prompt tail has 28 split items: one workgroup per item took 65 us, this form 6).
 constexpr int kMaxSplit = 16;
 template <int D, bool kVit>
-__global__ __launch_bounds__(512) void attn_combine_kernel(AttnParams p) {   // blockDim = 2 * qb_rows (one thread per query x half)
-  constexpr int NDB = (D + 31) / 32;
+__global__ __launch_bounds__(64) void attn_combine_kernel(AttnParams p) {
   const int n_split_items = p.items - p.n_whole;
   const int kvh = blockIdx.x / n_split_items, it = blockIdx.x % n_split_items;
   const int item = p.n_whole + it;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
+  const int lane = threadIdx.x, wave = blockIdx.y, db = blockIdx.z, hi = lane >> 5;
   const int qb = p.nqb - 1 - item / p.group;
   const int head = kvh * p.group + item % p.group;
+  if (qb * p.qb_rows + wave * 32 >= p.nq) return;
   const int qi = qb * p.qb_rows + wave * 32 + (lane & 31);
   const int pfl = partial_floats(p.qb_rows), o_floats = p.qb_rows * 128;
   const float* base = p.ws + (int64_t)(kvh * n_split_items + it) * p.nsplit * pfl;
@@ -277,18 +278,15 @@ __global__ __launch_bounds__(512) void attn_combine_kernel(AttnParams p) {   // 
     L += f[s] * e;
     f[s] = e;
   }
-  f32x4_t acc[NDB * 4];
+  f32x4_t acc[4];
 #pragma unroll
-  for (int r = 0; r < NDB * 4; ++r) acc[r] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-  for (int s = 0; s < p.nsplit; ++s) {
-    const f32x4_t* wo = reinterpret_cast<const f32x4_t*>(base + (int64_t)s * pfl) + (wave * 16) * 64 + lane;
-    float fs = f[0];
+  for (int r = 0; r < 4; ++r) acc[r] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int k = 1; k < kMaxSplit; ++k) fs = (s == k) ? f[k] : fs;       // static indexing only (runtime index -> scratch)
+  for (int s = 0; s < kMaxSplit; ++s) {
+    if (s < p.nsplit) {
+      const f32x4_t* wo = reinterpret_cast<const f32x4_t*>(base + (int64_t)s * pfl) + (wave * 16 + db * 4) * 64 + lane;
 #pragma unroll
-    for (int r = 0; r < NDB * 4; ++r) {
-      const f32x4_t v = wo[r * 64];
-      acc[r] += v * fs;
+      for (int r = 0; r < 4; ++r) acc[r] += wo[r * 64] * f[s];
     }
   }
   if (qi < p.nq) {
@@ -296,13 +294,11 @@ __global__ __launch_bounds__(512) void attn_combine_kernel(AttnParams p) {   // 
     uint2* op = kVit ? p.out + (((int64_t)(kvh / p.heads_per_seq) * p.n + qi) * p.heads_per_seq + (kvh % p.heads_per_seq)) * (D / 4)
                      : p.out + ((int64_t)qi * p.hq + head) * 32;
 #pragma unroll
-    for (int db = 0; db < NDB; ++db)
-#pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        const f32x4_t a = acc[db * 4 + r4];
-        bf16x4_t v = {(__bf16)(a[0] * inv), (__bf16)(a[1] * inv), (__bf16)(a[2] * inv), (__bf16)(a[3] * inv)};
-        if (db * 32 + 8 * r4 + 4 * hi < D) op[db * 8 + r4 * 2 + hi] = __builtin_bit_cast(uint2, v);
-      }
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const f32x4_t a = acc[r4];
+      bf16x4_t v = {(__bf16)(a[0] * inv), (__bf16)(a[1] * inv), (__bf16)(a[2] * inv), (__bf16)(a[3] * inv)};
+      if (db * 32 + 8 * r4 + 4 * hi < D) op[db * 8 + r4 * 2 + hi] = __builtin_bit_cast(uint2, v);
+    }
   }
 }
 
@@ -603,7 +599,7 @@ int qp_launch_prefill_attn(const qp_ctx* ctx, const void* q, const void* k_prefi
   int rc = qp_check_launch("prefill_attn");
   if (rc) return rc;
   if (a.nsplit > 1) {
-    attn_combine_kernel<128, false><<<dim3((unsigned)(hkv * (a.items - a.n_whole))), 2 * rows, 0, s>>>(p);
+    attn_combine_kernel<128, false><<<dim3((unsigned)(hkv * (a.items - a.n_whole)), (unsigned)(rows / 32), 4), 64, 0, s>>>(p);
     rc = qp_check_launch("prefill_attn(combine)");
   }
   return rc;
