@@ -155,6 +155,9 @@ int qp_add_rmsnorm(qp_ctx* ctx, void* h, const void* delta, const void* w, void*
 int qp_add_inplace(qp_ctx* ctx, void* h, const void* delta, int64_t n_elems, void* stream);
 /* gate_up bf16 [n][2*inter] (gate columns then up columns) -> out[n][inter] = bf16(bf16(silu(g)) * u). */
 int qp_swiglu(qp_ctx* ctx, const void* gate_up, int64_t n, int inter, void* out, void* stream);
+/* Same with the two projections in separate [n][inter] buffers (hipBLASLt runs two N = inter GEMMs faster than one N = 2*inter
+ * GEMM for 2000 <= n < 4000 rows on this hardware; the engine picks per segment size). */
+int qp_swiglu_split(qp_ctx* ctx, const void* gate, const void* up, int64_t n, int inter, void* out, void* stream);
 
 /* ---- decode step over the pruned cache (qwen25_lvu.py:744-761: HF generate with the LVU cache) -------------------
  * Every per-token scalar lives in a DEVICE state block  state int64[2] = { kv_len, rope_pos }  (rows already in every

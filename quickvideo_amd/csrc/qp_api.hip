@@ -267,7 +267,15 @@ int qp_swiglu(qp_ctx* ctx, const void* gate_up, int64_t n, int inter, void* out,
   QP_REQUIRE(n >= 0 && inter > 0 && inter % 8 == 0, QP_ERR_INVALID, "qp_swiglu: inter=%d must be a multiple of 8", inter);
   QP_REQUIRE(aligned16(gate_up) && aligned16(out), QP_ERR_INVALID, "qp_swiglu: alignment");
   if (n == 0) return QP_OK;
-  return qp_launch_swiglu(gate_up, n, inter, out, (hipStream_t)stream);
+  return qp_launch_swiglu(gate_up, (const uint16_t*)gate_up + inter, 2ll * inter, n, inter, out, (hipStream_t)stream);
+}
+
+int qp_swiglu_split(qp_ctx* ctx, const void* gate, const void* up, int64_t n, int inter, void* out, void* stream) {
+  QP_REQUIRE(ctx && gate && up && out, QP_ERR_INVALID, "qp_swiglu_split: NULL argument");
+  QP_REQUIRE(n >= 0 && inter > 0 && inter % 8 == 0, QP_ERR_INVALID, "qp_swiglu_split: inter=%d must be a multiple of 8", inter);
+  QP_REQUIRE(aligned16(gate) && aligned16(up) && aligned16(out), QP_ERR_INVALID, "qp_swiglu_split: alignment");
+  if (n == 0) return QP_OK;
+  return qp_launch_swiglu(gate, up, inter, n, inter, out, (hipStream_t)stream);
 }
 
 int qp_vit_rope(qp_ctx* ctx, void* qkv, const float* cos, const float* sin, int64_t n, int heads, int head_dim, void* stream) {

@@ -57,7 +57,7 @@ int qp_launch_copy_rows_kv(const void* k_src, const void* v_src, int64_t src_hea
 int qp_launch_add_rmsnorm(void* h, const void* delta, const void* w, void* out, int64_t n, int hidden, float eps,
                           hipStream_t s);
 int qp_launch_add_inplace(void* h, const void* delta, int64_t n_elems, hipStream_t s);
-int qp_launch_swiglu(const void* gate_up, int64_t n, int inter, void* out, hipStream_t s);
+int qp_launch_swiglu(const void* gate, const void* up, int64_t row_elems, int64_t n, int inter, void* out, hipStream_t s);
 int qp_launch_prefill_attn(const qp_ctx* ctx, const void* q, const void* k_prefix, const void* v_prefix,
                            int64_t prefix_head_stride, int64_t prefix_len, const void* k_new, const void* v_new,
                            int64_t new_head_stride, int64_t n, int64_t q_row0, int64_t nq, int hq, int hkv, float scale, void* out,

@@ -89,12 +89,14 @@ __device__ __forceinline__ float silu_mul_bf16(float g, float u) {
   return a * u;
 }
 
-__global__ __launch_bounds__(256) void swiglu_kernel(const uint4* __restrict__ gate_up, int64_t n, int inter16,
-                                                     uint4* __restrict__ out) {
+// gate / up rows of `row16` uint4 each (one fused [n][2*inter] projection: up = gate + inter16, row16 = 2*inter16; two separate
+// [n][inter] projections: row16 = inter16)
+__global__ __launch_bounds__(256) void swiglu_kernel(const uint4* __restrict__ gate, const uint4* __restrict__ up, int64_t row16,
+                                                     int64_t n, int inter16, uint4* __restrict__ out) {
   const int64_t total = n * inter16;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int64_t t = i / inter16, c = i - t * inter16;
-    uint4 g = gate_up[t * 2 * inter16 + c], u = gate_up[t * 2 * inter16 + inter16 + c];
+    uint4 g = gate[t * row16 + c], u = up[t * row16 + c];
     unsigned gw[4] = {g.x, g.y, g.z, g.w}, uw[4] = {u.x, u.y, u.z, u.w}, o[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -106,12 +108,12 @@ __global__ __launch_bounds__(256) void swiglu_kernel(const uint4* __restrict__ g
   }
 }
 
-int qp_launch_swiglu(const void* gate_up, int64_t n, int inter, void* out, hipStream_t s) {
+int qp_launch_swiglu(const void* gate, const void* up, int64_t row_elems, int64_t n, int inter, void* out, hipStream_t s) {
   int64_t total = n * (inter / 8);
   int64_t blocks = (total + 255) / 256;
   if (blocks > 8192) blocks = 8192;
   if (blocks < 1) blocks = 1;
-  swiglu_kernel<<<(int)blocks, 256, 0, s>>>((const uint4*)gate_up, n, inter / 8, (uint4*)out);
+  swiglu_kernel<<<(int)blocks, 256, 0, s>>>((const uint4*)gate, (const uint4*)up, row_elems / 8, n, inter / 8, (uint4*)out);
   return qp_check_launch("swiglu");
 }
 

@@ -56,6 +56,7 @@ SIGNATURES = {
     "qp_add_rmsnorm": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
     "qp_add_inplace": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "qp_swiglu": (_i32, [_vp, _vp, _i64, _i32, _vp, _vp]),
+    "qp_swiglu_split": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp, _vp]),
     "qp_gemv": (_i32, [_vp, _vp, _vp, _vp, _f32, _vp, _vp, _i64, _i64, _i32, _vp]),
     "qp_decode_rope_append": (_i32, [_vp, _vp, _vp, _vp, _vp, _f32, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _vp]),
     "qp_decode_attn_workspace_bytes": (_sz, [_vp, _i32, _i32]),
@@ -210,6 +211,10 @@ class QuickPrefillOps:
     def swiglu(self, gate_up, out):
         n, two_i = gate_up.shape
         self._check(self.lib.qp_swiglu(self.ctx, gate_up.data_ptr(), n, two_i // 2, out.data_ptr(), self._stream()))
+
+    def swiglu_split(self, gate, up, out):
+        n, inter = gate.shape
+        self._check(self.lib.qp_swiglu_split(self.ctx, gate.data_ptr(), up.data_ptr(), n, inter, out.data_ptr(), self._stream()))
 
     # -- decode step (device-resident state int64[2] = {kv_len, rope_pos}; graph-capturable)
     GEMV_BIAS, GEMV_SWIGLU, GEMV_RESIDUAL = 0, 1, 2

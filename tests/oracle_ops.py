@@ -111,6 +111,9 @@ class OracleOps:
     def add_inplace(self, h, delta):
         h.copy_(h + delta)
 
+    def swiglu_split(self, gate, up, out):
+        out.copy_(torch.nn.functional.silu(gate) * up)
+
     def swiglu(self, gate_up, out):
         i = gate_up.shape[1] // 2
         out.copy_(torch.nn.functional.silu(gate_up[:, :i]) * gate_up[:, i:])

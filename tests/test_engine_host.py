@@ -196,3 +196,19 @@ def test_engine_decode_vs_reference_golden(golden_dir, ci):
         assert np.max(np.abs(lg.numpy() - c["decode_logits"][i])) <= tol
         tok = int(torch.argmax(lg))
     assert eng.arena.len == c["cache_len"]
+
+
+def test_split_gate_up_path_equals_fused(monkeypatch):
+    """The engine may run gate and up as two GEMMs (faster in hipBLASLt for some segment sizes): same result as the fused one."""
+    spec_o, w, plan, pos, delta, embeds = make_case(8, 4, 6, 4, 5, 7)
+    cfg = LVUConfig("x", top_p=0.5, video_group_size=4)
+    outs = []
+    for rows in ("1000000,1000001", "0,1000000"):
+        monkeypatch.setenv("QP_SPLIT_GATE_UP_ROWS", rows)
+        eng = QuickPrefillEngine(DecoderWeights.from_named(TINY, w, "cpu"), cfg, capacity=embeds.shape[0] + 8, max_group_tokens=32, device="cpu",
+                                 ops=OracleOps())
+        post, st = torch.from_numpy(pos), 0
+        for n in plan.tokens:
+            eng.prefill_group(embeds[st:st + n], post[:, st:st + n]); st += n
+        outs.append(eng.prefill_tail(embeds[st:], post[:, st:]))
+    assert torch.allclose(outs[0], outs[1], atol=2e-2) and int(outs[0].argmax()) == int(outs[1].argmax())

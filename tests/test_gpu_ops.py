@@ -230,6 +230,16 @@ def test_prefill_attn_transpose_detecting(ops):
     assert (err <= 3e-2 + 1.5e-2 * ref.abs()).all(), err.max().item()
 
 
+def test_swiglu_split_equals_fused(ops):
+    rs = np.random.RandomState(8)
+    for n, inter in ((7, 512), (2880, 18944)):
+        gu = torch.from_numpy(rs.standard_normal((n, 2 * inter)).astype(np.float32) * 2).to(torch.bfloat16).cuda()
+        a, b = torch.empty(n, inter, dtype=torch.bfloat16, device="cuda"), torch.empty(n, inter, dtype=torch.bfloat16, device="cuda")
+        ops.swiglu(gu, a)
+        ops.swiglu_split(gu[:, :inter].contiguous(), gu[:, inter:].contiguous(), b)
+        assert torch.equal(a, b)
+
+
 def test_glue_kernels(ops):
     rs = np.random.RandomState(3)
     for n, hidden, inter in ((5, 256, 512), (33, 3584, 18944), (2, 8192, 29568)):
