@@ -156,7 +156,7 @@ int qp_add_inplace(qp_ctx* ctx, void* h, const void* delta, int64_t n_elems, voi
 /* gate_up bf16 [n][2*inter] (gate columns then up columns) -> out[n][inter] = bf16(bf16(silu(g)) * u). */
 int qp_swiglu(qp_ctx* ctx, const void* gate_up, int64_t n, int inter, void* out, void* stream);
 /* Same with the two projections in separate [n][inter] buffers (hipBLASLt runs two N = inter GEMMs faster than one N = 2*inter
- * GEMM for 2000 <= n < 4000 rows on this hardware; the engine picks per segment size). */
+ * GEMM for some row counts on this hardware; the engine times both once per segment size). */
 int qp_swiglu_split(qp_ctx* ctx, const void* gate, const void* up, int64_t n, int inter, void* out, void* stream);
 
 /* ---- decode step over the pruned cache (qwen25_lvu.py:744-761: HF generate with the LVU cache) -------------------

@@ -110,8 +110,10 @@ class QuickPrefillEngine:
                              f"{sorted(NORM_PRUNE_MODES)}; lvu/utils.py:117-136)")
         self.norm_source, self.norm_order = NORM_PRUNE_MODES[cfg.top_k_predict_type]
         self.ops.set_prune_mode(self.norm_source, self.norm_order)
-        lo, hi = (int(v) for v in os.environ.get("QP_SPLIT_GATE_UP_ROWS", "2000,4000").split(","))   # see _gate_up_swiglu
-        self.split_gate_up_rows = (lo, hi)
+        env = os.environ.get("QP_SPLIT_GATE_UP_ROWS")                                  # developer override, see _gate_up_swiglu
+        self.split_gate_up_rows = tuple(int(v) for v in env.split(",")) if env else None
+        self._tune_gemms = self.device.type == "cuda" and os.environ.get("QP_TUNE_GEMMS", "1") == "1"
+        self._gemm_plans, self._gu_split = {}, {}
         self.kept_trace: Optional[list] = None      # tests: set to [] to record kept indices per (group, layer)
         self.seq_pos = 0                            # tokens of the original sequence consumed so far
 
@@ -120,19 +122,88 @@ class QuickPrefillEngine:
         self.arena.reset()
         self.seq_pos = 0
 
+    # ------------------------------------------------------------------ GEMM decomposition (hipBLASLt shape sensitivity)
+    # hipBLASLt's heuristic is erratic in the row count: at 7B dims the down projection takes 576 us for n = 5760 rows but 940-950 us
+    # for n = 5775..5824 (o_proj 127 vs 185 us), and one fused [n, 2I] gate/up GEMM is 4-7 % slower than two [n, I] GEMMs for
+    # n = 2240..3600 but 7 % faster at 5760 (tools/bench_gemm.py, tools/probe/probe_gate_up_split.py).  So the first time a
+    # segment size shows up (the warm-up step) every projection is timed in a few row decompositions — whole, or rows
+    # [0, floor(n / q) * q) + the remainder for q in (64, 128, 256) — and gate/up also as two GEMMs; the fastest is kept if it wins
+    # by > 3 %.  Rows are independent in a GEMM, so every decomposition computes the same projection (fp32 accumulation order
+    # may differ between kernels, like between any two hipBLASLt algorithms).
+    def _run_linear(self, plan, x, w, out, bias):
+        for r0, r1 in plan:
+            if bias is None:
+                torch.mm(x[r0:r1], w.t(), out=out[r0:r1])
+            else:
+                torch.addmm(bias, x[r0:r1], w.t(), out=out[r0:r1])
+
+    def _time(self, fn) -> float:
+        for _ in range(2):
+            fn()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(4):
+            fn()
+        e.record()
+        e.synchronize()
+        return s.elapsed_time(e) / 4
+
+    def _row_plans(self, n: int):
+        plans = [[(0, n)]]
+        for q in (64, 128, 256):
+            m = n // q * q
+            if 0 < m < n and [(0, m), (m, n)] not in plans:
+                plans.append([(0, m), (m, n)])
+        return plans
+
+    def _linear(self, key: str, x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bias=None):
+        n = x.shape[0]
+        plan = self._gemm_plans.get((key, n))
+        if plan is None:
+            plan = [(0, n)]
+            if self._tune_gemms and n >= 256:
+                best = None
+                for cand in self._row_plans(n):
+                    ms = self._time(lambda: self._run_linear(cand, x, w, out, bias))
+                    if best is None:
+                        best, whole = (ms, cand), ms
+                    elif ms < best[0] and ms < 0.97 * whole:
+                        best = (ms, cand)
+                plan = best[1]
+                if os.environ.get("QP_ENGINE_DEBUG"):
+                    print(f"[engine] {key} n={n}: whole {whole * 1e3:.0f} us -> {plan} {best[0] * 1e3:.0f} us", flush=True)
+            self._gemm_plans[(key, n)] = plan
+        self._run_linear(plan, x, w, out, bias)
+
     def _gate_up_swiglu(self, x2: torch.Tensor, lw, act: torch.Tensor):
-        """act = silu(x2 W_gate^T) * (x2 W_up^T).  One fused [n, 2I] GEMM, or two [n, I] GEMMs where hipBLASLt runs them faster:
-        measured on MI355X (tools/probe/probe_gate_up_split.py, sustained 4-GEMM loop, 7B dims): two GEMMs +7 % / +4 % / +5 % per
-        layer at n = 2240 / 2880 / 3600 rows, -8 % / -7 % at 4320 / 5760, neutral at 720 / 1440.  Same arithmetic either way."""
+        """act = silu(x2 W_gate^T) * (x2 W_up^T) as one fused [n, 2I] GEMM or two [n, I] GEMMs, whichever hipBLASLt runs faster for
+        this row count (see above; QP_SPLIT_GATE_UP_ROWS="lo,hi" forces the two-GEMM form for lo <= n < hi)."""
         n, li = x2.shape[0], self.li
-        if self.split_gate_up_rows[0] <= n < self.split_gate_up_rows[1]:
-            flat = self.b_gu.view(-1)
-            g, u = flat[: n * li].view(n, li), flat[n * li: 2 * n * li].view(n, li)
+        flat = self.b_gu.view(-1)
+        g, u = flat[: n * li].view(n, li), flat[n * li: 2 * n * li].view(n, li)
+        gu = self.b_gu[:n]
+
+        def two():
             torch.mm(x2, lw.w_gate_up[:li].t(), out=g)
             torch.mm(x2, lw.w_gate_up[li:].t(), out=u)
+
+        split = self._gu_split.get(n)
+        if split is None:
+            if self.split_gate_up_rows is not None:
+                split = self.split_gate_up_rows[0] <= n < self.split_gate_up_rows[1]
+            elif self._tune_gemms and n >= 256:
+                t_one = self._time(lambda: torch.mm(x2, lw.w_gate_up.t(), out=gu))
+                t_two = self._time(two)
+                split = t_two < 0.97 * t_one
+                if os.environ.get("QP_ENGINE_DEBUG"):
+                    print(f"[engine] gate_up n={n}: fused {t_one * 1e3:.0f} us, two GEMMs {t_two * 1e3:.0f} us -> {'two' if split else 'fused'}", flush=True)
+            else:
+                split = False
+            self._gu_split[n] = split
+        if split:
+            two()
             self.ops.swiglu_split(g, u, act)
         else:
-            gu = self.b_gu[:n]
             torch.mm(x2, lw.w_gate_up.t(), out=gu)
             self.ops.swiglu(gu, act)
 
@@ -178,7 +249,7 @@ class QuickPrefillEngine:
             x = self.b_x[:n]
             ops.add_rmsnorm(h, delta, lw.ln1, x, s.rms_eps)                  # h += delta; x = RMSNorm(h)   (qwen25_lvu.py:167-169)
             qkv = self.b_qkv[:n]
-            torch.addmm(lw.b_qkv, x, lw.w_qkv.t(), out=qkv)                  # q/k/v proj + bias             (:42-44)
+            self._linear("qkv", x, lw.w_qkv, qkv, lw.b_qkv)                  # q/k/v proj + bias             (:42-44)
             k_keep = effective_k(n, cfg, self.l0 + l, L) if prune else None  # utils.py:231-255
             past = self.arena.len[l]
             assert past + (k_keep if k_keep is not None else n) <= self.arena.capacity, "KV arena overflow"
@@ -201,7 +272,7 @@ class QuickPrefillEngine:
             ops.prefill_attn(q, self.arena.k(l), self.arena.v(l), self.arena.head_stride, past_attn, kn, vn, new_stride, n, self.hq,
                              self.hkv, D, scale, att)                        # :61-62, :102-112
             o = self.b_o[:n]
-            torch.mm(att.view(n, self.hq * D), lw.w_o.t(), out=o)            # o_proj                        (:114-115)
+            self._linear("o", att.view(n, self.hq * D), lw.w_o, o)           # o_proj                        (:114-115)
             self._all_reduce(o)
             prune_hidden = (k_keep is not None and cfg.enable and isinstance(cfg.prefill_prune_starting_layer, int)
                             and cfg.prefill_prune_starting_layer >= 0 and l >= cfg.prefill_prune_starting_layer)
@@ -234,7 +305,7 @@ class QuickPrefillEngine:
             act = self.b_act[:n]
             self._gate_up_swiglu(x2, lw, act)                                # gate & up, act(gate) * up      (:197)
             dn = self.b_dn[:n]
-            torch.mm(act, lw.w_down.t(), out=dn)
+            self._linear("down", act, lw.w_down, dn)
             self._all_reduce(dn)
             delta = dn
         ops.add_inplace(h, delta)                                            # last residual                  (:198)
@@ -281,7 +352,7 @@ class QuickPrefillEngine:
             x = self.b_x[:ml]
             ops.add_rmsnorm(h, delta, lw.ln1, x, s.rms_eps)
             qkv = self.b_qkv[:ml]
-            torch.addmm(lw.b_qkv, x, lw.w_qkv.t(), out=qkv)
+            self._linear("qkv", x, lw.w_qkv, qkv, lw.b_qkv)
             k_keep = effective_k(n, cfg, self.l0 + l, L) if prune else None
             past = self.arena.len[l]
             assert past + (k_keep if k_keep is not None else n) <= self.arena.capacity, "KV arena overflow"
@@ -304,7 +375,7 @@ class QuickPrefillEngine:
                     ops.prefill_attn(q[lo_:hi_], self.arena.k(l), self.arena.v(l), self.arena.head_stride, past_attn, kn, vn, new_stride,
                                      n, self.hq, self.hkv, D, scale, att[lo_:hi_], q_row0=q0, nq=hi_ - lo_)
             o = self.b_o[:ml]
-            torch.mm(att.view(ml, self.hq * D), lw.w_o.t(), out=o)
+            self._linear("o", att.view(ml, self.hq * D), lw.w_o, o)
             if k_keep is not None:
                 idx = self.b_idx[:k_keep]
                 ops.prune_staged(ss_all, self.hkv, n, k_keep, kn, vn, new_stride, self.hkv, D, self.arena.k(l), self.arena.v(l),
@@ -323,7 +394,7 @@ class QuickPrefillEngine:
             act = self.b_act[:ml]
             self._gate_up_swiglu(x2, lw, act)
             dn = self.b_dn[:ml]
-            torch.mm(act, lw.w_down.t(), out=dn)
+            self._linear("down", act, lw.w_down, dn)
             delta = dn
         ops.add_inplace(h, delta)
         return h
