@@ -127,7 +127,7 @@ class QuickPrefillEngine:
     # for n = 5775..5824 (o_proj 127 vs 185 us), and one fused [n, 2I] gate/up GEMM is 4-7 % slower than two [n, I] GEMMs for
     # n = 2240..3600 but 7 % faster at 5760 (tools/bench_gemm.py, tools/probe/probe_gate_up_split.py).  So the first time a
     # segment size shows up (the warm-up step) every projection is timed in a few row decompositions — whole, or rows
-    # [0, floor(n / q) * q) + the remainder for q in (64, 128, 256) — and gate/up also as two GEMMs; the fastest is kept if it wins
+    # [0, floor(n / q) * q) + the remainder for q in (64, ..., 4096) — and gate/up also as two GEMMs; the fastest is kept if it wins
     # by > 3 %.  Rows are independent in a GEMM, so every decomposition computes the same projection (fp32 accumulation order
     # may differ between kernels, like between any two hipBLASLt algorithms).
     def _run_linear(self, plan, x, w, out, bias):
@@ -150,7 +150,7 @@ class QuickPrefillEngine:
 
     def _row_plans(self, n: int):
         plans = [[(0, n)]]
-        for q in (64, 128, 256):
+        for q in (64, 128, 256, 512, 1024, 2048, 4096):
             m = n // q * q
             if 0 < m < n and [(0, m), (m, n)] not in plans:
                 plans.append([(0, m), (m, n)])
@@ -176,35 +176,45 @@ class QuickPrefillEngine:
         self._run_linear(plan, x, w, out, bias)
 
     def _gate_up_swiglu(self, x2: torch.Tensor, lw, act: torch.Tensor):
-        """act = silu(x2 W_gate^T) * (x2 W_up^T) as one fused [n, 2I] GEMM or two [n, I] GEMMs, whichever hipBLASLt runs faster for
-        this row count (see above; QP_SPLIT_GATE_UP_ROWS="lo,hi" forces the two-GEMM form for lo <= n < hi)."""
+        """act = silu(x2 W_gate^T) * (x2 W_up^T) as one fused [n, 2I] GEMM or two [n, I] GEMMs, each whole or in the row decompositions
+        of _row_plans, whichever hipBLASLt runs fastest for this row count (see above; QP_SPLIT_GATE_UP_ROWS="lo,hi" forces the
+        whole-rows two-GEMM form for lo <= n < hi)."""
         n, li = x2.shape[0], self.li
         flat = self.b_gu.view(-1)
         g, u = flat[: n * li].view(n, li), flat[n * li: 2 * n * li].view(n, li)
         gu = self.b_gu[:n]
 
-        def two():
-            torch.mm(x2, lw.w_gate_up[:li].t(), out=g)
-            torch.mm(x2, lw.w_gate_up[li:].t(), out=u)
+        def run(two, plan):
+            for r0, r1 in plan:
+                if two:
+                    torch.mm(x2[r0:r1], lw.w_gate_up[:li].t(), out=g[r0:r1])
+                    torch.mm(x2[r0:r1], lw.w_gate_up[li:].t(), out=u[r0:r1])
+                else:
+                    torch.mm(x2[r0:r1], lw.w_gate_up.t(), out=gu[r0:r1])
 
-        split = self._gu_split.get(n)
-        if split is None:
+        choice = self._gu_split.get(n)
+        if choice is None:
+            choice = (False, [(0, n)])
             if self.split_gate_up_rows is not None:
-                split = self.split_gate_up_rows[0] <= n < self.split_gate_up_rows[1]
+                choice = (self.split_gate_up_rows[0] <= n < self.split_gate_up_rows[1], [(0, n)])
             elif self._tune_gemms and n >= 256:
-                t_one = self._time(lambda: torch.mm(x2, lw.w_gate_up.t(), out=gu))
-                t_two = self._time(two)
-                split = t_two < 0.97 * t_one
+                whole = best = self._time(lambda: run(False, [(0, n)]))
+                for two in (False, True):
+                    for plan in self._row_plans(n):
+                        if not two and plan == [(0, n)]:
+                            continue
+                        ms = self._time(lambda: run(two, plan))
+                        if ms < best and ms < 0.97 * whole:
+                            best, choice = ms, (two, plan)
                 if os.environ.get("QP_ENGINE_DEBUG"):
-                    print(f"[engine] gate_up n={n}: fused {t_one * 1e3:.0f} us, two GEMMs {t_two * 1e3:.0f} us -> {'two' if split else 'fused'}", flush=True)
-            else:
-                split = False
-            self._gu_split[n] = split
-        if split:
-            two()
+                    print(f"[engine] gate_up n={n}: fused whole {whole * 1e3:.0f} us -> {'two GEMMs' if choice[0] else 'fused'} {choice[1]} "
+                          f"{best * 1e3:.0f} us", flush=True)
+            self._gu_split[n] = choice
+        two, plan = choice
+        run(two, plan)
+        if two:
             self.ops.swiglu_split(g, u, act)
         else:
-            torch.mm(x2, lw.w_gate_up.t(), out=gu)
             self.ops.swiglu(gu, act)
 
     def _all_reduce(self, t: torch.Tensor):
