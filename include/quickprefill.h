@@ -207,6 +207,13 @@ int qp_vit_attn(qp_ctx* ctx, const void* qkv, int64_t n_seq, int64_t seq_len, in
  * out = bf16((x - mean) * rstd * w + b) with fp32 statistics over the row (torch layer_norm).  x, delta, out bf16 [n][hidden]. */
 int qp_add_layernorm(qp_ctx* ctx, void* x, const void* delta, const void* w, const void* b, void* out, int64_t n, int hidden,
                      float eps, void* stream);
+/* out[m][n] = act(alpha * x[m][k] W[n][k]^T + bias[n]) as ONE hipBLASLt GEMM with the activation in its epilogue (act: 0 none,
+ * 1 Swish z*sigmoid(z) = SiLU): fp32 accumulate + bias + activation, one rounding to bf16.  bias: bf16, or fp32 when bias_f32,
+ * or NULL.  quick-GELU (y*sigmoid(1.702 y), the vision MLP's fc1): alpha = 1.702, bias pre-scaled by 1.702, act = 1 gives
+ * 1.702*quick_gelu(y); the 1/1.702 goes onto the alpha of the next GEMM.  workspace: caller-owned scratch for hipBLASLt (128 MB
+ * covers every shape tried; the call fails with QP_ERR_WORKSPACE if the chosen algorithm wants more). */
+int qp_linear_act(qp_ctx* ctx, const void* x, const void* w, const void* bias, int bias_f32, float alpha, void* out, int64_t m,
+                  int64_t n, int64_t k, int act, void* workspace, size_t workspace_bytes, void* stream);
 /* out = y * sigmoid(1.702 y) with torch's bf16 rounding steps (hidden_act = quick_gelu). */
 int qp_quick_gelu(qp_ctx* ctx, const void* x, void* out, int64_t n_elems, void* stream);
 

@@ -314,6 +314,17 @@ int qp_add_layernorm(qp_ctx* ctx, void* x, const void* delta, const void* w, con
   return qp_launch_add_layernorm(x, delta, w, b, out, n, hidden, eps, (hipStream_t)stream);
 }
 
+int qp_linear_act(qp_ctx* ctx, const void* x, const void* w, const void* bias, int bias_f32, float alpha, void* out, int64_t m,
+                  int64_t n, int64_t k, int act, void* workspace, size_t workspace_bytes, void* stream) {
+  QP_REQUIRE(ctx && x && w && out, QP_ERR_INVALID, "qp_linear_act: NULL argument");
+  QP_REQUIRE(m > 0 && n > 0 && k > 0 && k % 8 == 0 && n % 8 == 0, QP_ERR_INVALID, "qp_linear_act: m=%lld n=%lld k=%lld (n, k multiples of 8)",
+             (long long)m, (long long)n, (long long)k);
+  QP_REQUIRE(act >= 0 && act <= 1, QP_ERR_INVALID, "qp_linear_act: act=%d (0 none, 1 Swish z*sigmoid(z))", act);
+  QP_REQUIRE(aligned16(x) && aligned16(w) && aligned16(out) && (!bias || aligned16(bias)) && (!workspace || aligned16(workspace)),
+             QP_ERR_INVALID, "qp_linear_act: alignment");
+  return qp_launch_linear_act(x, w, bias, bias_f32, alpha, out, m, n, k, act, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
 // ---- decode step (qp_decode.hip) ------------------------------------------------------------------------------------
 int qp_gemv(qp_ctx* ctx, const void* w, const void* x, const void* norm_w, float eps, const void* bias, void* out,
             int64_t n_out, int64_t k, int mode, void* stream) {

@@ -1,0 +1,96 @@
+// out = act(alpha * x W^T + b) for a bf16 Linear through hipBLASLt with the activation in the GEMM EPILOGUE (plain library GEMM, no
+// own kernel).  The vision tower's fc1 + quick-GELU (transformers VisionMlp [3P]: QuickGELUActivation, y * sigmoid(1.702 y)) becomes
+// ONE GEMM: with alpha = 1.702 and the bias pre-scaled by 1.702 the Swish epilogue (z * sigmoid(z)) yields 1.702 * quick_gelu(y), and
+// the factor 1/1.702 rides on the alpha of the fc2 GEMM — the [n, 5120] intermediate is never re-read and re-written by a separate
+// activation kernel.  fp32 accumulation + bias + activation, ONE rounding to bf16 (the unfused path rounds after the bias and
+// inside the activation: results agree to a bf16 ulp or two).  (The process runs torch's bundled hipBLASLt, ROCm 7.0: its
+// Swish epilogue has no slope argument, hence the alpha route.)
+// Row-major x [m][k], W [n][k] (a torch Linear weight), out [m][n]  ==  column-major  D[n x m] = op_T(W[k x n]) * x[k x m].
+#include "qp_common.h"
+#include <hipblaslt/hipblaslt.h>
+#include <map>
+#include <mutex>
+#include <tuple>
+
+namespace {
+
+struct Plan {
+  hipblasLtMatmulDesc_t desc = nullptr;
+  hipblasLtMatrixLayout_t a = nullptr, b = nullptr, d = nullptr;
+  hipblasLtMatmulAlgo_t algo;
+  size_t ws = 0;
+};
+
+struct LtState {
+  hipblasLtHandle_t handle = nullptr;
+  std::map<std::tuple<int64_t, int64_t, int64_t, int, int>, Plan> plans;   // (m, n, k, act, bias kind: 0 none, 1 bf16, 2 fp32)
+  std::mutex mu;
+};
+
+LtState& lt() {
+  static LtState s;
+  return s;
+}
+
+#define LT_CHECK(call)                                                                                     \
+  do {                                                                                                     \
+    hipblasStatus_t st_ = (call);                                                                          \
+    if (st_ != HIPBLAS_STATUS_SUCCESS) return qp_fail(QP_ERR_HIP, "qp_linear_act: %s failed (%d)", #call, (int)st_); \
+  } while (0)
+
+int make_plan(Plan& p, int64_t m, int64_t n, int64_t k, int act, int bias_kind, size_t max_ws) {
+  const bool has_bias = bias_kind != 0;
+  LT_CHECK(hipblasLtMatmulDescCreate(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F));
+  const hipblasOperation_t ta = HIPBLAS_OP_T, tb = HIPBLAS_OP_N;
+  LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSA, &ta, sizeof(ta)));
+  LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_TRANSB, &tb, sizeof(tb)));
+  hipblasLtEpilogue_t epi = HIPBLASLT_EPILOGUE_DEFAULT;
+  if (act == 0) epi = has_bias ? HIPBLASLT_EPILOGUE_BIAS : HIPBLASLT_EPILOGUE_DEFAULT;
+  else epi = has_bias ? HIPBLASLT_EPILOGUE_SWISH_BIAS_EXT : HIPBLASLT_EPILOGUE_SWISH_EXT;
+  LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_EPILOGUE, &epi, sizeof(epi)));
+  if (has_bias) {
+    const hipDataType bt = bias_kind == 2 ? HIP_R_32F : HIP_R_16BF;
+    LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE, &bt, sizeof(bt)));
+  }
+  LT_CHECK(hipblasLtMatrixLayoutCreate(&p.a, HIP_R_16BF, k, n, k));      // W: column-major [k x n], ld k
+  LT_CHECK(hipblasLtMatrixLayoutCreate(&p.b, HIP_R_16BF, k, m, k));      // x: column-major [k x m], ld k
+  LT_CHECK(hipblasLtMatrixLayoutCreate(&p.d, HIP_R_16BF, n, m, n));      // out: column-major [n x m], ld n
+  hipblasLtMatmulPreference_t pref;
+  LT_CHECK(hipblasLtMatmulPreferenceCreate(&pref));
+  const uint64_t ws64 = max_ws;
+  LT_CHECK(hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &ws64, sizeof(ws64)));
+  hipblasLtMatmulHeuristicResult_t res[4];
+  int found = 0;
+  hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(lt().handle, p.desc, p.a, p.b, p.d, p.d, pref, 4, res, &found);
+  hipblasLtMatmulPreferenceDestroy(pref);
+  if (st != HIPBLAS_STATUS_SUCCESS || found < 1)
+    return qp_fail(QP_ERR_UNSUPPORTED, "qp_linear_act: hipBLASLt has no algorithm for m=%lld n=%lld k=%lld act=%d (status %d)", (long long)m,
+                   (long long)n, (long long)k, act, (int)st);
+  p.algo = res[0].algo;
+  p.ws = res[0].workspaceSize;
+  return QP_OK;
+}
+
+}  // namespace
+
+int qp_launch_linear_act(const void* x, const void* w, const void* bias, int bias_f32, float alpha, void* out, int64_t m, int64_t n,
+                         int64_t k, int act, void* workspace, size_t workspace_bytes, hipStream_t s) {
+  LtState& st = lt();
+  std::lock_guard<std::mutex> g(st.mu);
+  if (!st.handle) LT_CHECK(hipblasLtCreate(&st.handle));
+  const int bias_kind = bias ? (bias_f32 ? 2 : 1) : 0;
+  const auto key = std::make_tuple(m, n, k, act, bias_kind);
+  auto it = st.plans.find(key);
+  if (it == st.plans.end()) {
+    Plan p;
+    int rc = make_plan(p, m, n, k, act, bias_kind, workspace_bytes);
+    if (rc) return rc;
+    it = st.plans.emplace(key, p).first;
+  }
+  Plan& p = it->second;
+  if (p.ws > workspace_bytes) return qp_fail(QP_ERR_WORKSPACE, "qp_linear_act: workspace %zu < %zu bytes", workspace_bytes, p.ws);
+  if (bias) LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)));
+  const float beta = 0.f;
+  LT_CHECK(hipblasLtMatmul(st.handle, p.desc, &alpha, w, p.a, x, p.b, &beta, out, p.d, out, p.d, &p.algo, workspace, workspace_bytes, s));
+  return QP_OK;
+}

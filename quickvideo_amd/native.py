@@ -66,6 +66,7 @@ SIGNATURES = {
     "qp_vit_rope": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "qp_vit_attn": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _f32, _vp, _vp]),
     "qp_quick_gelu": (_i32, [_vp, _vp, _vp, _i64, _vp]),
+    "qp_linear_act": (_i32, [_vp, _vp, _vp, _vp, _i32, _f32, _vp, _i64, _i64, _i64, _i32, _vp, _sz, _vp]),
     "qp_add_layernorm": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
 }
 
@@ -259,6 +260,18 @@ class QuickPrefillOps:
         n, hidden = x.shape
         self._check(self.lib.qp_add_layernorm(self.ctx, x.data_ptr(), _ptr(delta), w.data_ptr(), b.data_ptr(), out.data_ptr(), n, hidden,
                                               float(eps), self._stream()))
+
+    ACT_NONE, ACT_SWISH = 0, 1
+
+    def linear_act(self, x, w, bias, out, act, alpha=1.0):
+        """out = act(alpha * x w^T + bias) as one hipBLASLt GEMM with the activation in the epilogue (bias bf16 or fp32)."""
+        m, k = x.shape
+        n = w.shape[0]
+        if getattr(self, "_lt_ws", None) is None:
+            self._lt_ws = torch.empty(128 << 20, dtype=torch.uint8, device=self.device)
+        f32 = 1 if (bias is not None and bias.dtype == torch.float32) else 0
+        self._check(self.lib.qp_linear_act(self.ctx, x.data_ptr(), w.data_ptr(), _ptr(bias), f32, float(alpha), out.data_ptr(), m, n, k, act,
+                                           self._lt_ws.data_ptr(), self._lt_ws.numel(), self._stream()))
 
     def quick_gelu(self, x, out):
         self._check(self.lib.qp_quick_gelu(self.ctx, x.data_ptr(), out.data_ptr(), x.numel(), self._stream()))

@@ -158,6 +158,10 @@ def _rotate_half(x):
     return torch.cat((-x[..., h:], x[..., :h]), dim=-1)
 
 
+def b_contig(w) -> bool:
+    return all(blk.fc1_w.is_contiguous() and blk.fc2_w.is_contiguous() for blk in w.blocks)
+
+
 class VisionTower:
     """Stateless forward over VisionWeights; runs on whatever device the weights live on (MI355X in the product)."""
 
@@ -190,6 +194,8 @@ class VisionTower:
                     and os.environ.get("QP_VIT_FUSED_LN", "1") == "1")               # developer A/B switch (tools/bench_vit.py)
         pend = None                                   # residual branch not yet added to x (fused into the next LayerNorm launch)
         ybuf = torch.empty_like(x) if fused_ln else None
+        fused_act = (ops is not None and hasattr(ops, "linear_act") and os.environ.get("QP_VIT_FUSED_ACT", "1") == "1"
+                     and x.is_cuda and b_contig(w))
 
         def norm(wt, bs):
             """x += pending residual; LayerNorm(x)  (Qwen2VLVisionBlock: x = x + attn(norm1(x)); x = x + mlp(norm2(x)))"""
@@ -222,6 +228,14 @@ class VisionTower:
                 a = a.transpose(1, 2).reshape(n, H * hd)
             pend = F.linear(a, b.proj_w, b.proj_b)
             y = norm(b.ln2_w, b.ln2_b)
+            if fused_act:
+                # fc1 + quick-GELU in ONE GEMM: Swish epilogue on 1.702 (y W1^T + b1) = 1.702 quick_gelu(.), the 1/1.702 rides on fc2's alpha
+                if getattr(b, "_fc1_b_scaled", None) is None:
+                    b._fc1_b_scaled = (b.fc1_b.float() * 1.702).contiguous()
+                z = torch.empty(n, b.fc1_w.shape[0], dtype=x.dtype, device=x.device)
+                ops.linear_act(y.contiguous(), b.fc1_w, b._fc1_b_scaled, z, ops.ACT_SWISH, alpha=1.702)
+                pend = torch.addmm(b.fc2_b, z, b.fc2_w.t(), alpha=1.0 / 1.702)
+                continue
             y = F.linear(y, b.fc1_w, b.fc1_b)
             if ops is not None:
                 ops.quick_gelu(y, y)

@@ -230,6 +230,26 @@ def test_prefill_attn_transpose_detecting(ops):
     assert (err <= 3e-2 + 1.5e-2 * ref.abs()).all(), err.max().item()
 
 
+def test_linear_act_epilogue(ops):
+    """hipBLASLt GEMM with bias / Swish epilogue and alpha (the vision MLP's fc1 + quick-GELU in one GEMM) vs an fp32 reference:
+    one bf16 rounding of the fused result => within 1 ulp + the fp32 accumulation-order noise."""
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    for (m, n, k) in ((23040, 5120, 1280), (77, 64, 32), (300, 1280, 5120)):
+        x = torch.randn(m, k, generator=g, device="cuda").to(torch.bfloat16)
+        w = (torch.randn(n, k, generator=g, device="cuda") * 0.05).to(torch.bfloat16)
+        b = torch.randn(n, generator=g, device="cuda").to(torch.bfloat16)
+        y = torch.nn.functional.linear(x.float(), w.float(), b.float())
+        cases = ((ops.ACT_NONE, 1.0, b, y), (ops.ACT_NONE, 1.0, None, y - b.float()), (ops.ACT_SWISH, 1.0, b, torch.nn.functional.silu(y)),
+                 (ops.ACT_SWISH, 1.702, b.float() * 1.702, 1.702 * y * torch.sigmoid(1.702 * y)))
+        for act, alpha, bias, ref in cases:
+            out = torch.empty(m, n, dtype=torch.bfloat16, device="cuda")
+            ops.linear_act(x, w, bias, out, act, alpha)
+            err = (out.float() - ref).abs()
+            assert (err <= 2.0 ** -7 * ref.abs() + 2e-2).all(), (m, n, k, act, alpha, err.max().item())
+    with pytest.raises(ValueError):
+        ops.linear_act(x, w, None, out, 7)
+
+
 def test_swiglu_split_equals_fused(ops):
     rs = np.random.RandomState(8)
     for n, inter in ((7, 512), (2880, 18944)):
