@@ -214,6 +214,12 @@ int qp_add_layernorm(qp_ctx* ctx, void* x, const void* delta, const void* w, con
  * covers every shape tried; the call fails with QP_ERR_WORKSPACE if the chosen algorithm wants more). */
 int qp_linear_act(qp_ctx* ctx, const void* x, const void* w, const void* bias, int bias_f32, float alpha, void* out, int64_t m,
                   int64_t n, int64_t k, int act, void* workspace, size_t workspace_bytes, void* stream);
+/* Picks the hipBLASLt algorithm later qp_linear_act calls of this (m, n, k, act, bias kind) use: every heuristic candidate is timed
+ * over `weights[0..n_weights)` (HOST array of device pointers to the same projection of several layers, visited round-robin so
+ * the weights are cold like in the layer loop) and the fastest is kept.  For skinny problems (prompt tail, m = 30) the default
+ * pick can be 2x off.  SYNCHRONISES `stream` (the only entry point that does); `out` is scratch. */
+int qp_linear_tune(qp_ctx* ctx, const void* x, const void* const* weights, int n_weights, const void* bias, int bias_f32, float alpha,
+                   void* out, int64_t m, int64_t n, int64_t k, int act, void* workspace, size_t workspace_bytes, void* stream);
 /* out = y * sigmoid(1.702 y) with torch's bf16 rounding steps (hidden_act = quick_gelu). */
 int qp_quick_gelu(qp_ctx* ctx, const void* x, void* out, int64_t n_elems, void* stream);
 

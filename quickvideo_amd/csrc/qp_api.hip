@@ -325,6 +325,17 @@ int qp_linear_act(qp_ctx* ctx, const void* x, const void* w, const void* bias, i
   return qp_launch_linear_act(x, w, bias, bias_f32, alpha, out, m, n, k, act, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
+int qp_linear_tune(qp_ctx* ctx, const void* x, const void* const* weights, int n_weights, const void* bias, int bias_f32, float alpha,
+                   void* out, int64_t m, int64_t n, int64_t k, int act, void* workspace, size_t workspace_bytes, void* stream) {
+  QP_REQUIRE(ctx && x && weights && out && n_weights > 0, QP_ERR_INVALID, "qp_linear_tune: NULL argument");
+  QP_REQUIRE(m > 0 && n > 0 && k > 0 && k % 8 == 0 && n % 8 == 0, QP_ERR_INVALID, "qp_linear_tune: m=%lld n=%lld k=%lld", (long long)m,
+             (long long)n, (long long)k);
+  QP_REQUIRE(act >= 0 && act <= 1, QP_ERR_INVALID, "qp_linear_tune: act=%d", act);
+  for (int i = 0; i < n_weights; ++i) QP_REQUIRE(weights[i] && aligned16(weights[i]), QP_ERR_INVALID, "qp_linear_tune: weight %d", i);
+  return qp_launch_linear_tune(x, weights, n_weights, bias, bias_f32, alpha, out, m, n, k, act, workspace, workspace_bytes,
+                               (hipStream_t)stream, nullptr);
+}
+
 // ---- decode step (qp_decode.hip) ------------------------------------------------------------------------------------
 int qp_gemv(qp_ctx* ctx, const void* w, const void* x, const void* norm_w, float eps, const void* bias, void* out,
             int64_t n_out, int64_t k, int mode, void* stream) {

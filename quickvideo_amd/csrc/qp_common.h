@@ -83,5 +83,7 @@ int qp_launch_decode_attn_fused(const qp_ctx* ctx, const void* qkv, const void* 
                                 int64_t head_stride, const int64_t* state, int hq, int hkv, float scale, void* out, void* workspace,
                                 hipStream_t s);
 int qp_launch_decode_advance(int64_t* state, int n, hipStream_t s);
+int qp_launch_linear_tune(const void* x, const void* const* ws_list, int n_ws, const void* bias, int bias_f32, float alpha, void* out,
+                          int64_t m, int64_t n, int64_t k, int act, void* workspace, size_t workspace_bytes, hipStream_t s, int* chosen);
 int qp_launch_linear_act(const void* x, const void* w, const void* bias, int bias_f32, float alpha, void* out, int64_t m, int64_t n,
                          int64_t k, int act, void* workspace, size_t workspace_bytes, hipStream_t s);

@@ -8,9 +8,12 @@
 // Row-major x [m][k], W [n][k] (a torch Linear weight), out [m][n]  ==  column-major  D[n x m] = op_T(W[k x n]) * x[k x m].
 #include "qp_common.h"
 #include <hipblaslt/hipblaslt.h>
+#include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <tuple>
+#include <vector>
 
 namespace {
 
@@ -19,6 +22,7 @@ struct Plan {
   hipblasLtMatrixLayout_t a = nullptr, b = nullptr, d = nullptr;
   hipblasLtMatmulAlgo_t algo;
   size_t ws = 0;
+  std::vector<hipblasLtMatmulHeuristicResult_t> cands;         // every heuristic candidate (qp_linear_tune picks among them)
 };
 
 struct LtState {
@@ -59,15 +63,20 @@ int make_plan(Plan& p, int64_t m, int64_t n, int64_t k, int act, int bias_kind, 
   LT_CHECK(hipblasLtMatmulPreferenceCreate(&pref));
   const uint64_t ws64 = max_ws;
   LT_CHECK(hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &ws64, sizeof(ws64)));
-  hipblasLtMatmulHeuristicResult_t res[4];
+  hipblasLtMatmulHeuristicResult_t res[32];
   int found = 0;
-  hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(lt().handle, p.desc, p.a, p.b, p.d, p.d, pref, 4, res, &found);
+  hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(lt().handle, p.desc, p.a, p.b, p.d, p.d, pref, 32, res, &found);
   hipblasLtMatmulPreferenceDestroy(pref);
   if (st != HIPBLAS_STATUS_SUCCESS || found < 1)
     return qp_fail(QP_ERR_UNSUPPORTED, "qp_linear_act: hipBLASLt has no algorithm for m=%lld n=%lld k=%lld act=%d (status %d)", (long long)m,
                    (long long)n, (long long)k, act, (int)st);
-  p.algo = res[0].algo;
-  p.ws = res[0].workspaceSize;
+  int pick = 0;                                                // developer probe: QP_LT_ALGO_INDEX = i-th heuristic candidate
+  if (const char* e = getenv("QP_LT_ALGO_INDEX")) { pick = atoi(e); if (pick >= found) pick = found - 1; if (pick < 0) pick = 0; }
+  if (getenv("QP_LT_DEBUG")) fprintf(stderr, "[qp_linear_act] m=%lld n=%lld k=%lld act=%d: %d candidates, using %d (ws %zu)\n", (long long)m,
+                                     (long long)n, (long long)k, act, found, pick, res[pick].workspaceSize);
+  p.algo = res[pick].algo;
+  p.ws = res[pick].workspaceSize;
+  p.cands.assign(res, res + found);
   return QP_OK;
 }
 
@@ -92,5 +101,54 @@ int qp_launch_linear_act(const void* x, const void* w, const void* bias, int bia
   if (bias) LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)));
   const float beta = 0.f;
   LT_CHECK(hipblasLtMatmul(st.handle, p.desc, &alpha, w, p.a, x, p.b, &beta, out, p.d, out, p.d, &p.algo, workspace, workspace_bytes, s));
+  return QP_OK;
+}
+
+// Times every heuristic candidate of this problem with COLD weights — the caller passes the same projection of several layers,
+// visited round-robin, because a skinny GEMM re-reading one hot weight matrix is served by the Infinity Cache and ranks the
+// candidates differently (prompt tail, M = 30, 7B dims: down projection 110 us with the default pick, 47 us with the best) —
+// and keeps the fastest for later qp_linear_act calls of the same (m, n, k, act, bias kind).  Synchronises the stream.
+int qp_launch_linear_tune(const void* x, const void* const* ws_list, int n_ws, const void* bias, int bias_f32, float alpha, void* out,
+                          int64_t m, int64_t n, int64_t k, int act, void* workspace, size_t workspace_bytes, hipStream_t s, int* chosen) {
+  LtState& st = lt();
+  std::lock_guard<std::mutex> g(st.mu);
+  if (!st.handle) LT_CHECK(hipblasLtCreate(&st.handle));
+  const int bias_kind = bias ? (bias_f32 ? 2 : 1) : 0;
+  const auto key = std::make_tuple(m, n, k, act, bias_kind);
+  auto it = st.plans.find(key);
+  if (it == st.plans.end()) {
+    Plan p;
+    int rc = make_plan(p, m, n, k, act, bias_kind, workspace_bytes);
+    if (rc) return rc;
+    it = st.plans.emplace(key, p).first;
+  }
+  Plan& p = it->second;
+  if (bias) LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)));
+  const float beta = 0.f;
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return qp_fail(QP_ERR_HIP, "qp_linear_tune: hipEventCreate");
+  float best = 1e30f;
+  int best_i = -1;
+  for (int c = 0; c < (int)p.cands.size(); ++c) {
+    if (p.cands[c].workspaceSize > workspace_bytes) continue;
+    bool ok = true;
+    for (int rep = -2; rep < n_ws && ok; ++rep) {               // two untimed runs, then one pass over the weight list
+      if (rep == 0) (void)hipEventRecord(e0, s);
+      const void* w = ws_list[(rep + 2 * n_ws) % n_ws];
+      ok = hipblasLtMatmul(st.handle, p.desc, &alpha, w, p.a, x, p.b, &beta, out, p.d, out, p.d, &p.cands[c].algo, workspace, workspace_bytes,
+                           s) == HIPBLAS_STATUS_SUCCESS;
+    }
+    (void)hipEventRecord(e1, s);
+    if (hipEventSynchronize(e1) != hipSuccess) ok = false;
+    float ms = 0.f;
+    if (ok && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms < best) { best = ms; best_i = c; }
+  }
+  (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  if (best_i < 0) return qp_fail(QP_ERR_HIP, "qp_linear_tune: no candidate ran");
+  p.algo = p.cands[best_i].algo;
+  p.ws = p.cands[best_i].workspaceSize;
+  if (chosen) *chosen = best_i;
+  if (getenv("QP_LT_DEBUG")) fprintf(stderr, "[qp_linear_tune] m=%lld n=%lld k=%lld: candidate %d of %zu, %.1f us per call\n", (long long)m,
+                                     (long long)n, (long long)k, best_i, p.cands.size(), best * 1e3f / n_ws);
   return QP_OK;
 }

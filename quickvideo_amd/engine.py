@@ -113,7 +113,7 @@ class QuickPrefillEngine:
         env = os.environ.get("QP_SPLIT_GATE_UP_ROWS")                                  # developer override, see _gate_up_swiglu
         self.split_gate_up_rows = tuple(int(v) for v in env.split(",")) if env else None
         self._tune_gemms = self.device.type == "cuda" and os.environ.get("QP_TUNE_GEMMS", "1") == "1"
-        self._gemm_plans, self._gu_split = {}, {}
+        self._gemm_plans, self._gu_split, self._lt_tuned = {}, {}, {}
         self.kept_trace: Optional[list] = None      # tests: set to [] to record kept indices per (group, layer)
         self.seq_pos = 0                            # tokens of the original sequence consumed so far
 
@@ -156,8 +156,31 @@ class QuickPrefillEngine:
                 plans.append([(0, m), (m, n)])
         return plans
 
+    def _small_linear(self, key: str, x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bias=None) -> bool:
+        """Segments of a few dozen rows (prompt tail, eager decode): the GEMM is a pass over the weights and hipBLASLt's default pick
+        streams them at 1.2-2.4 TB/s when they are cold; the library times all of its candidates over every layer's copy of this
+        projection once (qp_linear_tune) and qp_linear_act then runs the fastest (down projection at 30 rows: 110 -> 47 us)."""
+        n = x.shape[0]
+        if not (self._tune_gemms and n < 256 and hasattr(self.ops, "linear_tune") and x.is_contiguous() and w.is_contiguous()):
+            return False
+        if (key, n) not in self._lt_tuned:
+            ws = [getattr(lw, self._WKEY[key]) for lw in self.w.layers]
+            try:
+                self.ops.linear_tune(x, ws, bias, out, self.ops.ACT_NONE)
+                self._lt_tuned[(key, n)] = True
+            except Exception:                         # no usable candidate: stay on torch.mm for this shape
+                self._lt_tuned[(key, n)] = False
+        if not self._lt_tuned[(key, n)]:
+            return False
+        self.ops.linear_act(x, w, bias, out, self.ops.ACT_NONE)
+        return True
+
+    _WKEY = {"qkv": "w_qkv", "o": "w_o", "gate_up": "w_gate_up", "down": "w_down"}
+
     def _linear(self, key: str, x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bias=None):
         n = x.shape[0]
+        if n < 256 and self._small_linear(key, x, w, out, bias):
+            return
         plan = self._gemm_plans.get((key, n))
         if plan is None:
             plan = [(0, n)]
@@ -192,6 +215,9 @@ class QuickPrefillEngine:
                 else:
                     torch.mm(x2[r0:r1], lw.w_gate_up.t(), out=gu[r0:r1])
 
+        if n < 256 and self._small_linear("gate_up", x2, lw.w_gate_up, gu):
+            self.ops.swiglu(gu, act)
+            return
         choice = self._gu_split.get(n)
         if choice is None:
             choice = (False, [(0, n)])

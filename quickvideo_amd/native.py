@@ -66,6 +66,7 @@ SIGNATURES = {
     "qp_vit_rope": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "qp_vit_attn": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _f32, _vp, _vp]),
     "qp_quick_gelu": (_i32, [_vp, _vp, _vp, _i64, _vp]),
+    "qp_linear_tune": (_i32, [_vp, _vp, _c.POINTER(_vp), _i32, _vp, _i32, _f32, _vp, _i64, _i64, _i64, _i32, _vp, _sz, _vp]),
     "qp_linear_act": (_i32, [_vp, _vp, _vp, _vp, _i32, _f32, _vp, _i64, _i64, _i64, _i32, _vp, _sz, _vp]),
     "qp_add_layernorm": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
 }
@@ -272,6 +273,17 @@ class QuickPrefillOps:
         f32 = 1 if (bias is not None and bias.dtype == torch.float32) else 0
         self._check(self.lib.qp_linear_act(self.ctx, x.data_ptr(), w.data_ptr(), _ptr(bias), f32, float(alpha), out.data_ptr(), m, n, k, act,
                                            self._lt_ws.data_ptr(), self._lt_ws.numel(), self._stream()))
+
+    def linear_tune(self, x, weights, bias, out, act=0, alpha=1.0):
+        """Time hipBLASLt's candidates for out = act(alpha x w^T + bias) over the given weight tensors (cold, round-robin); keep the best."""
+        m, k = x.shape
+        n = weights[0].shape[0]
+        if getattr(self, "_lt_ws", None) is None:
+            self._lt_ws = torch.empty(128 << 20, dtype=torch.uint8, device=self.device)
+        arr = (_vp * len(weights))(*[w.data_ptr() for w in weights])
+        f32 = 1 if (bias is not None and bias.dtype == torch.float32) else 0
+        self._check(self.lib.qp_linear_tune(self.ctx, x.data_ptr(), arr, len(weights), _ptr(bias), f32, float(alpha), out.data_ptr(), m, n, k,
+                                            act, self._lt_ws.data_ptr(), self._lt_ws.numel(), self._stream()))
 
     def quick_gelu(self, x, out):
         self._check(self.lib.qp_quick_gelu(self.ctx, x.data_ptr(), out.data_ptr(), x.numel(), self._stream()))
