@@ -55,6 +55,7 @@ class KVArena:
 
 
 class QuickPrefillEngine:
+    _SHARED: dict = {}
     def __init__(self, weights: DecoderWeights, cfg: LVUConfig, capacity: int, max_group_tokens: int, device=None, ops=None,
                  tp_group=None, sp_group=None, sp_rank: int = 0, sp_size: int = 1, pp_group=None, pp_rank: int = 0, pp_size: int = 1,
                  pp_peers: Optional[List[int]] = None):
@@ -113,7 +114,8 @@ class QuickPrefillEngine:
         env = os.environ.get("QP_SPLIT_GATE_UP_ROWS")                                  # developer override, see _gate_up_swiglu
         self.split_gate_up_rows = tuple(int(v) for v in env.split(",")) if env else None
         self._tune_gemms = self.device.type == "cuda" and os.environ.get("QP_TUNE_GEMMS", "1") == "1"
-        self._gemm_plans, self._gu_split, self._lt_tuned = {}, {}, {}
+        # decisions are per (projection shape, rows, device) and shared by every engine of the process
+        self._gemm_plans, self._gu_split, self._lt_tuned = (QuickPrefillEngine._SHARED.setdefault((str(self.device), i), {}) for i in range(3))
         self.kept_trace: Optional[list] = None      # tests: set to [] to record kept indices per (group, layer)
         self.seq_pos = 0                            # tokens of the original sequence consumed so far
 
@@ -163,14 +165,15 @@ class QuickPrefillEngine:
         n = x.shape[0]
         if not (self._tune_gemms and n < 256 and hasattr(self.ops, "linear_tune") and x.is_contiguous() and w.is_contiguous()):
             return False
-        if (key, n) not in self._lt_tuned:
+        lk = (key, n, tuple(w.shape), bias is not None)
+        if lk not in self._lt_tuned:
             ws = [getattr(lw, self._WKEY[key]) for lw in self.w.layers]
             try:
                 self.ops.linear_tune(x, ws, bias, out, self.ops.ACT_NONE)
-                self._lt_tuned[(key, n)] = True
+                self._lt_tuned[lk] = True
             except Exception:                         # no usable candidate: stay on torch.mm for this shape
-                self._lt_tuned[(key, n)] = False
-        if not self._lt_tuned[(key, n)]:
+                self._lt_tuned[lk] = False
+        if not self._lt_tuned[lk]:
             return False
         self.ops.linear_act(x, w, bias, out, self.ops.ACT_NONE)
         return True
@@ -181,7 +184,8 @@ class QuickPrefillEngine:
         n = x.shape[0]
         if n < 256 and self._small_linear(key, x, w, out, bias):
             return
-        plan = self._gemm_plans.get((key, n))
+        pk = (key, n, tuple(w.shape), bias is not None)
+        plan = self._gemm_plans.get(pk)
         if plan is None:
             plan = [(0, n)]
             if self._tune_gemms and n >= 256:
@@ -195,7 +199,7 @@ class QuickPrefillEngine:
                 plan = best[1]
                 if os.environ.get("QP_ENGINE_DEBUG"):
                     print(f"[engine] {key} n={n}: whole {whole * 1e3:.0f} us -> {plan} {best[0] * 1e3:.0f} us", flush=True)
-            self._gemm_plans[(key, n)] = plan
+            self._gemm_plans[pk] = plan
         self._run_linear(plan, x, w, out, bias)
 
     def _gate_up_swiglu(self, x2: torch.Tensor, lw, act: torch.Tensor):
@@ -218,7 +222,8 @@ class QuickPrefillEngine:
         if n < 256 and self._small_linear("gate_up", x2, lw.w_gate_up, gu):
             self.ops.swiglu(gu, act)
             return
-        choice = self._gu_split.get(n)
+        gk = (n, tuple(lw.w_gate_up.shape), self.split_gate_up_rows)
+        choice = self._gu_split.get(gk)
         if choice is None:
             choice = (False, [(0, n)])
             if self.split_gate_up_rows is not None:
@@ -235,7 +240,7 @@ class QuickPrefillEngine:
                 if os.environ.get("QP_ENGINE_DEBUG"):
                     print(f"[engine] gate_up n={n}: fused whole {whole * 1e3:.0f} us -> {'two GEMMs' if choice[0] else 'fused'} {choice[1]} "
                           f"{best * 1e3:.0f} us", flush=True)
-            self._gu_split[n] = choice
+            self._gu_split[gk] = choice
         two, plan = choice
         run(two, plan)
         if two:
