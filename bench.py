@@ -35,6 +35,7 @@ from quickvideo_amd.weights import DecoderWeights, pp_layer_split  # noqa: E402
 
 CONFIGS = {
     # name: (model, frames, frame_h, frame_w, group_size, rho, prefix, tail)
+    "cfg1": ("qwen2-vl-2b", 16, 560, 1008, 16, 1.0, 15, 30),      # BASELINE.json configs[0]: 2B, one group, no pruning
     "cfg2": ("qwen2-vl-7b", 64, 560, 1008, 16, 0.5, 15, 30),
     "cfg3": ("qwen2-vl-7b", 256, 280, 504, 32, 0.25, 15, 30),
     "cfg4s": ("qwen2-vl-7b", 720, 392, 560, 16, 0.5, 15, 30),     # 1/10 of the 1-hour video (100k tokens)
