@@ -134,3 +134,24 @@ def test_engine_other_norm_modes_vs_oracle(mode):
             tot += len(want); same += len(set(g.tolist()) & set(want.tolist()))
     assert same / tot >= 0.90, same / tot
     eng.ops.set_prune_mode(0, 0)
+
+
+def test_gemm_tuning_does_not_change_results(monkeypatch):
+    """The warm-up tuner only chooses between decompositions / hipBLASLt algorithms of the same projections: with and without it
+    (QP_TUNE_GEMMS) the engine must give the same cache lengths and logits within the end-to-end tolerance, at 7B width."""
+    spec = TextSpec(hidden=3584, n_heads=28, n_kv_heads=4, head_dim=128, intermediate=18944, n_layers=1, vocab=1024)
+    spec_o = O.TextSpec(hidden=3584, n_heads=28, n_kv_heads=4, head_dim=128, intermediate=18944, n_layers=1, vocab=1024)
+    w = {k: v.to(torch.bfloat16) for k, v in O.synthetic_text_weights(spec_o, seed=21, norm_jitter=0.05).items()}
+    frames, gh, gw, gs, prefix, tail = 8, 32, 40, 4, 15, 24        # 2 groups of 640 (+15) tokens: above the tuner's 256-row floor
+    n_video = (frames // 2) * (gh // 2) * (gw // 2)
+    T = prefix + n_video + tail
+    plan = planner.plan_groups(frames, gs, gh, gw, prefix, T)
+    pos, _ = planner.mrope_positions(prefix, (frames // 2, gh, gw), tail)
+    embeds = torch.from_numpy(np.random.RandomState(6).standard_normal((T, spec.hidden)).astype(np.float32) * 0.5).to(torch.bfloat16)
+    outs = []
+    for flag in ("0", "1"):
+        monkeypatch.setenv("QP_TUNE_GEMMS", flag)
+        eng, logits = run_gpu(spec, w, plan, pos, embeds, LVUConfig("x", top_p=0.5, video_group_size=gs))
+        outs.append((list(eng.arena.len), logits.numpy()))
+    assert outs[0][0] == outs[1][0]
+    check_logits(outs[1][1], outs[0][1])
