@@ -115,7 +115,7 @@ class QuickPrefillEngine:
         self.split_gate_up_rows = tuple(int(v) for v in env.split(",")) if env else None
         self._tune_gemms = self.device.type == "cuda" and os.environ.get("QP_TUNE_GEMMS", "1") == "1"
         # decisions are per (projection shape, rows, device) and shared by every engine of the process
-        self._gemm_plans, self._gu_split, self._lt_tuned = (QuickPrefillEngine._SHARED.setdefault((str(self.device), i), {}) for i in range(3))
+        self._gemm_plans, self._gu_split, self._lt_tuned = (QuickPrefillEngine._SHARED.setdefault((str(self.device), self._tune_gemms, i), {}) for i in range(3))
         self.kept_trace: Optional[list] = None      # tests: set to [] to record kept indices per (group, layer)
         self.seq_pos = 0                            # tokens of the original sequence consumed so far
 
