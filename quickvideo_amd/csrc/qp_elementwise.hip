@@ -111,7 +111,7 @@ __global__ __launch_bounds__(256) void swiglu_kernel(const uint4* __restrict__ g
 int qp_launch_swiglu(const void* gate, const void* up, int64_t row_elems, int64_t n, int inter, void* out, hipStream_t s) {
   int64_t total = n * (inter / 8);
   int64_t blocks = (total + 255) / 256;
-  if (blocks > 8192) blocks = 8192;
+  if (blocks > 65536) blocks = 65536;
   if (blocks < 1) blocks = 1;
   swiglu_kernel<<<(int)blocks, 256, 0, s>>>((const uint4*)gate, (const uint4*)up, row_elems / 8, n, inter / 8, (uint4*)out);
   return qp_check_launch("swiglu");
