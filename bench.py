@@ -1,25 +1,38 @@
 #!/usr/bin/env python
-"""bench.py — prefill tokens/s (+ TTFT) of the QuickPrefill hot path on MI355X.
+"""bench.py — prefill tokens/s + video->first-token of the QuickPrefill hot path on MI355X.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg2|cfg3|cfg4s|tiny]
-  (N>1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg4|cfg2|cfg3|cfg4s|cfg5|tiny]
+  (N>1: launched by the driver as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...
+   bench.py --gpus N ...`; run from a bare shell it re-launches itself that way.)
 
-A "step" = one full pass of the hot path over one synthetic video: every group through all decoder layers
-(QKV + M-RoPE/append + MFMA attention over the pruned prefix + key-norm select + KV gather + MLP) plus the
-prompt tail up to the first-token logits.  Inputs (ViT-output embeddings, position ids, weights) are resident in
-HBM when the timed region starts.  Default workload = BASELINE.json configs[1]:
-Qwen2-VL-7B, 64 frames (560x1008), group_size 16 -> 4 groups x 5760 tokens, key-norm rho=0.5, 1 x MI355X.
+Default workload = the configuration BASELINE.json's metric is quoted on: **cfg4**, Qwen2-VL-7B over a synthetic 1-hour
+video (7200 frames 392x560 -> 1 008 015 tokens, group_size 16 -> 450 groups of 2240 tokens, key-norm rho = 0.5), ONE
+MI355X; inputs (ViT-output embeddings, position ids, weights) resident in HBM when the timed region starts.
 
-Prints ONE JSON line (rank 0) with the driver's contract fields plus `roofline` (dominant hand-written kernel =
-the MFMA prefill attention, measured live with HIP events on the launch stream) and `cpu_baseline` (the CPU oracle
-timed on the host cores over a bounded sample).
+Step definition.  The hot path is one sequential pass over the video's groups (group g attends to every earlier group's
+pruned KV), so for a video with at least K groups a "step" is 1/K of that pass: step i = groups [i*G//K, (i+1)*G//K)
+through all decoder layers (QKV + M-RoPE/append + MFMA attention over the pruned prefix + key-norm select + KV gather +
+MLP); the last step also runs the prompt tail up to the first-token logits.  The K timed steps are therefore exactly ONE
+full prefill of the video (`ms_per_step * steps` = the whole prefill) and `value` = prefilled tokens / that time.  Warm-up
+steps (untimed) run the first groups + the prompt tail of the same video (GEMM plan selection, kernel plans), after
+which the KV arena is reset.  Videos with fewer groups than K (cfg2, cfg3) keep the step = one full pass over the video.
+
+Prints ONE JSON line (rank 0): the driver's contract fields, `roofline` (dominant hand-written kernel = the MFMA prefill
+attention, HIP events on the launch stream inside the timed region), `roofline_prune`, `cpu_baseline` (the CPU oracle on
+the host cores over a bounded sample, extrapolated over the groups as BASELINE.md §3 prescribes), `video_to_first_token`
+(the real front end: frame producer -> pinned ring -> copy stream -> GPU patchify + ViT -> group prefill -> first token)
+and, as a secondary block, the cfg2 numbers of round 1.
 """
 from __future__ import annotations
 
 import argparse
+import glob
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 import torch
@@ -39,14 +52,23 @@ CONFIGS = {
     "cfg2": ("qwen2-vl-7b", 64, 560, 1008, 16, 0.5, 15, 30),
     "cfg3": ("qwen2-vl-7b", 256, 280, 504, 32, 0.25, 15, 30),
     "cfg4s": ("qwen2-vl-7b", 720, 392, 560, 16, 0.5, 15, 30),     # 1/10 of the 1-hour video (100k tokens)
-    "cfg4": ("qwen2-vl-7b", 7200, 392, 560, 16, 0.5, 15, 30),      # synthetic 1-hour video, ~1M vision tokens
+    "cfg4": ("qwen2-vl-7b", 7200, 392, 560, 16, 0.5, 15, 30),      # synthetic 1-hour video, ~1M vision tokens (the metric's workload)
     "cfg5": ("qwen2-vl-72b", 512, 224, 420, 16, 0.5, 15, 30),      # 72B: TP=8 in BASELINE.json; also fits ONE MI355X (145 GB of 288 GB)
     "tiny": ("tiny", 16, 112, 168, 4, 0.5, 5, 7),
 }
 PEAK_BF16_TFLOPS = 2500.0     # dense MFMA peak, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
+QUESTION = "Describe what happens in this video in detail."
 
 
+def describe(name):
+    c = CONFIGS[name]
+    return f"{name}: {c[0]}, {c[1]} frames {c[2]}x{c[3]}, group_size {c[4]}, key-norm rho={c[5]}"
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# instrumentation
+# ----------------------------------------------------------------------------------------------------------------------
 class TimedOps:
     """Proxy over QuickPrefillOps that brackets chosen operators with HIP events on the launch stream."""
 
@@ -57,13 +79,14 @@ class TimedOps:
         fn = getattr(self._ops, name)
         if name not in self._names:
             return fn
+        ev = self.events[name]
 
         def timed(*a, **kw):
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             r = fn(*a, **kw)
             e.record()
-            self.events[name].append((s, e))
+            ev.append((s, e))
             return r
         return timed
 
@@ -72,24 +95,136 @@ class TimedOps:
         return {n: (sum(s.elapsed_time(e) for s, e in ev), len(ev)) for n, ev in self.events.items()}
 
 
-def choose_layout(n_groups, world):
+class Telemetry(threading.Thread):
+    """Samples the GPU's average socket power and shader clock from sysfs (hwmon) while the timed region runs, so that
+    'the MFMA kernels run power-limited' is a measurement in the bench line, not an inference."""
+
+    def __init__(self, period=0.25, device_index=0):
+        super().__init__(daemon=True)
+        self.period, self.stop_flag, self.samples = period, threading.Event(), []
+        self.power, self.sclk, self.card = None, None, None
+        # the box's sysfs lists every GPU of the node: pick the card whose PCI address is the visible device's
+        want = None
+        try:
+            pr = torch.cuda.get_device_properties(device_index)
+            want = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        except Exception:
+            pass
+        cards = sorted(glob.glob("/sys/class/drm/card*/device"))
+        if want is not None:
+            cards = [c for c in cards if os.path.basename(os.path.realpath(c)) == want]
+        elif len(cards) != 1:
+            cards = []
+        for c in cards:
+            for hw in sorted(glob.glob(os.path.join(c, "hwmon", "hwmon*"))):
+                p = next((os.path.join(hw, f) for f in ("power1_average", "power1_input") if os.path.exists(os.path.join(hw, f))), None)
+                f = os.path.join(hw, "freq1_input")
+                if p and self.power is None:
+                    self.power, self.sclk, self.card = p, (f if os.path.exists(f) else None), os.path.basename(os.path.realpath(c))
+
+    @staticmethod
+    def _read(path):
+        try:
+            return float(open(path).read().strip())
+        except Exception:
+            return None
+
+    def run(self):
+        while not self.stop_flag.is_set():
+            self.samples.append((self._read(self.power) if self.power else None, self._read(self.sclk) if self.sclk else None))
+            self.stop_flag.wait(self.period)
+
+    def summary(self):
+        self.stop_flag.set()
+        pw = [p / 1e6 for p, _ in self.samples if p]
+        ck = [c / 1e6 for _, c in self.samples if c]
+        if not pw and not ck:
+            return None
+        out = {"source": "sysfs hwmon of PCI device %s (power1_average, freq1_input = sclk), sampled every %.2f s during the timed region"
+                         % (self.card, self.period), "samples": len(self.samples)}
+        if pw:
+            out.update(power_w_avg=round(sum(pw) / len(pw), 1), power_w_max=round(max(pw), 1))
+        if ck:
+            out.update(sclk_mhz_avg=round(sum(ck) / len(ck), 1), sclk_mhz_min=round(min(ck), 1), sclk_mhz_max=round(max(ck), 1))
+        return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# multi-GPU layout
+# ----------------------------------------------------------------------------------------------------------------------
+def choose_layout(n_groups, world, eff_sp):
     """(pp, sp) with pp * sp == world for `--parallel auto`: a layer pipeline of pp stages, each a group-token parallel group of
-    sp ranks.  Model: the pipe is busy G / (G + pp - 1) of the time; an sp group of s ranks runs at EFF_SP[s] of a single GPU
-    (GEMMs at M = n/s, exchange, replicated prune; measured / estimated at cfg2 sizes)."""
-    EFF_SP = {1: 1.0, 2: 0.92, 4: 0.75, 8: 0.5}
-    best, best_eff = (1, world), -1.0
+    sp ranks.  Model: the pipe is busy G / (G + pp - 1) of the time; an sp group of s ranks runs at eff_sp[s] of a single GPU
+    (measured at start-up by probe_sp_efficiency: GEMMs at M = n/s, the K/V all-gather over RCCL, the replicated prune)."""
+    best, best_eff = (world, 1), -1.0
     pp = 1
     while pp <= world:
         sp = world // pp
-        if pp * sp == world and sp in EFF_SP:
-            eff = n_groups / (n_groups + pp - 1) * EFF_SP[sp]
+        if pp * sp == world and sp in eff_sp:
+            eff = n_groups / (n_groups + pp - 1) * eff_sp[sp]
             if eff > best_eff + 1e-9:
                 best, best_eff = (pp, sp), eff
         pp *= 2
     return best
 
 
-def build_workload(name, device, rank, world, seed=0, parallel="sp", layout=None):
+def probe_sp_efficiency(name, device, rank, world, single_dev):
+    """Measured efficiency of group-token parallelism on THIS machine: two decoder layers at the workload's group size over a
+    mid-video prefix, once on one rank and once split over s = 2, 4, ... ranks (real all-gather on the process group);
+    eff[s] = t(1) / (s * t(s)).  Replaces round 1's guessed table."""
+    model, frames, fh, fw, gs, rho, prefix, tail = CONFIGS[name]
+    spec = PRESETS[model]
+    n = (gs // 2) * (fh // 28) * (fw // 28)
+    G = -(-frames // gs)
+    P = min(int(n * rho) * (G // 2), 120_000)
+    cfg = LVUConfig(model, top_p=rho, video_group_size=gs, num_frames=frames)
+    w = DecoderWeights.synthetic(spec, device, seed=0, n_layers=2)
+    g = torch.Generator(device=device); g.manual_seed(7)
+    emb = (torch.randn(n, spec.hidden, generator=g, device=device, dtype=torch.float32) * 0.5).to(torch.bfloat16)
+    pos = (torch.arange(n, device=device)[None] + P).repeat(3, 1)
+    eff, times = {1: 1.0}, {}
+    for s in [1] + [s for s in (2, 4, 8) if s <= world and world % s == 0]:
+        grp = None
+        if s > 1:
+            grps = [torch.distributed.new_group(ranks=list(range(b, b + s))) for b in range(0, world, s)]
+            grp = grps[rank // s]
+        eng = QuickPrefillEngine(w, cfg, capacity=P + n + 64, max_group_tokens=n, device=device, sp_rank=rank % s, sp_size=s, sp_group=grp)
+        eng.arena.buf.normal_()
+
+        def one():
+            eng.arena.len = [P] * len(eng.arena.len)
+            eng.forward_segment(emb, pos, prune=True, video_group=True)
+        for _ in range(2):
+            one()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            one()
+        torch.cuda.synchronize()
+        t = torch.tensor([(time.perf_counter() - t0) / 3], device=device, dtype=torch.float64)
+        if world > 1:
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        times[s] = float(t.item())
+        del eng
+    for s, t in times.items():
+        eff[s] = round(times[1] / (s * t), 4)
+    return eff
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# workload
+# ----------------------------------------------------------------------------------------------------------------------
+def lvu_config_for(name):
+    model, frames, fh, fw, gs, rho, prefix, tail = CONFIGS[name]
+    # the front end's frame size follows the reference's pixel budget from the source size (qwen25_lvu.py:292-306); cfg4's 392x560
+    # is SURVEY §8d's deliberate choice (~1M vision tokens), reached with an explicit max_pixels on a 392x560 source
+    extra = {"max_pixels": fh * fw} if name in ("cfg4", "cfg4s") else {}
+    return LVUConfig(model, top_p=rho, video_group_size=gs, num_frames=frames, extra_kwargs=extra)
+
+
+def build_workload(name, device, rank, world, seed=0, parallel="single", layout=(1, 1), weights=None):
     model, frames, fh, fw, gs, rho, prefix, tail = CONFIGS[name]
     spec = PRESETS[model]
     gh, gw = fh // 14, fw // 14
@@ -97,36 +232,68 @@ def build_workload(name, device, rank, world, seed=0, parallel="sp", layout=None
     T = prefix + n_video + tail
     plan = planner.plan_groups(frames, gs, gh, gw, prefix, T)
     pos, delta = planner.mrope_positions(prefix, (frames // 2, gh, gw), tail, temporal_scale=spec.temporal_scale)
-    cfg = LVUConfig(model, top_p=rho, video_group_size=gs, num_frames=frames)
+    cfg = lvu_config_for(name)
     tp = parallel == "tp" and world > 1
-    pp_n, sp_n = layout if layout is not None else (1, 1)
+    pp_n, sp_n = layout
     stage, sp_rank = rank // sp_n, rank % sp_n                                   # ranks of a stage are consecutive
-    weights = DecoderWeights.synthetic(spec, device, seed=seed, tp_rank=rank if tp else 0, tp_size=world if tp else 1,
-                                       layer_range=pp_layer_split(spec.n_layers, pp_n, stage) if pp_n > 1 else None)
+    if weights is None:
+        weights = DecoderWeights.synthetic(spec, device, seed=seed, tp_rank=rank if tp else 0, tp_size=world if tp else 1,
+                                           layer_range=pp_layer_split(spec.n_layers, pp_n, stage) if pp_n > 1 else None)
     kept = sum(effective_k(n, cfg, 0, spec.n_layers) or n for n in plan.tokens)
-    cap = kept + plan.tail_len + 64
-    eng = QuickPrefillEngine(weights, cfg, capacity=cap, max_group_tokens=max(plan.tokens + [plan.tail_len]), device=device,
+    cap = kept + plan.tail_len + 384                             # room for the pipeline leg's prompt + decoded tokens
+    eng = QuickPrefillEngine(weights, cfg, capacity=cap, max_group_tokens=max(plan.tokens + [plan.tail_len]) + 16, device=device,
                              sp_rank=sp_rank, sp_size=sp_n, pp_rank=stage, pp_size=pp_n,
                              pp_peers=[s * sp_n + sp_rank for s in range(pp_n)] if pp_n > 1 else None)
     eng.rope_delta = int(delta)                                  # decode positions continue at sequence index + delta
-    g = torch.Generator(device=device); g.manual_seed(1234)      # same embeddings on every TP rank
-    # synthetic ViT output / text embeddings: N(0, 1) scaled like embedding rows (the ViT front end is bench'd separately)
-    embeds = (torch.randn(T, spec.hidden, generator=g, device=device, dtype=torch.float32) * 0.5).to(torch.bfloat16)
+    g = torch.Generator(device=device); g.manual_seed(1234)      # same embeddings on every rank
+    # synthetic ViT output / text embeddings: N(0, 1) scaled like embedding rows (the ViT front end is timed in video_to_first_token)
+    embeds = torch.empty(T, spec.hidden, device=device, dtype=torch.bfloat16)
+    for r0 in range(0, T, 65536):                                # chunked: no 14 GB fp32 transient for the 1M-token video
+        r1 = min(T, r0 + 65536)
+        embeds[r0:r1] = (torch.randn(r1 - r0, spec.hidden, generator=g, device=device, dtype=torch.float32) * 0.5).to(torch.bfloat16)
     pos_d = torch.from_numpy(pos).to(device)
     return spec, cfg, plan, eng, embeds, pos_d, T
 
 
-def run_step(eng, plan, embeds, pos):
-    eng.reset()
-    start = 0
+def group_starts(plan):
+    out, s = [], 0
     for n in plan.tokens:
-        eng.prefill_group(embeds[start:start + n], pos[:, start:start + n])
-        start += n
-    logits = eng.prefill_tail(embeds[start:], pos[:, start:])
+        out.append(s)
+        s += n
+    return out + [s]
+
+
+def run_groups(eng, plan, starts, embeds, pos, g0, g1):
+    for g in range(g0, g1):
+        s, n = starts[g], plan.tokens[g]
+        eng.prefill_group(embeds[s:s + n], pos[:, s:s + n])
+
+
+def run_tail(eng, starts, embeds, pos):
+    s = starts[-1]
+    logits = eng.prefill_tail(embeds[s:], pos[:, s:])
     tok = torch.argmax(logits) if logits is not None else torch.zeros((), dtype=torch.int64, device=embeds.device)
     if eng.pp_size > 1:                  # layer pipeline: the last stage holds the logits; the token returns to every stage
         torch.distributed.broadcast(tok, src=torch.distributed.get_world_size() - 1)
-    return tok                           # first generated token id (stays on device; .item() would be the TTFT point)
+    return tok                           # first generated token id (stays on device; .item() is the TTFT point)
+
+
+def run_video(eng, plan, starts, embeds, pos):
+    eng.reset()
+    run_groups(eng, plan, starts, embeds, pos, 0, len(plan.tokens))
+    return run_tail(eng, starts, embeds, pos)
+
+
+def fast_forward(eng, plan, cfg, spec, g0):
+    """Put the engine in the state it has before group g0 WITHOUT running groups [0, g0): arena rows [0, P_g0) filled with
+    N(0,1) K/V.  For profiling a steady-state window of the long video (rocprofv3 over all 12.6k launches is impractical)."""
+    eng.reset()
+    P = sum(effective_k(n, cfg, 0, spec.n_layers) or n for n in plan.tokens[:g0])
+    for l in range(eng.arena.buf.shape[0]):
+        eng.arena.buf[l, :, :, :P].normal_()
+    eng.arena.len = [P] * len(eng.arena.len)
+    eng.seq_pos = sum(plan.tokens[:g0])
+    return P
 
 
 def decode_leg(eng, first_token: int, n_tokens: int = 32):
@@ -155,8 +322,8 @@ def decode_leg(eng, first_token: int, n_tokens: int = 32):
             "achieved_tb_s": round(tbs, 2), "frac_of_hbm_peak": round(tbs / 8.0, 3), "kv_rows_per_layer": len0[0]}
 
 
-def flops_and_bytes(spec, cfg, plan, tp_size):
-    """Algorithmic FLOPs of one step (F_lin per token, F_att(g) = 4 L Hq D (n P + n(n+1)/2)) and the
+def flops_and_bytes(spec, cfg, plan):
+    """Algorithmic FLOPs of one pass (F_lin per token, F_att(g) = 4 L Hq D (n P + n(n+1)/2)) and the
     prune-path bytes in the unfused convention (B_prune = n Hkv D 2 + 2 (k Hkv D 2 2) + 4k per layer per group)."""
     L = spec.n_layers
     lin = att = prune_bytes = 0.0
@@ -173,26 +340,31 @@ def flops_and_bytes(spec, cfg, plan, tp_size):
     return lin, att, prune_bytes
 
 
-def cpu_baseline(name, sample_layers=2, sample_tokens=2880):
-    """Time the CPU oracle (oracle/qp_oracle.py — the checker, used here only as the reported baseline) on a
-    bounded sample: `sample_layers` decoder layers of the SECOND group (n new tokens over the pruned prefix of
-    group 0), bf16, all host cores; scaled to tokens/s of the full model by L / sample_layers."""
-    from oracle import qp_oracle as O
-    model, frames, fh, fw, gs, rho, prefix, tail = CONFIGS[name]
-    ps = PRESETS[model]
-    # torch-CPU on the GPU box's 256-thread EPYC host slows down past ~32 threads for these op sizes (measured:
-    # tools/probe/cpu_diag.py), so the baseline uses min(host cores, 32) threads and reports that count.
-    cores = min(os.cpu_count() or 1, 32)
-    torch.set_num_threads(cores)
+def local_attn_flops(spec, cfg, plan, world, rank, parallel, layout, att):
+    """Attention FLOPs rank `rank` executes in one pass (tp: heads sharded; pp x sp: its stage's layers x its zigzag rows)."""
+    if world == 1:
+        return att
+    if parallel == "tp":
+        return att / world
+    pp_n, sp_n = layout
+    l0_, l1_ = pp_layer_split(spec.n_layers, pp_n, rank // sp_n)
+    loc, Pp = 0.0, 0
+    for n in plan.tokens:
+        if sp_n > 1 and n >= 64 * sp_n:
+            for lo, hi in sp_row_ranges(n, sp_n, rank % sp_n):
+                loc += 4.0 * spec.n_layers * spec.n_heads * spec.head_dim * sum(Pp + i + 1 for i in range(lo, hi))
+        else:
+            loc += spec.attn_flops(n, Pp)
+        Pp += effective_k(n, cfg, 0, spec.n_layers) or n
+    return (loc + spec.attn_flops(plan.tail_len, Pp)) * (l1_ - l0_) / spec.n_layers
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# CPU baseline (the oracle, timed on the host cores; a reported baseline, never the product path)
+# ----------------------------------------------------------------------------------------------------------------------
+def _cpu_layers(O, ps, sample_layers, rn):
     spec = O.TextSpec(hidden=ps.hidden, n_heads=ps.n_heads, n_kv_heads=ps.n_kv_heads, head_dim=ps.head_dim,
                       intermediate=ps.intermediate, n_layers=sample_layers, vocab=8)
-    gh, gw = fh // 14, fw // 14
-    n_video = (frames // 2) * (gh // 2) * (gw // 2)
-    plan = planner.plan_groups(frames, gs, gh, gw, prefix, prefix + n_video + tail)
-    n0, n1 = plan.tokens[0], min(sample_tokens, plan.tokens[min(1, len(plan.tokens) - 1)])
-    P = int(n0 * rho)
-    g = torch.Generator().manual_seed(0)
-    rn = lambda *s, sc=0.02: (torch.randn(*s, generator=g) * sc).to(torch.bfloat16)
     w = {}
     for l in range(sample_layers):
         p = f"layers.{l}."
@@ -204,25 +376,86 @@ def cpu_baseline(name, sample_layers=2, sample_tokens=2880):
         w[p + "o_proj.weight"] = rn(spec.hidden, spec.n_heads * 128)
         w[p + "mlp.gate_proj.weight"], w[p + "mlp.up_proj.weight"] = rn(spec.intermediate, spec.hidden), rn(spec.intermediate, spec.hidden)
         w[p + "mlp.down_proj.weight"] = rn(spec.hidden, spec.intermediate)
+    return spec, w
+
+
+def _cpu_time_group(O, spec, w, ps, sample_layers, n_rows, P, rho, rn):
+    """Seconds for `sample_layers` oracle decoder layers (incl. the key-norm prune) over n_rows new tokens on a P-row prefix."""
     cache = O.OracleCache(sample_layers)
-    for l in range(sample_layers):
-        cache.append(l, rn(spec.n_kv_heads, P, 128, sc=1.0), rn(spec.n_kv_heads, P, 128, sc=1.0))
-    h = rn(n1, spec.hidden, sc=0.5)
-    pos = torch.arange(n1)[None].repeat(3, 1) + P
+    if P > 0:
+        blk = rn(spec.n_kv_heads, min(P, 8192), 128, sc=1.0)                   # prefix content is irrelevant to the timing: tile one block
+        reps = -(-P // blk.shape[1])
+        for l in range(sample_layers):
+            cache.append(l, blk.repeat(1, reps, 1)[:, :P].contiguous(), blk.repeat(1, reps, 1)[:, :P].contiguous())
+    h = rn(n_rows, spec.hidden, sc=0.5)
+    pos = torch.arange(n_rows)[None].repeat(3, 1) + P
     cos, sin = O.mrope_cos_sin(pos, spec, torch.bfloat16)
-    k_keep = O.effective_k(n1, None, rho, None, None, 0, ps.n_layers)
+    k_keep = O.effective_k(n_rows, None, rho, None, None, 0, ps.n_layers)
     t0 = time.perf_counter()
     with torch.no_grad():
         for l in range(sample_layers):
             h, _, cos, sin = O.decoder_layer(h, w, l, spec, cache, cos, sin, k_keep)
-    dt = time.perf_counter() - t0
-    tok_s = n1 / (dt / sample_layers * ps.n_layers)
-    return {"value": round(tok_s, 2), "unit": "tokens/s", "cores": cores, "kind": "port",
-            "sample": f"{sample_layers} of {ps.n_layers} decoder layers (bf16 torch-CPU oracle incl. key-norm prune) over the first "
-                      f"{n1} new tokens of group 1 on a {P}-token pruned prefix, {dt:.2f}s, scaled by L/{sample_layers}"}
+    return time.perf_counter() - t0
 
 
-def pipeline_leg(name, eng, device):
+def cpu_baseline(name, sample_layers=2):
+    """The CPU oracle (oracle/qp_oracle.py — the checker, used here only as the reported baseline) on a bounded sample.
+
+    Short videos (cfg1-3): `sample_layers` layers over the first 2880 new tokens of group 1 on group 0's pruned prefix, scaled by
+    L / sample_layers.  Long videos (cfg4, cfg5: BASELINE.md §3): groups g in {0, G/2, G-1} — `sample_layers` layers over the
+    first `rows` tokens of the group on that group's full pruned prefix P_g — a least-squares line t(P) through the three
+    points, summed over all G groups, scaled by L / sample_layers and n_g / rows.  Labelled "extrapolated"."""
+    from oracle import qp_oracle as O
+    model, frames, fh, fw, gs, rho, prefix, tail = CONFIGS[name]
+    ps = PRESETS[model]
+    # torch-CPU on the GPU box's 256-thread EPYC host slows down past ~32 threads for these op sizes (measured in round 1:
+    # tools/probe/cpu_diag.py), so the baseline uses min(host cores, 32) threads and reports that count.
+    cores = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(cores)
+    gh, gw = fh // 14, fw // 14
+    n_video = (frames // 2) * (gh // 2) * (gw // 2)
+    plan = planner.plan_groups(frames, gs, gh, gw, prefix, prefix + n_video + tail)
+    G = len(plan.tokens)
+    g = torch.Generator().manual_seed(0)
+    rn = lambda *s, sc=0.02: (torch.randn(*s, generator=g) * sc).to(torch.bfloat16)
+    if G >= 16:
+        sample_layers = 1                      # long video: the two far points are attention over 250k / 500k rows — one layer keeps it bounded
+    spec, w = _cpu_layers(O, ps, sample_layers, rn)
+    if G < 16:
+        n0, n1 = plan.tokens[0], min(2880, plan.tokens[min(1, G - 1)])
+        P = int(n0 * rho) if rho < 1.0 else n0
+        dt = _cpu_time_group(O, spec, w, ps, sample_layers, n1, P, rho, rn)
+        tok_s = n1 / (dt / sample_layers * ps.n_layers)
+        return {"value": round(tok_s, 2), "unit": "tokens/s", "cores": cores, "kind": "port",
+                "sample": f"{sample_layers} of {ps.n_layers} decoder layers (bf16 torch-CPU oracle incl. key-norm prune) over the first "
+                          f"{n1} new tokens of group 1 on a {P}-token pruned prefix, {dt:.2f}s, scaled by L/{sample_layers}"}
+    ks = [effective_k(n, LVUConfig(model, top_p=rho), 0, ps.n_layers) or n for n in plan.tokens]
+    Pg = [sum(ks[:i]) for i in range(G)]
+    rows = max(64, plan.tokens[-1] // 8)
+    pts = []
+    for gi in (0, G // 2, G - 1):
+        dt = _cpu_time_group(O, spec, w, ps, sample_layers, min(rows, plan.tokens[gi]), Pg[gi], rho, rn)
+        pts.append((gi, Pg[gi], dt))
+    # least-squares line through (P, t)
+    mx = sum(p for _, p, _ in pts) / 3.0
+    my = sum(t for _, _, t in pts) / 3.0
+    b = sum((p - mx) * (t - my) for _, p, t in pts) / max(sum((p - mx) ** 2 for _, p, _ in pts), 1e-30)
+    a = my - b * mx
+    total = sum((a + b * Pg[i]) * (plan.tokens[i] / rows) for i in range(G)) * (ps.n_layers / sample_layers)
+    tok_s = sum(plan.tokens) / total
+    return {"value": round(tok_s, 3), "unit": "tokens/s", "cores": cores, "kind": "port", "extrapolated": True,
+            "full_video_cpu_seconds_extrapolated": round(total, 1),
+            "points": [{"group": gi, "prefix_rows": p, "seconds": round(t, 3)} for gi, p, t in pts],
+            "sample": f"extrapolated (BASELINE.md §3): {sample_layers} of {ps.n_layers} decoder layers (bf16 torch-CPU oracle incl. key-norm "
+                      f"prune) over the first {rows} of {plan.tokens[-1]} new tokens of groups 0, {G // 2}, {G - 1} on their full pruned "
+                      f"prefixes ({pts[0][1]}, {pts[1][1]}, {pts[2][1]} rows): {sum(t for *_, t in pts):.1f}s of CPU work; line t(P) fitted "
+                      f"through the three points, summed over all {G} groups, scaled by L/{sample_layers} and n_g/{rows}"}
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# video -> first token through the real front end
+# ----------------------------------------------------------------------------------------------------------------------
+def pipeline_leg(name, eng, device, modes=("overlapped", "sequential"), warm_video=None):
     """video -> first token with the real front end: synthetic frame source (CPU producer thread) -> pinned ring -> H2D
     on a copy stream -> GPU normalise/patchify + ViT on a second stream -> group prefill -> tail -> first token id on
     the host.  Reported next to the headline number (which excludes the ViT, like SURVEY §8d 'with and without ViT')."""
@@ -233,19 +466,188 @@ def pipeline_leg(name, eng, device):
     model, frames, fh, fw, gs, rho, prefix, tail = CONFIGS[name]
     vis = VisionWeights.synthetic(_VIT[model], device, seed=0)
     m = QwenVLNative(eng.w, vis, device, name=model)
-    cfg = LVUConfig(model, top_p=rho, video_group_size=gs, num_frames=frames)
-    pipe = PrefillPipeline(m, cfg, SyntheticProcessor(eng.spec), ops=eng.ops)
-    video = f"synthetic://?frames={frames * 4}&h=1080&w=1920&fps=2&seed=1"
+    m.engine = eng                                               # same engine (KV arena, tuned GEMM plans) as the headline pass
+    pipe = PrefillPipeline(m, eng.cfg, SyntheticProcessor(eng.spec), ops=eng.ops)
+    if name in ("cfg4", "cfg4s"):     # a 1-hour (or 6-minute) video at 8 fps sampled at 2 fps; frames already at the model's size
+        video = f"synthetic://?frames={frames * 4}&h={fh}&w={fw}&fps=8&seed=1"
+        warm = f"synthetic://?frames=256&h={fh}&w={fw}&fps=8&seed=2" if warm_video is None else warm_video
+    else:
+        video = f"synthetic://?frames={frames * 4}&h=1080&w=1920&fps=2&seed=1"
+        warm = video
     res = {}
-    for mode, overlap in (("overlapped", True), ("sequential", False)):
-        pipe.generate("Describe what happens in this video in detail.", video, max_new_tokens=1, overlap=overlap)   # warm-up
-        pipe.generate("Describe what happens in this video in detail.", video, max_new_tokens=1, overlap=overlap)
+    for mode in modes:
+        overlap = mode == "overlapped"
+        if warm != video:                                        # short clip of the same geometry: pinned ring, ViT GEMM plans
+            nf, eng.cfg.num_frames = eng.cfg.num_frames, 64
+            pipe.generate(QUESTION, warm, max_new_tokens=1, overlap=overlap)
+            eng.cfg.num_frames = nf
+        else:
+            pipe.generate(QUESTION, warm, max_new_tokens=1, overlap=overlap)
+        pipe.generate(QUESTION, video, max_new_tokens=1, overlap=overlap)
         t = pipe.last_timings
         res[mode] = {"ttft_ms": round(t.ttft * 1e3, 2), "frame_wait_ms": round(t.fetch * 1e3, 2), "vit_ms": round(t.vit * 1e3, 2),
                      "group_loop_ms": round(t.prefill * 1e3, 2), "prefill_tokens_per_s_with_vit": round(t.tokens / t.prefill, 1),
-                     "tokens": t.tokens}
-    res["note"] = "frames: seeded synthetic uint8 generated on the host CPU (no codec in the image); ViT: Qwen2-VL 32-layer tower, random weights"
+                     "tokens": t.tokens, "groups": t.groups}
+    res["note"] = ("frames: seeded synthetic uint8 generated on the host CPU by the producer thread (no codec in the image), "
+                   f"{CONFIGS[name][1]} frames {fh}x{fw}; ViT: Qwen2-VL 32-layer tower, random weights; clock starts when the video is opened "
+                   "and stops when the first generated token id is on the host")
     return res
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# one measured pass
+# ----------------------------------------------------------------------------------------------------------------------
+def measure(args, name, device, rank, world, parallel, layout, group, weights=None, timing="inline", telemetry=False):
+    """Build the workload for `parallel`/`layout`, warm up, time K steps.  Returns (result dict, engine, context)."""
+    spec, cfg, plan, eng, embeds, pos, T = build_workload(name, device, rank, world, parallel=parallel, layout=layout, weights=weights)
+    if parallel == "tp":
+        eng.tp_group = group
+    elif world > 1:
+        pp_n, sp_n = layout
+        if sp_n == world:
+            eng.sp_group = group
+        elif sp_n > 1:                        # every rank creates every stage's group, in the same order
+            stage_groups = [torch.distributed.new_group(ranks=list(range(s * sp_n, (s + 1) * sp_n))) for s in range(pp_n)]
+            eng.sp_group = stage_groups[rank // sp_n]
+    G, K = len(plan.tokens), args.steps
+    starts = group_starts(plan)
+    tokens = sum(plan.tokens)                 # tokens prefilled in the group loop (the reference's total_prefill span)
+    fraction = G >= K                         # long video: a step = 1/K of the one sequential pass
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    # warm-up: the engine picks its GEMM decompositions / hipBLASLt algorithms the first time a segment size shows up (one-off, like
+    # building the weights); with --warmup 0 that first use must still not land in the timed steps
+    for _ in range(max(args.warmup, 1)):
+        if fraction:
+            eng.reset()
+            run_groups(eng, plan, starts, embeds, pos, 0, min(G, 4))
+            run_tail(eng, starts, embeds, pos)
+        else:
+            run_video(eng, plan, starts, embeds, pos)
+
+    timed_names = ["prefill_attn", "prune_staged"] if fraction else ["prefill_attn", "prune_staged", "rope_append", "add_rmsnorm", "swiglu"]
+    timed = TimedOps(eng.ops, timed_names) if (timing != "off") else None
+    real_ops = eng.ops
+    tele = Telemetry() if telemetry else None
+    if args.window:                                               # profiling: steady-state window of the long video, fast-forwarded
+        g0, g1 = (int(v) for v in args.window.split(":"))
+        P0 = fast_forward(eng, plan, cfg, spec, g0)
+        barrier()
+        t0 = time.perf_counter()
+        run_groups(eng, plan, starts, embeds, pos, g0, g1)
+        barrier()
+        dt = time.perf_counter() - t0
+        wtok = sum(plan.tokens[g0:g1])
+        return ({"window": args.window, "prefix_rows_at_start": P0, "ms_per_group": round(dt / (g1 - g0) * 1e3, 3),
+                 "tokens_per_s": round(wtok / dt, 1)}, eng, None)
+    if fraction:
+        if timed is not None:
+            eng.ops = timed                                       # attention + prune bracketed with HIP events INSIDE the timed pass
+        eng.reset()
+        barrier()
+        if tele:
+            tele.start()
+        t0 = time.perf_counter()
+        for i in range(K):
+            run_groups(eng, plan, starts, embeds, pos, i * G // K, (i + 1) * G // K)
+        tok = run_tail(eng, starts, embeds, pos)
+        barrier()
+        dt = time.perf_counter() - t0
+        first = int(tok.item())
+        eng.ops = real_ops
+    else:
+        barrier()
+        if tele:
+            tele.start()
+        t0 = time.perf_counter()
+        for _ in range(K):
+            tok = run_video(eng, plan, starts, embeds, pos)
+        barrier()
+        dt = time.perf_counter() - t0
+        first = int(tok.item())
+        if timed is not None:                                     # short video: one extra, separately bracketed pass
+            eng.ops = timed
+            run_video(eng, plan, starts, embeds, pos)
+            eng.ops = real_ops
+    tele_sum = tele.summary() if tele else None
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / K * 1e3
+    pass_s = dt if fraction else dt / K
+    lin, att, prune_bytes = flops_and_bytes(spec, cfg, plan)
+    res = {"value": round(tokens / pass_s, 1), "ms_per_step": round(ms_per_step, 3), "first_token": first,
+           "full_prefill_ms": round(pass_s * 1e3, 2),
+           "algorithmic_tflop_per_pass": round((lin + att) / 1e12, 2),
+           "mfma_frac_whole_pass": round((lin + att) / world / pass_s / 1e12 / PEAK_BF16_TFLOPS, 4)}
+    if tele_sum:
+        res["telemetry"] = tele_sum
+    if timed is not None:
+        tot = timed.totals_ms()
+        att_ms, att_n = tot["prefill_attn"]
+        att_local = local_attn_flops(spec, cfg, plan, world, rank, parallel, layout, att)
+        ach = att_local / (att_ms * 1e-3) / 1e12
+        res["roofline"] = {"kernel": "attn_fwd_kernel_s6 (MFMA prefill attention over pruned prefix + causal tail; + attn_combine_kernel when kv-split)",
+                           "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                           "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None, "launches": att_n,
+                           "avg_launch_ms": round(att_ms / max(att_n, 1), 4), "algorithmic_flops_per_launch": att_local / max(att_n, 1),
+                           "algorithmic_flops_per_pass": att_local, "kernel_ms_per_pass": round(att_ms, 2),
+                           "timing": "HIP events on the launch stream, " + ("inside the timed region" if fraction else "one extra pass")}
+        pr_ms, pr_n = tot["prune_staged"]
+        if pr_ms > 0:
+            pb = prune_bytes / world if world > 1 else prune_bytes
+            res["roofline_prune"] = {"kernels": "qp_prune_staged (key-norm select + KV gather)", "bound": "hbm",
+                                     "achieved": round(pb / (pr_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                     "frac": round(pb / (pr_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "launches": pr_n,
+                                     "avg_launch_us": round(pr_ms / max(pr_n, 1) * 1e3, 2), "ms_per_pass": round(pr_ms, 3),
+                                     "algorithmic_bytes_per_pass": pb, "algorithmic_bytes_per_launch": pb / max(pr_n, 1)}
+        res["kernel_ms_per_pass"] = {k: round(v[0], 3) for k, v in tot.items()}
+    ctx = dict(spec=spec, cfg=cfg, plan=plan, embeds=embeds, pos=pos, starts=starts, tokens=tokens, fraction=fraction, G=G)
+    return res, eng, ctx
+
+
+def attach_traffic(roofline, name, world):
+    """HBM bytes per attention launch come from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; gfx950 correction as in
+    MI355X_MICROARCH.md) of this same command, committed under profiles/ — labelled with their source."""
+    if roofline is None or world != 1:
+        return
+    path = os.path.join(ROOT, "profiles", f"attn_pmc_traffic_{name}.json")
+    if not os.path.exists(path) and name == "cfg2":
+        path = os.path.join(ROOT, "profiles", "attn_pmc_traffic_latest.json")
+    if os.path.exists(path):
+        d = json.load(open(path)).get("attn_fwd_kernel_s6", {})
+        roofline["traffic"] = d.get("traffic_bytes_per_launch")
+        roofline["traffic_source"] = (f"committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes ({os.path.relpath(path, ROOT)}: "
+                                      f"{d.get('window', 'whole bench command')}), not collected in this run")
+        if d.get("algorithmic_bytes_per_launch"):
+            roofline["traffic_over_algorithmic"] = round(roofline["traffic"] / d["algorithmic_bytes_per_launch"], 3)
+
+
+def secondary_cfg2(args, device, weights):
+    """Round 1's headline (BASELINE.json configs[1]) kept as a secondary block: 5 full passes + the front-end TTFT."""
+    a = argparse.Namespace(**vars(args)); a.steps, a.warmup, a.window = 5, 2, None
+    res, eng, ctx = measure(a, "cfg2", device, 0, 1, "single", (1, 1), None, weights=weights, timing="extra")
+    attach_traffic(res.get("roofline"), "cfg2", 1)
+    out = {"workload": describe("cfg2"), "prefill_tokens": ctx["tokens"], "steps": 5, "step": "one full pass over the video", **res}
+    if not args.no_pipeline:
+        out["video_to_first_token"] = pipeline_leg("cfg2", eng, device)
+    return out
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def self_launch(args):
+    """`python bench.py --gpus N` from a bare shell: re-exec under torch.distributed.run, one rank per GPU (RCCL)."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -253,24 +655,30 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--config", default="cfg4", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--no-pipeline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="skip the video -> first token leg through the real front end")
     ap.add_argument("--no-decode", action="store_true", help="skip the greedy-decode leg (hipGraph step, ms per token)")
-    ap.add_argument("--no-ttft", action="store_true", help="skip the extra step that times prefill -> first token id on the host")
-    ap.add_argument("--parallel", default="auto", choices=["auto", "sp", "tp", "pp"],
-                    help="N>1: sp = group-token parallel (replicated weights/KV, one K/V all-gather per layer), "
-                         "tp = tensor parallel over heads / MLP columns (two [n,d] all-reduces per layer), "
-                         "pp = layer pipeline (each rank holds L/N layers and their KV; one [n,d] hand-off per group and stage); "
-                         "auto = pp when the video has >= 4*N groups (the pipeline stays full), else sp")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary cfg2 block")
+    ap.add_argument("--lean", action="store_true", help="only the timed pass (= all the --no-* switches)")
+    ap.add_argument("--window", default=None, help="g0:g1 — profile groups [g0, g1) of the video from a fast-forwarded state")
+    ap.add_argument("--parallel", default="both", choices=["both", "auto", "sp", "tp", "pp"],
+                    help="N>1: tp = tensor parallel over heads / MLP columns (two [n,d] all-reduces + one key-sum all-gather per layer: the "
+                         "north_star contract), sp = group-token parallel (replicated weights/KV, one K/V all-gather per layer), pp = layer "
+                         "pipeline (each rank holds L/N layers and their KV; one [n,d] hand-off per group and stage), auto = pp x sp "
+                         "factorisation chosen from a measured efficiency probe; both (default) = auto as `value` + a `tp` block")
     args = ap.parse_args()
+    if args.lean:
+        args.no_cpu_baseline = args.no_pipeline = args.no_decode = args.no_secondary = True
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus} (WORLD_SIZE={world})")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # QP_BENCH_SINGLE_DEVICE=1: developer hook to exercise the multi-process path on a 1-GPU box (all ranks on cuda:0, gloo
     # collectives) — never used by the driver, numbers from it are meaningless.
     single_dev = os.environ.get("QP_BENCH_SINGLE_DEVICE") == "1"
@@ -278,138 +686,98 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    tp_group = None
+    group, backend = None, None
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if single_dev:
             torch.distributed.init_process_group("gloo")
         else:
             torch.distributed.init_process_group("nccl", device_id=device)    # nccl == RCCL over xGMI on ROCm
-        tp_group = torch.distributed.group.WORLD
+        group = torch.distributed.group.WORLD
+        backend = torch.distributed.get_backend()
 
-    # layout = (pp stages) x (sp ranks per stage); auto picks it from the number of groups (long videos keep a layer pipeline full,
-    # short ones split each group's tokens); "sp" / "pp" force the pure forms, "tp" is tensor parallel
-    _, frames_, _, _, gs_, _, _, _ = CONFIGS[args.config]
-    n_groups_ = -(-frames_ // gs_)
-    layout = (1, 1)
-    if world > 1:
-        layout = {"auto": choose_layout(n_groups_, world), "sp": (1, world), "pp": (world, 1), "tp": (1, 1)}[args.parallel]
-    if args.parallel != "tp":
-        args.parallel = "single" if world == 1 else ("sp" if layout[0] == 1 else "pp" if layout[1] == 1 else "ppsp")
-    spec, cfg, plan, eng, embeds, pos, T = build_workload(args.config, device, rank, world, parallel=args.parallel, layout=layout)
-    if args.parallel == "tp":
-        eng.tp_group = tp_group
-    elif world > 1:
-        pp_n, sp_n = layout
-        if sp_n == world:
-            eng.sp_group = tp_group
-        elif sp_n > 1:                        # every rank creates every stage's group, in the same order
-            stage_groups = [torch.distributed.new_group(ranks=list(range(s * sp_n, (s + 1) * sp_n))) for s in range(pp_n)]
-            eng.sp_group = stage_groups[rank // sp_n]
-    tokens = sum(plan.tokens)                 # tokens prefetched in the group loop (the reference's total_prefill span)
+    name = args.config
+    _, frames_, _, _, gs_, _, _, _ = CONFIGS[name]
+    n_groups_ = -(-frames_ // gs_) if gs_ > 0 else 1
+    timing = "off" if args.no_kernel_timing else "inline"
+    out_extra, tp_block, eff_sp = {}, None, None
+    if world == 1:
+        parallel, layout = "single", (1, 1)
+    elif args.parallel == "tp":
+        parallel, layout = "tp", (1, 1)
+    else:
+        if args.parallel == "both" and not args.window:
+            # the north_star's contract layout: heads / MLP columns sharded, 2 x [n, d] all-reduce + key-sum all-gather per layer
+            res_tp, eng_tp, _ = measure(args, name, device, rank, world, "tp", (1, 1), group, timing=timing)
+            tp_block = {"parallelism": f"tp{world}", **res_tp}
+            del eng_tp
+            torch.cuda.empty_cache()
+        if args.parallel in ("both", "auto"):
+            eff_sp = probe_sp_efficiency(name, device, rank, world, single_dev)
+            layout = choose_layout(n_groups_, world, eff_sp)
+        else:
+            layout = {"sp": (1, world), "pp": (world, 1)}[args.parallel]
+        parallel = "sp" if layout[0] == 1 else "pp" if layout[1] == 1 else "ppsp"
 
-    def barrier():
+    res, eng, ctx = measure(args, name, device, rank, world, parallel, layout, group, timing=timing, telemetry=(world == 1))
+    if args.window:
+        if rank == 0:
+            print(json.dumps({"config": describe(name), **res}))
         if world > 1:
-            torch.distributed.barrier()
-        torch.cuda.synchronize()
+            torch.distributed.destroy_process_group()
+        return
+    attach_traffic(res.get("roofline"), name, world)
 
-    # the engine chooses its GEMM decompositions / hipBLASLt algorithms the first time a segment size shows up (one-off, like
-    # building the weights): with --warmup 0 that first use must not land in the timed steps
-    for _ in range(max(args.warmup, 1)):
-        run_step(eng, plan, embeds, pos)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        tok = run_step(eng, plan, embeds, pos)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        dt = float(t.item())
-    ms_per_step = dt / args.steps * 1e3
-
-    # TTFT of the prefill leg: one step ending with the first token id on the host
-    barrier()
-    first, ttft_ms = int(tok.item()), None
-    if not args.no_ttft:
-        t1 = time.perf_counter()
-        first = int(run_step(eng, plan, embeds, pos).item())
-        ttft_ms = (time.perf_counter() - t1) * 1e3
-
-    decode = None
-    if world == 1 and not args.no_decode:
-        decode = decode_leg(eng, first)            # the engine holds the cache of the last step (prefill + tail)
-
-    lin, att, prune_bytes = flops_and_bytes(spec, cfg, plan, world)
-    roofline = None
-    extra = {}
-    if not args.no_kernel_timing:
-        timed = TimedOps(eng.ops, ["prefill_attn", "prune_staged", "rope_append", "add_rmsnorm", "swiglu"])
-        real_ops, eng.ops = eng.ops, timed
-        run_step(eng, plan, embeds, pos)
-        eng.ops = real_ops
-        tot = timed.totals_ms()
-        att_ms, att_n = tot["prefill_attn"]
-        att_local = att / world                                  # tp: heads sharded
-        if world > 1 and args.parallel != "tp":                  # rank 0: its stage's layers x its zigzag query rows
-            pp_n, sp_n = layout
-            l0_, l1_ = pp_layer_split(spec.n_layers, pp_n, rank // sp_n)
-            att_local, Pp = 0.0, 0
-            for n in plan.tokens:
-                if sp_n > 1 and n >= 64 * sp_n:
-                    for lo, hi in sp_row_ranges(n, sp_n, rank % sp_n):
-                        att_local += 4.0 * spec.n_layers * spec.n_heads * spec.head_dim * sum(Pp + i + 1 for i in range(lo, hi))
-                else:
-                    att_local += spec.attn_flops(n, Pp)
-                Pp += effective_k(n, cfg, 0, spec.n_layers) or n
-            att_local = (att_local + spec.attn_flops(plan.tail_len, Pp)) * (l1_ - l0_) / spec.n_layers
-        ach = att_local / (att_ms * 1e-3) / 1e12
-        traffic = None            # HBM bytes per launch from the committed rocprofv3 PMC passes (tools/profile_bench.sh), same command
-        tpath = os.path.join(ROOT, "profiles", "attn_pmc_traffic_latest.json")
-        if args.config == "cfg2" and world == 1 and os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("attn_fwd_kernel_s6", {}).get("traffic_bytes_per_launch")
-        roofline = {"kernel": "attn_fwd_kernel_s6 (MFMA prefill attention over pruned prefix + causal tail)", "bound": "mfma",
-                    "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-                    "traffic": traffic, "launches": att_n, "avg_launch_ms": round(att_ms / max(att_n, 1), 4),
-                    "algorithmic_flops_per_step": att_local}
-        pr_ms = tot["prune_staged"][0]
-        if pr_ms > 0:
-            pb = prune_bytes / world if world > 1 else prune_bytes
-            extra["roofline_prune"] = {"kernels": "prune_fused_kernel (select + gather, one launch)", "bound": "hbm",
-                                       "achieved": round(pb / (pr_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                       "frac": round(pb / (pr_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "launches": tot["prune_staged"][1],
-                                       "ms_per_step": round(pr_ms, 3), "algorithmic_bytes_per_step": pb}
-        extra["kernel_ms_per_step"] = {k: round(v[0], 3) for k, v in tot.items()}
-
-    pipe_stats = None
-    if world == 1 and not args.no_pipeline:
-        pipe_stats = pipeline_leg(args.config, eng, device)
+    decode = pipe_stats = cpu = secondary = None
+    if world == 1:
+        if not args.no_decode:
+            decode = decode_leg(eng, res["first_token"])           # the engine holds the cache of the timed pass (prefill + tail)
+        if not args.no_pipeline:
+            long_video = ctx["fraction"]
+            pipe_stats = pipeline_leg(name, eng, device, modes=("overlapped",) if long_video else ("overlapped", "sequential"))
+        if not args.no_secondary and name != "cfg2" and CONFIGS[name][0] == "qwen2-vl-7b":
+            secondary = secondary_cfg2(args, device, eng.w)
+        if not args.no_cpu_baseline and rank == 0:
+            cpu = cpu_baseline(name)
 
     if rank == 0:
+        plan, spec = ctx["plan"], ctx["spec"]
+        plan_desc = {"groups": len(plan.tokens), "tokens_per_group": plan.tokens[-1], "prefill_tokens": ctx["tokens"],
+                     "tail_tokens": plan.tail_len, "layers": spec.n_layers}
+        step_desc = (f"1/{args.steps} of the video's sequential group loop (groups [i*G//K, (i+1)*G//K) through all layers; the last "
+                     f"step also runs the prompt tail -> first-token logits): the {args.steps} timed steps are exactly one full prefill"
+                     if ctx["fraction"] else "one full pass over the video (all groups x all layers + prompt tail -> first-token logits)")
+        par = "single" if world == 1 else (f"tp{world}" if parallel == "tp" else f"pp{layout[0]}xsp{layout[1]}")
         out = {
-            "metric": "prefill_tokens_per_s", "value": round(tokens / (ms_per_step * 1e-3), 1), "unit": "tokens/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "metric": "prefill_tokens_per_s", "value": res["value"], "unit": "tokens/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": res["ms_per_step"],
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{args.config}: {CONFIGS[args.config][0]}, {CONFIGS[args.config][1]} frames "
-                                   f"{CONFIGS[args.config][2]}x{CONFIGS[args.config][3]}, group_size {CONFIGS[args.config][4]}, "
-                                   f"key-norm rho={CONFIGS[args.config][5]}",
-                       "groups": len(plan.tokens), "tokens_per_group": plan.tokens[-1], "prefill_tokens": tokens,
-                       "tail_tokens": plan.tail_len, "layers": spec.n_layers, "parallelism": ("single" if world == 1 else f"tp{world}" if args.parallel == "tp" else
-                                                                                   f"pp{layout[0]}xsp{layout[1]}"),
-                       "vit": "excluded (synthetic ViT-output embeddings resident in HBM)",
+            "config": {"workload": describe(name), **plan_desc, "parallelism": par, "step": step_desc,
+                       "warmup_step": "first 4 groups + prompt tail of the same video, arena reset afterwards" if ctx["fraction"] else "one full pass",
+                       "vit": "excluded from `value` (synthetic ViT-output embeddings resident in HBM); included in video_to_first_token",
                        "weights": "seeded random at real dims"},
-            "ttft_ms_prefill_leg": None if ttft_ms is None else round(ttft_ms, 3), "first_token": first,
-            "decode": decode,
-            "algorithmic_tflop_per_step": round((lin + att) / 1e12, 2),
-            "mfma_frac_whole_step": round((lin + att) / world / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
-            "roofline": roofline,
+            "full_prefill_ms": res["full_prefill_ms"], "ttft_ms_prefill_leg": res["full_prefill_ms"], "first_token": res["first_token"],
+            "algorithmic_tflop_per_pass": res["algorithmic_tflop_per_pass"], "mfma_frac_whole_pass": res["mfma_frac_whole_pass"],
+            "roofline": res.get("roofline"),
         }
-        out.update(extra)
+        for k in ("roofline_prune", "kernel_ms_per_pass", "telemetry"):
+            if k in res:
+                out[k] = res[k]
+        if world > 1:
+            out["rccl_ranks"] = {"world_size": torch.distributed.get_world_size(), "backend": backend,
+                                 "note": "backend 'nccl' is RCCL over xGMI on ROCm; 'gloo' only under QP_BENCH_SINGLE_DEVICE=1"}
+            if eff_sp is not None:
+                out["sp_efficiency_probe"] = {str(k): v for k, v in eff_sp.items()}
+            if tp_block is not None and parallel != "tp":
+                out["tp"] = tp_block
+        if decode:
+            out["decode"] = decode
         if pipe_stats:
             out["video_to_first_token"] = pipe_stats
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.config)
+        if cpu:
+            out["cpu_baseline"] = cpu
+        if secondary:
+            out["cfg2"] = secondary
         print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()

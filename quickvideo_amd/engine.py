@@ -267,14 +267,14 @@ class QuickPrefillEngine:
         return allb[::rep].contiguous(), total
 
     # ------------------------------------------------------------------ one segment through all layers
-    def forward_segment(self, embeds: torch.Tensor, pos: torch.Tensor, prune: bool) -> torch.Tensor:
+    def forward_segment(self, embeds: torch.Tensor, pos: torch.Tensor, prune: bool, video_group: bool = False) -> torch.Tensor:
         """embeds [n, d] (device, engine dtype), pos int64 [3, n].  Returns the final hidden rows [n', d] (pre-norm)
         (group-token parallel segments: this rank's rows only)."""
         s, ops, cfg, D = self.spec, self.ops, self.cfg, self.D
         n = pos.shape[1]                             # embeds may hold only this rank's rows (sp stage behind another stage)
         assert n <= self.n_max, f"group of {n} tokens exceeds max_group_tokens={self.n_max}"
         if self._sp_active(n):
-            return self._forward_segment_sp(embeds, pos, prune)
+            return self._forward_segment_sp(embeds, pos, prune, video_group)
         assert embeds.shape[0] == n
         L = self.n_layers_total                      # effective_k's decay uses the GLOBAL layer index / count
         cos, sin = ops.mrope_table(pos.contiguous(), s.mrope_section, s.rope_theta, D)
@@ -307,9 +307,10 @@ class QuickPrefillEngine:
                 ops.rope_append(qkv, cos, sin, self.hq, self.hkv, D, q, kc, vc, self.arena.head_stride, past, None)
                 kn, vn, new_stride = kc[:, past:], vc[:, past:], self.arena.head_stride
             att = self.b_att[:n]
-            # adaptive_local_attention=False: video groups are prefilled independently (no cross-group attention,
-            # qwen25_lvu.py:700-714); their pruned K/V still accumulate in the arena for the prompt tail.
-            past_attn = past if (cfg.adaptive_local_attention or not prune) else 0
+            # adaptive_local_attention=False: VIDEO GROUPS are prefilled independently (no cross-group attention,
+            # qwen25_lvu.py:700-714); their pruned K/V still accumulate in the arena, and the prompt tail / decode steps always
+            # attend to all of it (:724-742), also when do_top_k_for_query prunes them.
+            past_attn = 0 if (video_group and not cfg.adaptive_local_attention) else past
             ops.prefill_attn(q, self.arena.k(l), self.arena.v(l), self.arena.head_stride, past_attn, kn, vn, new_stride, n, self.hq,
                              self.hkv, D, scale, att)                        # :61-62, :102-112
             o = self.b_o[:n]
@@ -353,7 +354,7 @@ class QuickPrefillEngine:
         return h
 
     # ------------------------------------------------------------------ group-token parallel variant of forward_segment
-    def _forward_segment_sp(self, embeds: torch.Tensor, pos: torch.Tensor, prune: bool) -> torch.Tensor:
+    def _forward_segment_sp(self, embeds: torch.Tensor, pos: torch.Tensor, prune: bool, video_group: bool = False) -> torch.Tensor:
         """Rank r runs its token rows of the segment through every layer; per layer ONE all-gather moves the ranks' new K/V rows
         and key sums, after which every rank holds the whole group's K/V in its staging block, attends its own query rows
         (qp_prefill_attn_rows) and applies the identical prune to its arena replica.  Rows are dealt "zigzag" (sp_row_ranges):
@@ -410,7 +411,7 @@ class QuickPrefillEngine:
             if self.norm_source == 1 and k_keep is not None:                 # vector_norms*: every rank scores the gathered value rows
                 ops.key_sumsq(vn, new_stride, 0, n, self.hkv, D, ss_all)
             att = self.b_att[:ml]
-            past_attn = past if (cfg.adaptive_local_attention or not prune) else 0
+            past_attn = 0 if (video_group and not cfg.adaptive_local_attention) else past
             for (q0, lo_, hi_) in ((a0, 0, nA), (b0, nA, ml)):               # the two row chunks of this rank
                 if hi_ > lo_:
                     ops.prefill_attn(q[lo_:hi_], self.arena.k(l), self.arena.v(l), self.arena.head_stride, past_attn, kn, vn, new_stride,
@@ -488,7 +489,7 @@ class QuickPrefillEngine:
     def prefill_group(self, embeds: torch.Tensor, pos: torch.Tensor):
         """One video group (qwen25_lvu.py:671-717): KV appended + pruned; hidden output is discarded like the
         reference discards the group's logits (:697-699).  (Layer pipeline: `embeds` only matters on stage 0.)"""
-        h = self.forward_segment(self._pp_in(embeds), pos, prune=True)
+        h = self.forward_segment(self._pp_in(embeds), pos, prune=True, video_group=True)
         self._pp_out(h)
         self.seq_pos += embeds.shape[0]
 

@@ -72,6 +72,8 @@ class _Producer(threading.Thread):
         self.slots_free = threading.Semaphore(depth)
         self.ring = None
         self.fpg = frames_per_group
+        self.h2d_done = [None] * depth      # per slot: event after the last H2D copy out of the pinned buffer (copy stream)
+        self.read_done = [None] * depth     # per slot: event after the consumer's last GPU read of the device buffer (ViT stream)
 
     def run(self):
         try:
@@ -87,12 +89,22 @@ class _Producer(threading.Thread):
                             self.ring_cache[key] = [(torch.empty(shape, dtype=torch.uint8).pin_memory(),
                                                      torch.empty(shape, dtype=torch.uint8, device=self.device)) for _ in range(self.depth)]
                         self.ring = self.ring_cache[key]
-                    host, dev = self.ring[g % self.depth]
-                    host[: frames.shape[0]].copy_(frames)
+                    slot = g % self.depth
+                    host, dev = self.ring[slot]
+                    # slot reuse is ordered explicitly, not by luck: (1) the pinned host buffer may only be overwritten once the
+                    # previous H2D copy out of it has finished (host-side wait, this thread only); (2) the device buffer may only
+                    # be overwritten once the consumer's last GPU read of it (patchify on the ViT stream) has finished — the
+                    # consumer hands that event back through release() and the copy stream waits on it.
+                    if self.h2d_done[slot] is not None:
+                        self.h2d_done[slot].synchronize()
+                    host[: frames.shape[0]].copy_(frames)           # torch releases the GIL inside copy_ (measured: tests/test_api_cpu.py)
                     with torch.cuda.stream(self.copy_stream):
+                        if self.read_done[slot] is not None:
+                            self.copy_stream.wait_event(self.read_done[slot])
                         dev[: frames.shape[0]].copy_(host[: frames.shape[0]], non_blocking=True)
                         ev = torch.cuda.Event()
                         ev.record(self.copy_stream)
+                    self.h2d_done[slot] = ev
                     self.q.put((g, dev[: frames.shape[0]], ev))
                 else:
                     self.q.put((g, frames.clone(), None))
@@ -106,7 +118,9 @@ class _Producer(threading.Thread):
             raise self.exc
         return item
 
-    def release(self):
+    def release(self, g: int = 0, read_done=None):
+        """Group g's slot may be refilled; `read_done` = event recorded after the last GPU read of its device buffer."""
+        self.read_done[g % self.depth] = read_done
         self.slots_free.release()
 
 
@@ -207,26 +221,32 @@ class PrefillPipeline:
                 with torch.cuda.stream(self.vit_stream):
                     s_ev.record(self.vit_stream)
                     rows, grid = patchify_frames(frames, self.model.vision.spec, self.model.text.embed.dtype)
+                    read_done = torch.cuda.Event()
+                    read_done.record(self.vit_stream)             # last read of the ring's device slot
                     feats = self.tower.forward(rows, grid)
                     e_ev.record(self.vit_stream)
-                return feats, (s_ev, e_ev)
+                return feats, (s_ev, e_ev), read_done
             rows, grid = patchify_frames(frames, self.model.vision.spec, self.model.text.embed.dtype)
-            return self.tower.forward(rows, grid), None
+            return self.tower.forward(rows, grid), None, None
 
         t_pre = time.perf_counter()
         start, vit_events = 0, []
         nxt = vit_group(0)
         for g, n in enumerate(plan.tokens):
-            feats, evs = nxt
+            feats, evs, read_done = nxt
             if self.use_gpu:
-                torch.cuda.current_stream(dev).wait_event(evs[1])
+                main = torch.cuda.current_stream(dev)
+                main.wait_event(evs[1])
+                # feats was allocated on the ViT stream and is read on the main stream (cat / copy into the engine's buffer): tell
+                # the caching allocator, or ViT(g+2) could be handed the same block while prefill(g) is still queued
+                feats.record_stream(main)
                 vit_events.append(evs)
             emb = torch.cat([eng.embed_tokens(prefix), feats], 0) if g == 0 else feats
             assert emb.shape[0] == n, (emb.shape, n)
             if g + 1 < len(plan.tokens):
                 nxt = vit_group(g + 1)                                # ViT of the next group runs ahead on its own stream
             eng.prefill_group(emb, pos[:, start:start + n])
-            prod.release()
+            prod.release(g, read_done)
             start += n
         sync()
         tm.prefill = time.perf_counter() - t_pre

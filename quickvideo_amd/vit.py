@@ -59,6 +59,19 @@ QWEN2_VL_VIT_72B = VisionSpec(out_hidden=8192)
 TINY_VIT = VisionSpec(depth=2, embed_dim=64, num_heads=4, mlp_ratio=2.0, out_hidden=256)
 
 
+_CLIP_CONST: dict = {}
+
+
+def _clip_constants(device):
+    """CLIP mean/std as device tensors, built once per device: a torch.tensor(..., device=cuda) per group is a blocking pageable
+    H2D copy that stalls the launch thread (and used to hide a ring-slot race in the pipeline by accident)."""
+    key = str(device)
+    if key not in _CLIP_CONST:
+        _CLIP_CONST[key] = (torch.tensor(CLIP_MEAN, dtype=torch.float32).view(1, 3, 1, 1).to(device),
+                            torch.tensor(CLIP_STD, dtype=torch.float32).view(1, 3, 1, 1).to(device))
+    return _CLIP_CONST[key]
+
+
 def patchify_frames(frames_u8: torch.Tensor, spec: VisionSpec, dtype=torch.bfloat16) -> Tuple[torch.Tensor, Tuple[int, int, int]]:
     """uint8 frames [F, 3, H, W] (already at the smart_resize target size) -> (pixel rows [grid_t*grid_h*grid_w, 1176],
     (grid_t, grid_h, grid_w)) in the HF Qwen2VLImageProcessor order (t, h/2, w/2, 2, 2 | C, T, 14, 14) [3P]."""
@@ -66,8 +79,7 @@ def patchify_frames(frames_u8: torch.Tensor, spec: VisionSpec, dtype=torch.bfloa
     ps, tp, mg = spec.patch_size, spec.temporal_patch_size, spec.spatial_merge_size
     assert Fn % tp == 0 and H % (ps * mg) == 0 and W % (ps * mg) == 0, "frame count / size not aligned to the patch grid"
     gt, gh, gw = Fn // tp, H // ps, W // ps
-    mean = torch.tensor(CLIP_MEAN, device=frames_u8.device, dtype=torch.float32).view(1, C, 1, 1)
-    std = torch.tensor(CLIP_STD, device=frames_u8.device, dtype=torch.float32).view(1, C, 1, 1)
+    mean, std = _clip_constants(frames_u8.device)
     x = (frames_u8.to(torch.float32) * (1.0 / 255.0) - mean) / std
     x = x.view(gt, tp, C, gh // mg, mg, ps, gw // mg, mg, ps).permute(0, 3, 6, 4, 7, 2, 1, 5, 8)
     return x.reshape(gt * gh * gw, C * tp * ps * ps).to(dtype), (gt, gh, gw)
