@@ -529,7 +529,23 @@ def measure(args, name, device, rank, world, parallel, layout, group, weights=No
         else:
             run_video(eng, plan, starts, embeds, pos)
 
-    timed_names = ["prefill_attn", "prune_staged"] if fraction else ["prefill_attn", "prune_staged", "rope_append", "add_rmsnorm", "swiglu"]
+    # floor of ANY launch in the prune's position (right after the o_proj GEMM): a 1-thread kernel bracketed the same way.  The
+    # prune moves 7-18 MB per launch, i.e. 1-3 us of HBM time, so its bracket is this floor + a latency chain, not bandwidth.
+    floor_us = None
+    if timing != "off" and world == 1 and getattr(eng, "_keys_path", False):
+        eng.reset()
+        eng._prune_probe, eng._probe_key = True, torch.empty(8, dtype=torch.int16, device=device)
+        probe = TimedOps(eng.ops, ["norm_keys"])
+        real0, eng.ops = eng.ops, probe
+        run_groups(eng, plan, starts, embeds, pos, 0, min(G, 2))
+        eng.ops, eng._prune_probe = real0, False
+        pt = probe.totals_ms()["norm_keys"]
+        floor_us = round(pt[0] / max(pt[1], 1) * 1e3, 2)
+        eng.reset()
+
+    PRUNE_OPS = ["prune_keys", "norm_keys", "prune_staged"]       # the prune step's launches (staged = the round-1 form, n > 8192)
+    timed_names = ["prefill_attn"] + PRUNE_OPS + ([] if fraction else ["rope_append", "rope_append_keys", "add_rmsnorm", "swiglu"])
+    timed_names = [t for t in timed_names if hasattr(eng.ops, t)]
     timed = TimedOps(eng.ops, timed_names) if (timing != "off") else None
     real_ops = eng.ops
     tele = Telemetry() if telemetry else None
@@ -598,14 +614,21 @@ def measure(args, name, device, rank, world, parallel, layout, group, weights=No
                            "avg_launch_ms": round(att_ms / max(att_n, 1), 4), "algorithmic_flops_per_launch": att_local / max(att_n, 1),
                            "algorithmic_flops_per_pass": att_local, "kernel_ms_per_pass": round(att_ms, 2),
                            "timing": "HIP events on the launch stream, " + ("inside the timed region" if fraction else "one extra pass")}
-        pr_ms, pr_n = tot["prune_staged"]
+        pr_ms = sum(tot[t][0] for t in PRUNE_OPS if t in tot)
+        pr_n = max([tot[t][1] for t in PRUNE_OPS if t in tot] + [0])
         if pr_ms > 0:
             pb = prune_bytes / world if world > 1 else prune_bytes
-            res["roofline_prune"] = {"kernels": "qp_prune_staged (key-norm select + KV gather)", "bound": "hbm",
+            res["roofline_prune"] = {"kernels": "prune step per layer: " + " + ".join(f"qp_{t}" for t in PRUNE_OPS if tot.get(t, (0, 0))[1]) +
+                                                " (radix select on the 16-bit norm keys + KV gather, one launch; the keys come out of the RoPE/append kernel)",
+                                     "bound": "hbm",
                                      "achieved": round(pb / (pr_ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                      "frac": round(pb / (pr_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "launches": pr_n,
                                      "avg_launch_us": round(pr_ms / max(pr_n, 1) * 1e3, 2), "ms_per_pass": round(pr_ms, 3),
-                                     "algorithmic_bytes_per_pass": pb, "algorithmic_bytes_per_launch": pb / max(pr_n, 1)}
+                                     "algorithmic_bytes_per_pass": pb, "algorithmic_bytes_per_launch": pb / max(pr_n, 1),
+                                     "empty_launch_floor_us": floor_us,
+                                     "note": "empty_launch_floor_us = bracket of a 1-thread kernel launched in the same position (after the "
+                                             "o_proj GEMM: launch + cold instruction cache + event pair); the prune's bytes are 1-3 us of HBM time, "
+                                             "so this launch is latency-bound whatever the kernel does"}
         res["kernel_ms_per_pass"] = {k: round(v[0], 3) for k, v in tot.items()}
     ctx = dict(spec=spec, cfg=cfg, plan=plan, embeds=embeds, pos=pos, starts=starts, tokens=tokens, fraction=fraction, G=G)
     return res, eng, ctx

@@ -67,6 +67,15 @@ int qp_rope_append(qp_ctx* ctx, const void* qkv, const void* cos, const void* si
                    int n_kv_heads, int head_dim, void* q_out, void* k_dst, void* v_dst, int64_t dst_head_stride,
                    int64_t dst_row0, float* head_sumsq, void* stream);
 
+/* qp_rope_append that also prepares the layer's prune (seam 1) while it holds the key rows: the 16-bit norm key of every token
+ * (bf16 pattern of the cross-head key norm bf16(sqrt(((s0+s1)+s2)+...)), complemented when the ctx's prune order is "k largest")
+ * goes to norm_keys[t] (uint16 [n]) for qp_prune_keys.  Needs all KV heads of the layer in this call (no tensor-parallel head
+ * sharding) and n_kv_heads in {1, 2, 4} with n_q_heads a multiple of it; returns QP_ERR_UNSUPPORTED otherwise — callers then
+ * use qp_rope_append + qp_norm_keys.  head_sumsq may be NULL. */
+int qp_rope_append_keys(qp_ctx* ctx, const void* qkv, const void* cos, const void* sin, int64_t n, int n_q_heads,
+                        int n_kv_heads, int head_dim, void* q_out, void* k_dst, void* v_dst, int64_t dst_head_stride,
+                        int64_t dst_row0, float* head_sumsq, uint16_t* norm_keys, void* stream);
+
 /* ---- seam 3: prefill attention over (pruned prefix, new group)  (qwen25_lvu.py:61-62,102-112) - */
 /* q bf16 [n][n_q][128]; prefix K/V rows [0,prefix_len) with head stride prefix_head_stride; new K/V rows
  * [0,n) with head stride new_head_stride.  Query i attends every prefix key and new keys j <= i
@@ -125,6 +134,20 @@ int qp_gather_kv(qp_ctx* ctx, const void* k_src, const void* v_src, int64_t src_
 int qp_prune_staged(qp_ctx* ctx, const float* head_sumsq, int n_heads_total, int64_t n, int64_t k, const void* k_src,
                     const void* v_src, int64_t src_head_stride, int n_kv_heads, int head_dim, void* k_dst, void* v_dst,
                     int64_t dst_head_stride, int64_t dst_row0, int32_t* kept_idx_out, uint16_t* norm_bits_out, void* stream);
+
+/* The engine's prune step since round 2 (one launch; replaces qp_prune_staged, which recomputed every norm with an fp64
+ * square root in each of up to 256 workgroups and needed up to 150 KB of LDS):
+ *   qp_norm_keys   head_sumsq fp32 [n_heads_total][n] -> norm_keys uint16 [n].  Only needed when qp_rope_append_keys could not
+ *                  produce them (tensor-/group-token-parallel gathered sums, value-row norms, 8 KV heads in one process).
+ *   qp_prune_keys  one workgroup per 16 tokens: all n keys in registers, threshold key by a two-pass radix select in LDS, kept
+ *                  tokens in front of the slice counted from the same registers, K/V rows of the slice's kept tokens moved
+ *                  src -> dst rows [dst_row0, dst_row0+k); kept_idx_out int32 [k] ascending; same tie rule as
+ *                  qp_select_k_smallest (keys below the threshold, then ties by lowest index).  Requires 0 < k <= n <= 8192,
+ *                  n_kv_heads <= 8 (larger n: qp_select_k_smallest + qp_gather_kv). */
+int qp_norm_keys(qp_ctx* ctx, const float* head_sumsq, int n_heads_total, int64_t n, uint16_t* norm_keys, void* stream);
+int qp_prune_keys(qp_ctx* ctx, const uint16_t* norm_keys, int64_t n, int64_t k, const void* k_src, const void* v_src,
+                  int64_t src_head_stride, int n_kv_heads, int head_dim, void* k_dst, void* v_dst, int64_t dst_head_stride,
+                  int64_t dst_row0, int32_t* kept_idx_out, void* stream);
 
 /* In-place drop-in for post_process_kv_cache's KV part on the arena (utils.py:266-342):
  * rows [past_len, past_len+n) are the group's new tokens; on return rows [past_len, past_len+k) hold the

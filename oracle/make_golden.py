@@ -403,6 +403,108 @@ def gen_rope_index():
     json.dump(rows, open(os.path.join(OUT, "gv6_rope_index.json"), "w"), indent=1)
 
 
+
+# ---------------------------------------------------------------- GV8: full depth at the real 7B dims
+
+DEEP = dict(hidden=3584, n_heads=28, n_kv_heads=4, head_dim=128, intermediate=18944, n_layers=28, vocab=32768)
+DEEP_CASE = dict(frames=48, grid_h=16, grid_w=40, group_size=16, prefix=15, tail=30, top_p=0.5, weight_seed=11, embed_seed=12)
+
+
+def build_hf_text(tspec: dict, seed: int, dtype=torch.bfloat16, attn="sdpa"):
+    """Installed transformers' Qwen2-VL text decoder at the given dims with hash-generated weights (O.hashed_text_weights:
+    the same bits on any device, so the GPU test regenerates them instead of shipping 15 GB)."""
+    from transformers.models.qwen2_vl.modeling_qwen2_vl import Qwen2VLTextConfig, Qwen2VLTextModel
+    cfg = Qwen2VLTextConfig(hidden_size=tspec["hidden"], num_attention_heads=tspec["n_heads"], num_key_value_heads=tspec["n_kv_heads"],
+                            intermediate_size=tspec["intermediate"], num_hidden_layers=tspec["n_layers"], vocab_size=tspec["vocab"],
+                            rms_norm_eps=1e-6, max_position_embeddings=32768, tie_word_embeddings=False,
+                            rope_parameters=dict(rope_type="default", mrope_section=[16, 24, 24], rope_theta=1_000_000.0))
+    cfg._attn_implementation = attn
+    prev = torch.get_default_dtype()
+    torch.set_default_dtype(dtype)
+    try:
+        lm = Qwen2VLTextModel(cfg).eval()
+    finally:
+        torch.set_default_dtype(prev)
+    spec = O.TextSpec(**tspec)
+    w = O.hashed_text_weights(spec, seed=seed, dtype=dtype)
+    sd = {}
+    for k, v in w.items():
+        if k == "lm_head.weight":
+            continue
+        sd[k.replace("q_proj", "self_attn.q_proj").replace("k_proj", "self_attn.k_proj").replace("v_proj", "self_attn.v_proj")
+           .replace("o_proj", "self_attn.o_proj")] = v
+    missing, unexpected = lm.load_state_dict(sd, strict=False, assign=True)
+    assert not unexpected and all("rotary" in m for m in missing), (missing, unexpected)
+    return lm, spec, w
+
+
+def gen_e2e_deep(ref):
+    """GV8: 28 layers at the Qwen2-VL-7B dims (d=3584, 28/4 heads, I=18944; vocab cut to 32768), bf16, 3 groups x 1280 tokens
+    (+15 prefix on group 0) + 30-token tail, key-norm rho=0.5, through the composite oracle: installed HF decoder (sdpa) + the
+    REFERENCE's post_process_kv_cache in a forward hook after every attention, get_top_k_mask_to_predict wrapped to record the mask
+    it returns.  Stored: cache lengths, the kept-index list of every (group, layer), the first-token logits."""
+    from transformers import DynamicCache
+    U, C = ref["utils"], ref["lvu_config"]
+    c = DEEP_CASE
+    lm, spec, w = build_hf_text(DEEP, c["weight_seed"])
+    n_video = (c["frames"] // 2) * (c["grid_h"] // 2) * (c["grid_w"] // 2)
+    T = c["prefix"] + n_video + c["tail"]
+    plan = O.plan_groups(c["frames"], c["group_size"], c["grid_h"], c["grid_w"], c["prefix"], T)
+    pos, delta = O.mrope_positions(c["prefix"], (c["frames"] // 2, c["grid_h"], c["grid_w"]), c["tail"])
+    embeds = O.hashed_normal((T, spec.hidden), c["embed_seed"], 0.5)
+    cfg = C.LVUConfig(model_name_or_path="x", top_p=c["top_p"])
+    layer_cfgs = [C.LVULayerConfig(layer_idx=i, total_layers=spec.n_layers, lvu_config=cfg) for i in range(spec.n_layers)]
+    cache = DynamicCache(config=lm.config)
+    masks = []
+    orig_mask_fn = U.get_top_k_mask_to_predict
+
+    def rec_mask(*a, **kw):
+        m = orig_mask_fn(*a, **kw)
+        masks.append(torch.nonzero(m[0], as_tuple=True)[0].numpy().astype(np.int16))
+        return m
+    U.get_top_k_mask_to_predict = rec_mask
+
+    def make_hook(i):
+        def hook(mod, args, kwargs, output):
+            lay = cache.layers[i]
+            with force_stable_argsort():
+                res = U.post_process_kv_cache(kwargs["hidden_states"], None, None, None, None, None, (lay.keys, lay.values), layer_cfgs[i])
+            lay.keys, lay.values = res[5]
+            return output
+        return hook
+    hooks = [l.self_attn.register_forward_hook(make_hook(i), with_kwargs=True) for i, l in enumerate(lm.layers)]
+    segs = plan.tokens + [plan.tail_len]
+    post = torch.from_numpy(pos)
+    start = 0
+    import time
+    t0 = time.time()
+    with torch.no_grad():
+        for gi, n in enumerate(segs):
+            if gi == len(segs) - 1:
+                cfg.enable = False
+            o = lm(inputs_embeds=embeds[None, start:start + n], position_ids=post[:, None, start:start + n], past_key_values=cache,
+                   use_cache=True, cache_position=torch.arange(n) + start)
+            start += n
+            print("segment", gi, n, f"{time.time() - t0:.1f}s", flush=True)
+        logits = torch.nn.functional.linear(o.last_hidden_state[0, -1:], w["lm_head.weight"]).float()[0]
+    for h in hooks:
+        h.remove()
+    U.get_top_k_mask_to_predict = orig_mask_fn
+    L, G = spec.n_layers, len(plan.tokens)
+    assert len(masks) == L * G, len(masks)
+    out = {"logits": logits.numpy(), "cache_len": np.array([cache.layers[i].keys.shape[2] for i in range(L)], dtype=np.int32)}
+    for gi in range(G):
+        for l in range(L):
+            out[f"kept_g{gi}_l{l}"] = masks[gi * L + l]
+    srt = np.sort(out["logits"])[::-1]
+    meta = dict(DEEP_CASE, spec=DEEP, group_tokens=plan.tokens, tail_len=plan.tail_len, rope_delta=int(delta), dtype="bfloat16",
+                attn_implementation="sdpa", argmax=int(np.argmax(out["logits"])), top2_margin=float(srt[0] - srt[1]),
+                logit_absmax=float(np.abs(out["logits"]).max()))
+    np.savez_compressed(os.path.join(OUT, "gv8_deep.npz"), **out)
+    json.dump(meta, open(os.path.join(OUT, "gv8_deep.json"), "w"), indent=1)
+    print(meta)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     ref = load_reference()
@@ -415,3 +517,4 @@ if __name__ == "__main__":
     if "e2e_modes" in which: gen_e2e_modes(ref)
     if "e2e_decode" in which: gen_e2e_decode(ref)
     if "rope" in which: gen_rope_index()
+    if "deep" in which: gen_e2e_deep(ref)       # ~20 min of CPU and 40 GB of RAM: not in the default list

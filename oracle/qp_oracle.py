@@ -496,3 +496,65 @@ def synthetic_text_weights(spec: TextSpec, seed: int = 0, dtype: torch.dtype = t
     w["norm.weight"] = (torch.ones(spec.hidden) + mat(spec.hidden, s=norm_jitter).float()).to(dtype)
     w["lm_head.weight"] = w["embed_tokens.weight"] if spec.tie_embeddings else mat(spec.vocab, spec.hidden)
     return w
+
+
+# --------------------------------------------------------------------------------------
+# Hash-generated weights: bit-identical on every device (integer hash -> exact float steps),
+# so a fixture made from them on the build container's CPU can be replayed on the GPU box
+# without shipping 15 GB of weights.  Used by the full-depth 7B-dim parity case (GV8).
+# --------------------------------------------------------------------------------------
+
+def _lowbias32(x: torch.Tensor) -> torch.Tensor:
+    """32-bit integer mixer on int64 tensors (all intermediates < 2^63: exact on CPU and GPU)."""
+    m = 0xFFFFFFFF
+    x = x ^ (x >> 16)
+    x = (x * 0x7FEB352D) & m
+    x = x ^ (x >> 15)
+    x = (x * 0x846CA68B) & m
+    return x ^ (x >> 16)
+
+
+def hashed_normal(shape, seed: int, std: float, device="cpu", dtype=torch.bfloat16, chunk: int = 1 << 25) -> torch.Tensor:
+    """Approximately N(0, std^2) (Irwin-Hall: sum of 3 hashed uniforms, |x| <= 3 std) as a pure function of
+    (seed, flat index): element i is the same bit pattern whichever device computes it (integer ops are exact,
+    every float step is a single IEEE operation, bf16 cast = RNE)."""
+    n = 1
+    for s in shape:
+        n *= int(s)
+    out = torch.empty(n, dtype=dtype, device=device)
+    base = (int(seed) * 0x9E3779B1) & 0xFFFFFFFF
+    for c0 in range(0, n, chunk):
+        c1 = min(n, c0 + chunk)
+        i = torch.arange(c0, c1, dtype=torch.int64, device=device) * 3 + base
+        acc = None
+        for r in range(3):
+            u = (_lowbias32((i + r) & 0xFFFFFFFF) >> 8).to(torch.float32) * (1.0 / 16777216.0)
+            acc = u if acc is None else acc + u
+        out[c0:c1] = ((acc - 1.5) * (2.0 * std)).to(dtype)
+    return out.view(*shape)
+
+
+def hashed_text_weights(spec: TextSpec, seed: int = 0, device="cpu", dtype=torch.bfloat16, std: float = 0.02, bias_std: float = 0.02,
+                        norm_jitter: float = 0.1, layers: Optional[Sequence[int]] = None, with_embed: bool = True) -> dict:
+    """HF-named decoder weights from hashed_normal; every tensor has its own seed (seed, layer, slot), so any subset of
+    layers can be generated alone and agrees with the full model."""
+    d, qd, kd, I = spec.hidden, spec.n_heads * spec.head_dim, spec.n_kv_heads * spec.head_dim, spec.intermediate
+    hn = lambda shape, s, sd: hashed_normal(shape, s, sd, device, dtype)
+    one = lambda s: (1.0 + hashed_normal((d,), s, norm_jitter, device, torch.float32)).to(dtype)
+    w = {}
+    for l in (range(spec.n_layers) if layers is None else layers):
+        p, s0 = f"layers.{l}.", seed * 100_003 + (l + 1) * 101
+        w[p + "input_layernorm.weight"] = one(s0 + 0)
+        w[p + "q_proj.weight"], w[p + "q_proj.bias"] = hn((qd, d), s0 + 1, std), hn((qd,), s0 + 2, bias_std)
+        w[p + "k_proj.weight"], w[p + "k_proj.bias"] = hn((kd, d), s0 + 3, std), hn((kd,), s0 + 4, bias_std)
+        w[p + "v_proj.weight"], w[p + "v_proj.bias"] = hn((kd, d), s0 + 5, std), hn((kd,), s0 + 6, bias_std)
+        w[p + "o_proj.weight"] = hn((d, qd), s0 + 7, std)
+        w[p + "post_attention_layernorm.weight"] = one(s0 + 8)
+        w[p + "mlp.gate_proj.weight"] = hn((I, d), s0 + 9, std)
+        w[p + "mlp.up_proj.weight"] = hn((I, d), s0 + 10, std)
+        w[p + "mlp.down_proj.weight"] = hn((d, I), s0 + 11, std)
+    w["norm.weight"] = one(seed * 100_003 + 7)
+    if with_embed:
+        w["embed_tokens.weight"] = hn((spec.vocab, d), seed * 100_003 + 11, std)
+        w["lm_head.weight"] = w["embed_tokens.weight"] if spec.tie_embeddings else hn((spec.vocab, d), seed * 100_003 + 13, std)
+    return w

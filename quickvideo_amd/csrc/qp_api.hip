@@ -78,7 +78,49 @@ int qp_rope_append(qp_ctx* ctx, const void* qkv, const void* cos, const void* si
              QP_ERR_INVALID, "qp_rope_append: pointers must be 16-byte aligned");
   if (n == 0) return QP_OK;
   return qp_launch_rope_append(qkv, cos, sin, n, n_q_heads, n_kv_heads, q_out, k_dst, v_dst, dst_head_stride, dst_row0,
-                               head_sumsq, (hipStream_t)stream);
+                               head_sumsq, nullptr, 0, (hipStream_t)stream);
+}
+
+int qp_rope_append_keys(qp_ctx* ctx, const void* qkv, const void* cos, const void* sin, int64_t n, int n_q_heads, int n_kv_heads,
+                        int head_dim, void* q_out, void* k_dst, void* v_dst, int64_t dst_head_stride, int64_t dst_row0,
+                        float* head_sumsq, uint16_t* norm_keys, void* stream) {
+  QP_REQUIRE(ctx && qkv && cos && sin && q_out && k_dst && v_dst && norm_keys, QP_ERR_INVALID, "qp_rope_append_keys: NULL argument");
+  QP_REQUIRE(head_dim == 128, QP_ERR_UNSUPPORTED, "qp_rope_append_keys: head_dim=%d (only 128)", head_dim);
+  QP_REQUIRE(n >= 0 && n_q_heads > 0 && n_kv_heads > 0 && dst_row0 >= 0, QP_ERR_INVALID, "qp_rope_append_keys: bad sizes");
+  QP_REQUIRE(qp_rope_can_fuse_keys(n_q_heads, n_kv_heads), QP_ERR_UNSUPPORTED,
+             "qp_rope_append_keys: %d q / %d kv heads: a token's key rows do not share a wave (use qp_rope_append + qp_norm_keys)",
+             n_q_heads, n_kv_heads);
+  QP_REQUIRE(dst_head_stride % 8 == 0 && dst_head_stride >= (dst_row0 + n) * head_dim, QP_ERR_INVALID,
+             "qp_rope_append_keys: head stride %lld too small for rows [%lld,%lld)", (long long)dst_head_stride, (long long)dst_row0,
+             (long long)(dst_row0 + n));
+  QP_REQUIRE(aligned16(qkv) && aligned16(cos) && aligned16(sin) && aligned16(q_out) && aligned16(k_dst) && aligned16(v_dst),
+             QP_ERR_INVALID, "qp_rope_append_keys: pointers must be 16-byte aligned");
+  if (n == 0) return QP_OK;
+  return qp_launch_rope_append(qkv, cos, sin, n, n_q_heads, n_kv_heads, q_out, k_dst, v_dst, dst_head_stride, dst_row0,
+                               head_sumsq, norm_keys, ctx->order, (hipStream_t)stream);
+}
+
+int qp_norm_keys(qp_ctx* ctx, const float* head_sumsq, int n_heads_total, int64_t n, uint16_t* norm_keys, void* stream) {
+  QP_REQUIRE(ctx && head_sumsq && norm_keys, QP_ERR_INVALID, "qp_norm_keys: NULL argument");
+  QP_REQUIRE(n_heads_total > 0 && n > 0 && n < (1ll << 31), QP_ERR_INVALID, "qp_norm_keys: need n_heads_total > 0 and n > 0 (n=%lld)", (long long)n);
+  return qp_launch_norm_keys(head_sumsq, n_heads_total, n, norm_keys, ctx->order, (hipStream_t)stream);
+}
+
+int qp_prune_keys(qp_ctx* ctx, const uint16_t* norm_keys, int64_t n, int64_t k, const void* k_src, const void* v_src,
+                  int64_t src_head_stride, int n_kv_heads, int head_dim, void* k_dst, void* v_dst, int64_t dst_head_stride,
+                  int64_t dst_row0, int32_t* kept_idx_out, void* stream) {
+  QP_REQUIRE(ctx && norm_keys && k_src && v_src && k_dst && v_dst && kept_idx_out, QP_ERR_INVALID, "qp_prune_keys: NULL argument");
+  QP_REQUIRE(head_dim == 128, QP_ERR_UNSUPPORTED, "qp_prune_keys: head_dim=%d (only 128)", head_dim);
+  QP_REQUIRE(k > 0 && k <= n && n_kv_heads > 0 && dst_row0 >= 0, QP_ERR_INVALID, "qp_prune_keys: need 0 < k <= n, got k=%lld n=%lld",
+             (long long)k, (long long)n);
+  QP_REQUIRE(n <= 8192, QP_ERR_UNSUPPORTED, "qp_prune_keys: n=%lld > 8192 (use qp_select_k_smallest + qp_gather_kv)", (long long)n);
+  QP_REQUIRE(n_kv_heads <= 8, QP_ERR_UNSUPPORTED, "qp_prune_keys: n_kv_heads=%d > 8", n_kv_heads);
+  QP_REQUIRE(src_head_stride % 8 == 0 && dst_head_stride % 8 == 0 && src_head_stride >= n * head_dim && dst_head_stride >= (dst_row0 + k) * head_dim,
+             QP_ERR_INVALID, "qp_prune_keys: bad strides");
+  QP_REQUIRE(aligned16(k_src) && aligned16(v_src) && aligned16(k_dst) && aligned16(v_dst) && aligned16(norm_keys), QP_ERR_INVALID,
+             "qp_prune_keys: pointers must be 16-byte aligned");
+  return qp_launch_prune_keys(norm_keys, n, k, k_src, v_src, src_head_stride, n_kv_heads, k_dst, v_dst, dst_head_stride, dst_row0,
+                              kept_idx_out, (hipStream_t)stream);
 }
 
 int qp_prefill_attn_rows(qp_ctx* ctx, const void* q, const void* k_prefix, const void* v_prefix, int64_t prefix_head_stride,

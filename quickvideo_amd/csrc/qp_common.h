@@ -36,13 +36,21 @@ __device__ __forceinline__ unsigned short f32_to_bf16_bits(float f) {
   return (unsigned short)(u >> 16);
 }
 __device__ __forceinline__ float round_bf16(float f) { return bf16_bits_to_f32(f32_to_bf16_bits(f)); }
+// Correctly rounded fp32 square root.  hipcc's sqrtf/__fsqrt_rn can be 1 ulp off (measured: s = 262.03513 gave
+// 16.187498 instead of 16.1875, which flipped a bf16 round-to-even tie and with it a kept index); the fp64 square root
+// rounded once to fp32 is exact because sqrt of an fp32 value is never within 2^-48 of an fp32 rounding boundary.
+__device__ __forceinline__ float sqrt_rn_f32(float s) { return (float)sqrt((double)s); }
 
 // kernel launchers (one per .hip file)
 int qp_launch_mrope_table(const int64_t* pos, int64_t n, const int32_t* sections, float theta, int head_dim, void* cos_out,
                           void* sin_out, hipStream_t s);
 int qp_launch_rope_append(const void* qkv, const void* cos, const void* sin, int64_t n, int hq, int hkv, void* q_out,
                           void* k_dst, void* v_dst, int64_t dst_head_stride, int64_t dst_row0, float* head_sumsq,
-                          hipStream_t s);
+                          uint16_t* norm_keys, int largest, hipStream_t s);
+bool qp_rope_can_fuse_keys(int hq, int hkv);
+int qp_launch_norm_keys(const float* head_sumsq, int n_heads, int64_t n, uint16_t* norm_keys, int largest, hipStream_t s);
+int qp_launch_prune_keys(const uint16_t* norm_keys, int64_t n, int64_t k, const void* k_src, const void* v_src, int64_t src_head_stride,
+                         int hkv, void* k_dst, void* v_dst, int64_t dst_head_stride, int64_t dst_row0, int32_t* kept, hipStream_t s);
 int qp_launch_key_sumsq(const void* k, int64_t head_stride, int64_t row0, int64_t n, int hkv, float* head_sumsq,
                         hipStream_t s);
 int qp_launch_select(const float* head_sumsq, int n_heads, int64_t n, int64_t k, int32_t* kept, uint16_t* norm_bits,

@@ -54,11 +54,6 @@ int qp_launch_key_sumsq(const void* k, int64_t head_stride, int64_t row0, int64_
 //   emits  {t : key<tau}  U  {first r ties of key==tau}.  No host round trip (the reference does
 //   .tolist() + torch.tensor + nonzero().cpu(): utils.py:136,191,284).
 // ------------------------------------------------------------------------------------------------
-// Correctly rounded fp32 square root.  hipcc's sqrtf/__fsqrt_rn can be 1 ulp off (measured: s = 262.03513 gave
-// 16.187498 instead of 16.1875, which flipped a bf16 round-to-even tie and with it a kept index); the fp64 square root
-// rounded once to fp32 is exact because sqrt of an fp32 value is never within 2^-48 of an fp32 rounding boundary.
-__device__ __forceinline__ float sqrt_rn_f32(float s) { return (float)sqrt((double)s); }
-
 __device__ __forceinline__ unsigned block_excl_scan_1024(unsigned v, unsigned* wave_tot, unsigned* total) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   unsigned incl = v;
@@ -240,6 +235,160 @@ __global__ __launch_bounds__(1024) void prune_fused_kernel(const float* __restri
     const uint4 val = (isv ? v_src : k_src)[hh * src_hs16 + (int64_t)kidx[j] * 16 + c];
     (isv ? v_dst : k_dst)[hh * dst_hs16 + (dst_row0 + j) * 16 + c] = val;
   }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// K5+K6, the engine's path since round 2: ONE launch, no 150 KB of LDS, no fp64 square roots per workgroup.
+//   * The 16-bit norm key of every token (bf16 pattern of the cross-head norm; complemented for "k largest") is produced once,
+//     by the RoPE/append kernel that already holds the key rows (qp_rope.hip) — or by norm_keys_kernel below when the per-head
+//     sums had to cross ranks first (tensor / group-token parallel) or come from the value rows.
+//   * prune_keys_kernel: one 256-thread workgroup per 16 consecutive tokens.  Every workgroup holds ALL n keys in registers
+//     (2 bytes per token from L2: n <= 8192) and finds the threshold key tau by a two-pass 256-bin radix select in LDS
+//     (8 bank-staggered histogram copies: norms concentrate on a few dozen values, so same-address adds are 8-way, not 64-way),
+//     counts the kept tokens in front of its slice from the same registers, and moves the K/V rows of its own kept tokens
+//     staging -> arena (16 lanes x 16 B per 256-B row, all loads in flight before the first store).  Tie rule and order as
+//     select_kernel: keys below tau, then the first (k - n_less) ties in index order; ascending index list out.
+//   Tried first (as the round-1 review suggested): a global two-level histogram filled with atomics from the RoPE kernel's
+//   epilogue and read by a scan+gather kernel.  The scan+gather kernel ran in 8.4-9.3 us back to back, but the atomics did not
+//   pay: a few dozen hot bins serialise at L2 round-trip latency — +43 us per RoPE launch at n=5760 (8.47 vs 3.68 ms per cfg2
+//   pass), 65 us for a stand-alone histogram kernel.  (profiles/r2_prune_hist_atomics.txt)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void norm_keys_kernel(const float* __restrict__ head_sumsq, int n_heads, int n,
+                                                        uint16_t* __restrict__ norm_keys, int largest) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= n) return;
+  float s = head_sumsq[t];
+  for (int h = 1; h < n_heads; ++h) s = s + head_sumsq[(int64_t)h * n + t];
+  uint16_t b = f32_to_bf16_bits(sqrt_rn_f32(s));
+  norm_keys[t] = largest ? (uint16_t)~b : b;
+}
+
+int qp_launch_norm_keys(const float* head_sumsq, int n_heads, int64_t n, uint16_t* norm_keys, int largest, hipStream_t s) {
+  norm_keys_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(head_sumsq, n_heads, (int)n, norm_keys, largest);
+  return qp_check_launch("norm_keys");
+}
+
+// exclusive scan of one value per thread over the 256 threads of the workgroup (one barrier inside)
+__device__ __forceinline__ unsigned block_excl_scan_256(unsigned v, unsigned* wave_tot) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  unsigned incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    unsigned t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  if (lane == 63) wave_tot[wave] = incl;
+  __syncthreads();
+  unsigned before = 0;
+#pragma unroll
+  for (int w = 0; w < 3; ++w) before += (w < wave) ? wave_tot[w] : 0u;
+  return before + incl - v;
+}
+
+#define QP_PRUNE_TS 16       // tokens per workgroup
+#define QP_HIST_COPIES 8
+#define QP_HIST_STRIDE 264   // 256 bins + 8: copy c of bin b sits in bank (b + 8c) % 64
+
+#define QP_PRUNE_MAX_N 8192  // keys of the whole group in LDS (16 KB)
+
+__global__ __launch_bounds__(256) void prune_keys_kernel(const uint16_t* __restrict__ keys_g, int n, int k,
+                                                         const uint4* __restrict__ k_src, const uint4* __restrict__ v_src,
+                                                         int64_t src_hs16, int hkv, uint4* __restrict__ k_dst,
+                                                         uint4* __restrict__ v_dst, int64_t dst_hs16, int64_t dst_row0,
+                                                         int32_t* __restrict__ kept) {
+  __shared__ __attribute__((aligned(16))) uint16_t keys[QP_PRUNE_MAX_N];
+  __shared__ unsigned hist[2][QP_HIST_COPIES * QP_HIST_STRIDE];
+  __shared__ unsigned wave_tot[2][4];
+  __shared__ unsigned res[4];                  // b1, count before b1, low byte, count before tau inside b1
+  __shared__ unsigned red[2][4];
+  __shared__ int s_tok[QP_PRUNE_TS], s_pos[QP_PRUNE_TS];
+  __shared__ int s_nk;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int t0 = blockIdx.x * QP_PRUNE_TS;
+  // the code is kept small on purpose (rolled loops, keys in LDS): between two launches of this kernel the GEMMs evict it from
+  // the instruction cache, and every cold line of code is a serial miss in a kernel that is nothing but a latency chain
+
+  // all n keys -> LDS, 8 per 16-byte load, the last n % 8 one by one
+  const int n8 = n >> 3;
+  for (int i = tid; i < n8; i += 256) ((uint4*)keys)[i] = ((const uint4*)keys_g)[i];
+  if (tid < (n & 7)) keys[n8 * 8 + tid] = keys_g[n8 * 8 + tid];
+  for (int i = tid; i < 2 * QP_HIST_COPIES * QP_HIST_STRIDE; i += 256) (&hist[0][0])[i] = 0u;
+  __syncthreads();
+  unsigned* h1c = &hist[0][(lane & (QP_HIST_COPIES - 1)) * QP_HIST_STRIDE];
+  unsigned* h2c = &hist[1][(lane & (QP_HIST_COPIES - 1)) * QP_HIST_STRIDE];
+
+  // pass 1: high byte
+  for (int t = tid; t < n; t += 256) atomicAdd(&h1c[keys[t] >> 8], 1u);
+  __syncthreads();
+  unsigned v1 = 0;
+#pragma unroll
+  for (int c = 0; c < QP_HIST_COPIES; ++c) v1 += hist[0][c * QP_HIST_STRIDE + tid];
+  const unsigned before1 = block_excl_scan_256(v1, wave_tot[0]);
+  if (before1 < (unsigned)k && (unsigned)k <= before1 + v1) { res[0] = (unsigned)tid; res[1] = before1; }
+  __syncthreads();
+  const unsigned b1 = res[0], c1 = res[1];
+  // pass 2: low byte inside bucket b1
+  for (int t = tid; t < n; t += 256) { const unsigned key = keys[t]; if ((key >> 8) == b1) atomicAdd(&h2c[key & 255u], 1u); }
+  __syncthreads();
+  unsigned v2 = 0;
+#pragma unroll
+  for (int c = 0; c < QP_HIST_COPIES; ++c) v2 += hist[1][c * QP_HIST_STRIDE + tid];
+  const unsigned kk = (unsigned)k - c1;
+  const unsigned before2 = block_excl_scan_256(v2, wave_tot[1]);
+  if (before2 < kk && kk <= before2 + v2) { res[2] = (unsigned)tid; res[3] = before2; }
+  __syncthreads();
+  const unsigned tau = (b1 << 8) | res[2];
+  const unsigned r_ties = (unsigned)k - (c1 + res[3]);   // >= 1 ties (key == tau) to take, lowest index first
+
+  // kept tokens in front of this slice
+  unsigned lt = 0, eq = 0;
+  for (int t = tid; t < t0; t += 256) { const unsigned key = keys[t]; lt += key < tau; eq += key == tau; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { lt += __shfl_xor(lt, o, 64); eq += __shfl_xor(eq, o, 64); }
+  if (lane == 0) { red[0][wave] = lt; red[1][wave] = eq; }
+  __syncthreads();
+  if (wave == 0) {
+    const unsigned lt_b = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    const unsigned eq_b = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    // slice: lane j < TS owns token t0 + j
+    const bool mine = lane < QP_PRUNE_TS && t0 + lane < n;
+    const unsigned mykey = mine ? (unsigned)keys[t0 + lane] : 0xffffffffu;
+    const bool is_lt = mykey < tau, is_eq = mykey == tau;
+    const unsigned long long m_eq = __ballot(is_eq);
+    const unsigned eq_rank = eq_b + (unsigned)__popcll(m_eq & ((1ull << lane) - 1ull));
+    const bool keep = is_lt || (is_eq && eq_rank < r_ties);
+    const unsigned long long m_keep = __ballot(keep);
+    const unsigned rank = (unsigned)__popcll(m_keep & ((1ull << lane) - 1ull));
+    const unsigned base = lt_b + min(eq_b, r_ties);
+    if (keep) { s_tok[rank] = t0 + lane; s_pos[rank] = (int)(base + rank); kept[base + rank] = t0 + lane; }
+    if (lane == 0) s_nk = (int)__popcll(m_keep);
+  }
+  __syncthreads();
+  // gather: 16-lane group g moves the K and V rows of kept slot g (16 B per lane), 4 rows in flight
+  const int c = tid & 15, grp = tid >> 4;
+  if (grp < s_nk) {
+    const uint4* ks = k_src + (int64_t)s_tok[grp] * 16 + c;
+    const uint4* vs = v_src + (int64_t)s_tok[grp] * 16 + c;
+    uint4* kd = k_dst + (dst_row0 + s_pos[grp]) * 16 + c;
+    uint4* vd = v_dst + (dst_row0 + s_pos[grp]) * 16 + c;
+    for (int h = 0; h < hkv; h += 2) {
+      const bool two = h + 1 < hkv;
+      const uint4 a0 = ks[h * src_hs16], b0 = vs[h * src_hs16];
+      uint4 a1 = a0, b1v = b0;
+      if (two) { a1 = ks[(h + 1) * src_hs16]; b1v = vs[(h + 1) * src_hs16]; }
+      kd[h * dst_hs16] = a0; vd[h * dst_hs16] = b0;
+      if (two) { kd[(h + 1) * dst_hs16] = a1; vd[(h + 1) * dst_hs16] = b1v; }
+    }
+  }
+}
+
+int qp_launch_prune_keys(const uint16_t* norm_keys, int64_t n, int64_t k, const void* k_src, const void* v_src, int64_t src_head_stride,
+                         int hkv, void* k_dst, void* v_dst, int64_t dst_head_stride, int64_t dst_row0, int32_t* kept, hipStream_t s) {
+  const unsigned grid = (unsigned)((n + QP_PRUNE_TS - 1) / QP_PRUNE_TS);
+  prune_keys_kernel<<<grid, 256, 0, s>>>(norm_keys, (int)n, (int)k, (const uint4*)k_src, (const uint4*)v_src, src_head_stride / 8, hkv,
+                                         (uint4*)k_dst, (uint4*)v_dst, dst_head_stride / 8, dst_row0, kept);
+  return qp_check_launch("prune_keys");
 }
 
 static size_t prune_fused_smem(int64_t n, int64_t k) { return (16 * 257 + 256 + 16 + 4 + 4) * 4 + (size_t)((n + 7) & ~7) * 2 + (size_t)k * 2 + 16; }

@@ -42,11 +42,17 @@ __device__ __forceinline__ float sumsq8(const unsigned short o[8]) {
   return s;
 }
 
+// kKeys: additionally reduce the per-head sums of a token to its 16-bit norm key (heads added in ascending order, correctly
+// rounded sqrt, bf16 RNE: bit-identical to select_kernel / the oracle) for prune_keys_kernel (qp_prune.hip).  Requires the hkv
+// key rows of a token to sit in ONE wave: the launcher checks (qp_rope_can_fuse_keys), otherwise norm_keys_kernel does this
+// step from head_sumsq.
+template <bool kKeys>
 __global__ __launch_bounds__(256) void rope_append_kernel(const uint4* __restrict__ qkv, const uint4* __restrict__ cos_t,
                                                           const uint4* __restrict__ sin_t, int64_t n, int hq, int hkv,
                                                           uint4* __restrict__ q_out, uint4* __restrict__ k_dst,
                                                           uint4* __restrict__ v_dst, int64_t dst_hs16, int64_t dst_row0,
-                                                          float* __restrict__ head_sumsq) {
+                                                          float* __restrict__ head_sumsq, uint16_t* __restrict__ norm_keys,
+                                                          int largest) {
   const int c = threadIdx.x & 15;
   const int rows_per_tok = hq + 2 * hkv;
   const int64_t rows = n * rows_per_tok;
@@ -83,25 +89,46 @@ __global__ __launch_bounds__(256) void rope_append_kernel(const uint4* __restric
     } else {
       const int h = hr - hq;
       k_dst[(int64_t)h * dst_hs16 + (dst_row0 + t) * 16 + c] = ov;
-      if (head_sumsq) {
+      if (head_sumsq || kKeys) {
         float s = sumsq8(o);
 #pragma unroll
         for (int m = 1; m < 16; m <<= 1) s = s + __shfl_xor(s, m, 16);
-        if (c == 0) head_sumsq[(int64_t)h * n + t] = s;
+        if (c == 0 && head_sumsq) head_sumsq[(int64_t)h * n + t] = s;
+        if (kKeys) {
+          // the token's key rows are the 16-lane groups g - h ... g - h + hkv - 1 of this wave (g = this group's index)
+          const int g0 = ((threadIdx.x & 63) >> 4) - h;
+          float tot = __shfl(s, g0 * 16, 64);
+          for (int j = 1; j < hkv; ++j) tot = tot + __shfl(s, (g0 + j) * 16, 64);
+          if (h == 0 && c == 0) {
+            const unsigned short b = f32_to_bf16_bits(sqrt_rn_f32(tot));
+            norm_keys[t] = largest ? (unsigned short)~b : b;
+          }
+        }
       }
     }
   }
 }
 
+// the hkv key rows of every token lie inside one 4-row wave (rows are dealt 16 per workgroup pass, 4 per wave, in row order)
+bool qp_rope_can_fuse_keys(int hq, int hkv) {
+  const int rpt = hq + 2 * hkv;
+  return (hkv == 1) || (hkv == 2 && rpt % 2 == 0 && hq % 2 == 0) || (hkv == 4 && rpt % 4 == 0 && hq % 4 == 0);
+}
+
 int qp_launch_rope_append(const void* qkv, const void* cos, const void* sin, int64_t n, int hq, int hkv, void* q_out,
                           void* k_dst, void* v_dst, int64_t dst_head_stride, int64_t dst_row0, float* head_sumsq,
-                          hipStream_t s) {
+                          uint16_t* norm_keys, int largest, hipStream_t s) {
   int64_t rows = n * (hq + 2 * hkv);
   int64_t blocks = (rows + 15) / 16;
   if (blocks > 8192) blocks = 8192;
   if (blocks < 1) blocks = 1;
-  rope_append_kernel<<<(int)blocks, 256, 0, s>>>((const uint4*)qkv, (const uint4*)cos, (const uint4*)sin, n, hq, hkv,
-                                                 (uint4*)q_out, (uint4*)k_dst, (uint4*)v_dst, dst_head_stride / 8, dst_row0,
-                                                 head_sumsq);
+  if (norm_keys)
+    rope_append_kernel<true><<<(int)blocks, 256, 0, s>>>((const uint4*)qkv, (const uint4*)cos, (const uint4*)sin, n, hq, hkv,
+                                                         (uint4*)q_out, (uint4*)k_dst, (uint4*)v_dst, dst_head_stride / 8, dst_row0,
+                                                         head_sumsq, norm_keys, largest);
+  else
+    rope_append_kernel<false><<<(int)blocks, 256, 0, s>>>((const uint4*)qkv, (const uint4*)cos, (const uint4*)sin, n, hq, hkv,
+                                                          (uint4*)q_out, (uint4*)k_dst, (uint4*)v_dst, dst_head_stride / 8, dst_row0,
+                                                          head_sumsq, nullptr, 0);
   return qp_check_launch("rope_append");
 }

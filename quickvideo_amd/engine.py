@@ -104,6 +104,13 @@ class QuickPrefillEngine:
         self.b_ss = e(self.hkv, n, dtype=torch.float32)
         self.b_ss_all = e(self.tp_size, self.hkv, n, dtype=torch.float32) if self.tp_size > 1 else None
         self.b_idx = e(n, dtype=torch.int32)
+        # prune through 16-bit norm keys (qp_prune_keys): the keys of the group's tokens, written by the RoPE kernel
+        self._keys_path = hasattr(self.ops, "prune_keys") and self.device.type == "cuda"
+        if self._keys_path:
+            self.b_keys = e(n, dtype=torch.int16)
+        self._prune_probe = os.environ.get("QP_PRUNE_PROBE") == "1"
+        if self._prune_probe:
+            self._probe_key = e(8, dtype=torch.int16)
         self.b_h2 = e(n, d)
         # norm-based predict type (utils.py:117-136): which rows are scored (keys / values) and which end is kept
         if cfg.top_k_predict_type not in NORM_PRUNE_MODES:
@@ -123,6 +130,20 @@ class QuickPrefillEngine:
     def reset(self):
         self.arena.reset()
         self.seq_pos = 0
+
+    def _prune(self, ss_all, heads_total, n, k_keep, kn, vn, new_stride, l, past, idx, keys_ready=False):
+        """post_process_kv_cache's KV part (utils.py:266-342): select the k_keep tokens + move their K/V rows staging -> arena tail."""
+        ops, D = self.ops, self.D
+        if not (self._keys_path and n <= ops.PRUNE_KEYS_MAX_N):
+            ops.prune_staged(ss_all, heads_total, n, k_keep, kn, vn, new_stride, self.hkv, D, self.arena.k(l), self.arena.v(l),
+                             self.arena.head_stride, past, idx)
+            return
+        if not keys_ready:                                   # sums crossed ranks / came from the value rows: keys now
+            ops.norm_keys(ss_all, heads_total, n, self.b_keys)
+        elif self._prune_probe:                              # developer probe: an (almost) empty launch in the prune's position
+            ops.norm_keys(self.b_ss, 1, 1, self._probe_key)
+        ops.prune_keys(self.b_keys, n, k_keep, kn, vn, new_stride, self.hkv, D, self.arena.k(l), self.arena.v(l), self.arena.head_stride,
+                       past, idx)
 
     # ------------------------------------------------------------------ GEMM decomposition (hipBLASLt shape sensitivity)
     # hipBLASLt's heuristic is erratic in the row count: at 7B dims the down projection takes 576 us for n = 5760 rows but 940-950 us
@@ -298,7 +319,12 @@ class QuickPrefillEngine:
             if k_keep is not None:                                           # prune layer: new K/V go to staging
                 kn = self.b_stage[0].view(-1)[: self.hkv * n * D].view(self.hkv, n, D)
                 vn = self.b_stage[1].view(-1)[: self.hkv * n * D].view(self.hkv, n, D)
-                ops.rope_append(qkv, cos, sin, self.hq, self.hkv, D, q, kn, vn, n * D, 0, self.b_ss)
+                fuse = (self._keys_path and n <= ops.PRUNE_KEYS_MAX_N and self.tp_size == 1 and self.norm_source == 0
+                        and ops.can_fuse_keys(self.hq, self.hkv))
+                if fuse:                                                     # 16-bit norm keys while the key rows are in registers
+                    ops.rope_append_keys(qkv, cos, sin, self.hq, self.hkv, D, q, kn, vn, n * D, 0, None, self.b_keys)
+                else:
+                    ops.rope_append(qkv, cos, sin, self.hq, self.hkv, D, q, kn, vn, n * D, 0, self.b_ss)
                 new_stride = n * D
                 if self.norm_source == 1:                                    # vector_norms*: score the value rows (utils.py:117-126)
                     ops.key_sumsq(vn, n * D, 0, n, self.hkv, D, self.b_ss)
@@ -319,10 +345,12 @@ class QuickPrefillEngine:
             prune_hidden = (k_keep is not None and cfg.enable and isinstance(cfg.prefill_prune_starting_layer, int)
                             and cfg.prefill_prune_starting_layer >= 0 and l >= cfg.prefill_prune_starting_layer)
             if k_keep is not None:                                           # post_process_kv_cache         (:183-192)
-                ss_all, heads_total = self._global_sumsq(n)
                 idx = self.b_idx[:k_keep]
-                ops.prune_staged(ss_all, heads_total, n, k_keep, kn, vn, n * D, self.hkv, D, self.arena.k(l), self.arena.v(l),
-                                 self.arena.head_stride, past, idx)                    # select + gather, one launch
+                if fuse:
+                    self._prune(None, 0, n, k_keep, kn, vn, n * D, l, past, idx, keys_ready=True)
+                else:
+                    ss_all, heads_total = self._global_sumsq(n)
+                    self._prune(ss_all, heads_total, n, k_keep, kn, vn, n * D, l, past, idx)
                 self.arena.len[l] = past + k_keep
                 if self.kept_trace is not None:
                     self.kept_trace.append((l, idx.clone()))
@@ -420,8 +448,7 @@ class QuickPrefillEngine:
             self._linear("o", att.view(ml, self.hq * D), lw.w_o, o)
             if k_keep is not None:
                 idx = self.b_idx[:k_keep]
-                ops.prune_staged(ss_all, self.hkv, n, k_keep, kn, vn, new_stride, self.hkv, D, self.arena.k(l), self.arena.v(l),
-                                 self.arena.head_stride, past, idx)
+                self._prune(ss_all, self.hkv, n, k_keep, kn, vn, new_stride, l, past, idx)
                 self.arena.len[l] = past + k_keep
                 if self.kept_trace is not None:
                     self.kept_trace.append((l, idx.clone()))

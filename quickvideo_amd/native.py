@@ -40,6 +40,9 @@ SIGNATURES = {
     "qp_device_cus": (_i32, [_vp]),
     "qp_mrope_table": (_i32, [_vp, _vp, _i64, _c.POINTER(_c.c_int32), _f32, _i32, _vp, _vp, _vp]),
     "qp_rope_append": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _vp, _vp]),
+    "qp_rope_append_keys": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
+    "qp_norm_keys": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp]),
+    "qp_prune_keys": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _i64, _vp, _vp]),
     "qp_prefill_attn": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _f32, _vp, _vp, _sz, _vp]),
     "qp_prefill_attn_rows": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _f32, _vp, _vp, _sz, _vp]),
     "qp_attn_workspace_bytes": (_sz, [_vp, _i64, _i64, _i32, _i32]),
@@ -144,6 +147,29 @@ class QuickPrefillOps:
         self._check(self.lib.qp_rope_append(self.ctx, qkv.data_ptr(), cos.data_ptr(), sin.data_ptr(), n, n_q, n_kv, head_dim,
                                             q_out.data_ptr(), k_dst.data_ptr(), v_dst.data_ptr(), dst_head_stride, dst_row0,
                                             _ptr(head_sumsq), self._stream()))
+
+    def rope_append_keys(self, qkv, cos, sin, n_q, n_kv, head_dim, q_out, k_dst, v_dst, dst_head_stride, dst_row0, head_sumsq, norm_keys):
+        """rope_append that also emits the layer's 16-bit norm keys (raises QuickPrefillError, status QP_ERR_UNSUPPORTED, when the
+        head layout cannot be fused: see can_fuse_keys)."""
+        n = qkv.shape[0]
+        self._check(self.lib.qp_rope_append_keys(self.ctx, qkv.data_ptr(), cos.data_ptr(), sin.data_ptr(), n, n_q, n_kv, head_dim,
+                                                 q_out.data_ptr(), k_dst.data_ptr(), v_dst.data_ptr(), dst_head_stride, dst_row0,
+                                                 _ptr(head_sumsq), norm_keys.data_ptr(), self._stream()))
+
+    @staticmethod
+    def can_fuse_keys(n_q, n_kv) -> bool:
+        rpt = n_q + 2 * n_kv
+        return n_kv == 1 or (n_kv == 2 and rpt % 2 == 0 and n_q % 2 == 0) or (n_kv == 4 and rpt % 4 == 0 and n_q % 4 == 0)
+
+    PRUNE_KEYS_MAX_N = 8192
+
+    def norm_keys(self, head_sumsq, n_heads_total, n, norm_keys):
+        self._check(self.lib.qp_norm_keys(self.ctx, head_sumsq.data_ptr(), n_heads_total, n, norm_keys.data_ptr(), self._stream()))
+
+    def prune_keys(self, norm_keys, n, k, k_src, v_src, src_head_stride, n_kv, head_dim, k_dst, v_dst, dst_head_stride, dst_row0, kept_idx):
+        self._check(self.lib.qp_prune_keys(self.ctx, norm_keys.data_ptr(), n, k, k_src.data_ptr(), v_src.data_ptr(), src_head_stride, n_kv,
+                                           head_dim, k_dst.data_ptr(), v_dst.data_ptr(), dst_head_stride, dst_row0, kept_idx.data_ptr(),
+                                           self._stream()))
 
     # -- seam 3
     def prefill_attn(self, q, k_prefix, v_prefix, prefix_head_stride, prefix_len, k_new, v_new, new_head_stride, n, n_q, n_kv,

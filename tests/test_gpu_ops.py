@@ -155,6 +155,137 @@ def test_rope_append_bit_exact(ops, n, hq, hkv, row0):
     assert torch.count_nonzero(kc[:, :row0]).item() == 0 and torch.count_nonzero(kc[:, row0 + n:]).item() == 0
 
 
+# ---------------------------------------------------------------- round 2: prune through norm keys (qp_norm_keys / qp_rope_append_keys + qp_prune_keys)
+
+def keys_prune(ops, ks, vs, k, past=0, keys=None):
+    """Run norm_keys (unless keys are given) + prune_keys on staging rows ks/vs [Hkv, n, D]; returns idx, arena K, arena V, key patterns."""
+    hkv, n, _ = ks.shape
+    cap = past + k + 5
+    kc = torch.zeros(hkv, cap, D, dtype=torch.bfloat16, device="cuda"); vc = torch.zeros_like(kc)
+    if keys is None:
+        ss = torch.empty(hkv, n, dtype=torch.float32, device="cuda")
+        ops.key_sumsq(ks, n * D, 0, n, hkv, D, ss)
+        keys = torch.zeros(n, dtype=torch.int16, device="cuda")
+        ops.norm_keys(ss, hkv, n, keys)
+    idx = torch.full((k,), -1, dtype=torch.int32, device="cuda")
+    ops.prune_keys(keys, n, k, ks, vs, n * D, hkv, D, kc, vc, cap * D, past, idx)
+    torch.cuda.synchronize()
+    return idx.cpu().numpy(), kc, vc, keys.cpu().numpy().view(np.uint16)
+
+
+@pytest.mark.parametrize("ci", range(len(SELECT_CASES)))
+def test_prune_keys_golden_select_cases(ops, golden_dir, ci):
+    """Same 18 reference cases as test_sumsq_select_bit_exact, through the engine's one-launch prune: identical index lists and rows."""
+    data = np.load(os.path.join(golden_dir, "gv1_select.npz"))
+    meta = json.load(open(os.path.join(golden_dir, "gv1_select.json")))[ci]
+    dist, hkv, n, k = SELECT_CASES[ci]
+    keys = make_keys(dist, hkv, n, meta["seed"])[0]
+    rs = np.random.RandomState(ci)
+    vals = torch.from_numpy(rs.standard_normal((hkv, n, D)).astype(np.float32)).to(torch.bfloat16)
+    idx, kc, vc, kb = keys_prune(ops, keys.cuda().contiguous(), vals.cuda().contiguous(), k, past=3)
+    nb_ref = O.key_norms_bf16(O.key_sumsq_heads(O.torch_bf16_to_bits(keys)))
+    assert np.array_equal(kb, nb_ref)
+    ref = O.select_k_smallest(nb_ref, k)
+    assert np.array_equal(idx, ref)
+    if meta["norm_rows_differ"] == 0:
+        assert np.array_equal(idx, data[f"c{ci}_ref_idx_stable"])
+    ti = torch.from_numpy(ref.astype(np.int64))
+    assert torch.equal(kc[:, 3:3 + k].cpu(), keys[:, ti]) and torch.equal(vc[:, 3:3 + k].cpu(), vals[:, ti])
+    assert torch.count_nonzero(kc[:, :3]).item() == 0 and torch.count_nonzero(kc[:, 3 + k:]).item() == 0
+
+
+@pytest.mark.parametrize("n,k,hkv", [(1, 1, 4), (2, 1, 2), (17, 16, 1), (64, 64, 4), (1024, 1, 4), (1025, 1, 4), (2240, 1120, 4), (3072, 3071, 2),
+                                     (3073, 5, 4), (5775, 2887, 4), (6144, 3000, 1), (6145, 3000, 1), (8192, 4096, 4), (960, 480, 8)])
+def test_prune_keys_edge_sizes(ops, n, k, hkv):
+    rs = np.random.RandomState(n + k)
+    keys = torch.from_numpy(rs.standard_normal((hkv, n, D)).astype(np.float32)).to(torch.bfloat16)
+    vals = torch.from_numpy(rs.standard_normal((hkv, n, D)).astype(np.float32)).to(torch.bfloat16)
+    idx, kc, vc, kb = keys_prune(ops, keys.cuda(), vals.cuda(), k)
+    nb_ref = O.key_norms_bf16(O.key_sumsq_heads(O.torch_bf16_to_bits(keys)))
+    ref = O.select_k_smallest(nb_ref, k)
+    assert np.array_equal(kb, nb_ref) and np.array_equal(idx, ref)
+    ti = torch.from_numpy(ref.astype(np.int64))
+    assert torch.equal(kc[:, :k].cpu(), keys[:, ti]) and torch.equal(vc[:, :k].cpu(), vals[:, ti])
+
+
+def test_prune_keys_spread_over_high_bytes(ops):
+    """Norms spanning many binades (several high-byte buckets): pass 1 of the radix select has real work to do."""
+    rs = np.random.RandomState(3)
+    n, hkv = 4000, 2
+    keys = torch.from_numpy(rs.standard_normal((hkv, n, D)).astype(np.float32) * np.exp2(rs.randint(-20, 20, size=(1, n, 1)))).to(torch.bfloat16)
+    for k in (1, 777, 2000, 3999, 4000):
+        idx, *_ = keys_prune(ops, keys.cuda(), keys.cuda(), k)
+        nb_ref = O.key_norms_bf16(O.key_sumsq_heads(O.torch_bf16_to_bits(keys)))
+        assert np.array_equal(idx, O.select_k_smallest(nb_ref, k))
+
+
+def test_prune_keys_special_values_and_largest(ops):
+    n, hkv = 300, 4
+    keys = torch.zeros(hkv, n, D, dtype=torch.bfloat16)
+    keys[0, 10:20, 0] = float("inf"); keys[1, 30, 5] = float("nan"); keys[:, 50:60] = 3.0e38
+    keys[2, 100:, 3] = 1.0
+    idx, *_ = keys_prune(ops, keys.cuda(), keys.cuda(), 150)
+    nb_ref = O.key_norms_bf16(O.key_sumsq_heads(O.torch_bf16_to_bits(keys)))
+    assert np.array_equal(idx, O.select_k_smallest(nb_ref, 150))
+    rs = np.random.RandomState(5)
+    keys = torch.from_numpy(rs.standard_normal((hkv, 777, D)).astype(np.float32)).to(torch.bfloat16)
+    ops.set_prune_mode(0, 1)                            # key_norms: k LARGEST
+    try:
+        idx, _, _, kb = keys_prune(ops, keys.cuda(), keys.cuda(), 300)
+    finally:
+        ops.set_prune_mode(0, 0)
+    nb_ref = O.key_norms_bf16(O.key_sumsq_heads(O.torch_bf16_to_bits(keys)))
+    assert np.array_equal(kb, (~nb_ref).astype(np.uint16)) and np.array_equal(idx, O.select_k_largest(nb_ref, 300))
+
+
+@pytest.mark.parametrize("n,hq,hkv", [(1, 2, 1), (77, 28, 4), (5775, 28, 4), (2240, 28, 4), (300, 12, 2), (960, 8, 1)])
+def test_rope_append_keys_equals_unfused(ops, n, hq, hkv):
+    """The fused norm-key epilogue of the RoPE kernel == qp_rope_append + qp_norm_keys, bit for bit."""
+    rs = np.random.RandomState(n + hq)
+    spec = O.TextSpec(hidden=hq * D, n_heads=hq, n_kv_heads=hkv, head_dim=D, intermediate=8, n_layers=1, vocab=8)
+    qkv = torch.from_numpy(rs.standard_normal((n, (hq + 2 * hkv) * D)).astype(np.float32) * 2).to(torch.bfloat16).cuda()
+    pos = np.stack([rs.randint(0, 4000, n), rs.randint(0, 60, n), rs.randint(0, 80, n)]).astype(np.int64)
+    cos, sin = O.mrope_cos_sin(torch.from_numpy(pos), spec, torch.bfloat16)
+    cos, sin = cos[:, :D // 2].contiguous().cuda(), sin[:, :D // 2].contiguous().cuda()
+    assert ops.can_fuse_keys(hq, hkv)
+    outs = []
+    for fused in (False, True):
+        kc = torch.zeros(hkv, n, D, dtype=torch.bfloat16, device="cuda"); vc = torch.zeros_like(kc)
+        q_out = torch.empty(n, hq, D, dtype=torch.bfloat16, device="cuda")
+        ss = torch.zeros(hkv, n, dtype=torch.float32, device="cuda")
+        keys = torch.zeros(n, dtype=torch.int16, device="cuda")
+        if fused:
+            ops.rope_append_keys(qkv, cos, sin, hq, hkv, D, q_out, kc, vc, n * D, 0, ss, keys)
+        else:
+            ops.rope_append(qkv, cos, sin, hq, hkv, D, q_out, kc, vc, n * D, 0, ss)
+            ops.norm_keys(ss, hkv, n, keys)
+        torch.cuda.synchronize()
+        outs.append((q_out, kc, vc, ss, keys))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    nb_ref = O.key_norms_bf16(O.key_sumsq_heads(dev_bits(outs[1][1])))
+    assert np.array_equal(outs[1][4].cpu().numpy().view(np.uint16), nb_ref)
+    k = max(1, n // 2)
+    idx, *_ = keys_prune(ops, outs[1][1], outs[1][2], k, keys=outs[1][4])
+    assert np.array_equal(idx, O.select_k_smallest(nb_ref, k))
+
+
+def test_rope_append_keys_refuses_unfusable_layout_and_prune_keys_large_n(ops):
+    from quickvideo_amd.native import QuickPrefillError
+    n, hq, hkv = 8, 64, 8
+    z = torch.zeros(n, (hq + 2 * hkv) * D, dtype=torch.bfloat16, device="cuda")
+    c = torch.zeros(n, D // 2, dtype=torch.bfloat16, device="cuda")
+    kc = torch.zeros(hkv, n, D, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(QuickPrefillError):
+        ops.rope_append_keys(z, c, c, hq, hkv, D, torch.empty(n, hq, D, dtype=torch.bfloat16, device="cuda"), kc, kc.clone(), n * D, 0, None,
+                             torch.zeros(n, dtype=torch.int16, device="cuda"))
+    n = 8193
+    big = torch.zeros(1, n, D, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(QuickPrefillError):
+        ops.prune_keys(torch.zeros(n, dtype=torch.int16, device="cuda"), n, 5, big, big, n * D, 1, D, big.clone(), big.clone(), n * D, 0,
+                       torch.zeros(5, dtype=torch.int32, device="cuda"))
+
+
 def test_mrope_table(ops):
     spec = O.TextSpec(hidden=256, n_heads=2, n_kv_heads=1, head_dim=D, intermediate=8, n_layers=1, vocab=8)
     pos, _ = O.mrope_positions(15, (32, 40, 72), 30)

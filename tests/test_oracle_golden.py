@@ -265,3 +265,30 @@ def test_e2e_composite_oracle_other_norm_modes(golden_dir, ci):
         assert float(np.dot(got, ref) / (np.linalg.norm(got) * np.linalg.norm(ref))) >= 0.999
     base = O.group_prefill(w, spec, embeds, pos, plan.tokens, O.PruneCfg(top_k=top_k, top_p=top_p))
     assert np.max(np.abs(base["logits"].numpy() - ref)) > 1e-3          # the mode matters: default scoring gives other logits
+
+
+def test_deep_fixture_first_layers_match_oracle(golden_dir):
+    """GV8 (28 layers at the 7B dims, made by the reference composite): the oracle re-runs layers 0-1 of group 0 on the CPU from
+    the same hash-generated weights / input rows and must reproduce the reference's kept index lists (layer 0: identical inputs,
+    so the lists agree except where a bf16 key norm sits on a rounding boundary between the two GEMM implementations)."""
+    import json
+    meta = json.load(open(os.path.join(golden_dir, "gv8_deep.json")))
+    gold = np.load(os.path.join(golden_dir, "gv8_deep.npz"))
+    s = dict(meta["spec"]); s["n_layers"] = 2
+    spec = O.TextSpec(**s)
+    w = O.hashed_text_weights(spec, seed=meta["weight_seed"], with_embed=False)
+    n0 = meta["group_tokens"][0]
+    T = meta["prefix"] + (meta["frames"] // 2) * (meta["grid_h"] // 2) * (meta["grid_w"] // 2) + meta["tail"]
+    emb = O.hashed_normal((T, spec.hidden), meta["embed_seed"], 0.5)[:n0]
+    pos, _ = O.mrope_positions(meta["prefix"], (meta["frames"] // 2, meta["grid_h"], meta["grid_w"]), meta["tail"])
+    cache = O.OracleCache(2)
+    cos, sin = O.mrope_cos_sin(torch.from_numpy(pos[:, :n0]), spec, torch.bfloat16)
+    h = emb
+    k_keep = O.effective_k(n0, None, meta["top_p"], None, None, 0, meta["spec"]["n_layers"])
+    assert k_keep == int(gold["kept_g0_l0"].shape[0])
+    with torch.no_grad():
+        for l in range(2):
+            h, kept, cos, sin = O.decoder_layer(h, w, l, spec, cache, cos, sin, k_keep)
+            want = gold[f"kept_g0_l{l}"].astype(np.int64)
+            ov = len(set(kept.tolist()) & set(want.tolist())) / len(want)
+            assert ov >= (0.99 if l == 0 else 0.95), (l, ov)
