@@ -185,6 +185,22 @@ def test_tensor_parallel_gloo_world4_replicated_kv_heads():
     assert np.max(np.abs(ret["logits0"] - ret["ref_logits"])) <= 4e-2
 
 
+def test_tensor_parallel_gloo_world8_one_kv_head_per_rank():
+    """The Qwen2-VL-72B layout of BASELINE.json configs[4] at tiny width: 8 kv heads over 8 ranks (one each, 2 q heads per rank),
+    MLP columns / 8; every rank must derive the identical kept-index lists from the all-gathered per-head key sums (fixed head
+    order) and the identical logits; cache lengths and logits vs the single-process oracle."""
+    port = 33500 + os.getpid() % 2000
+    ret = mp.Manager().dict()
+    mp.spawn(_tp_worker, args=(8, port, ret, 16, 8), nprocs=8, join=True)
+    assert all(ret[f"heads{r}"] == (2, 1, 64) for r in range(8))
+    assert all(ret[f"len{r}"] == ret["ref_len"] for r in range(8))
+    for r in range(1, 8):
+        for a, b in zip(ret["kept0"], ret[f"kept{r}"]):
+            assert (a is None) == (b is None) and (a is None or np.array_equal(a, b))
+        assert np.array_equal(ret["logits0"], ret[f"logits{r}"])
+    assert np.max(np.abs(ret["logits0"] - ret["ref_logits"])) <= 4e-2
+
+
 def test_load_hf_checkpoint_directory(tmp_path):
     """Local HF-layout checkpoint (config.json + model.safetensors with the transformers Qwen2-VL parameter names) loads
     into the native weight layout and produces the same logits as weights passed directly."""

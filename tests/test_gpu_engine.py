@@ -93,6 +93,60 @@ def test_engine_real_dims_one_layer():
     check_logits(logits.numpy(), ref["logits"].numpy())
 
 
+def test_engine_local_attention_off_vs_oracle():
+    """adaptive_local_attention=False on the GPU (qwen25_lvu.py:700-714): every video group is prefilled WITHOUT the earlier groups'
+    K/V (their pruned rows still accumulate in the cache), the prompt tail attends to all of it.  Oracle: each group through an empty
+    cache, caches concatenated, then the tail — exactly what the reference's branch does."""
+    spec_o, w, plan, pos, delta, embeds = make_case(24, 12, 16, 8, 15, 20)      # 3 groups x 192 tokens
+    cfg = LVUConfig("x", top_p=0.5, video_group_size=8, adaptive_local_attention=False)
+    eng, logits = run_gpu(TINY, w, plan, pos, embeds, cfg)
+    # oracle: groups independently
+    post = torch.from_numpy(pos)
+    caches, start = [], 0
+    for n in plan.tokens:
+        r = O.group_prefill(w, spec_o, embeds[start:start + n + 1], pos[:, start:start + n + 1], [n], O.PruneCfg(top_p=0.5), want_logits=False)
+        c = r["cache"]
+        for l in range(spec_o.n_layers):                       # drop the 1-token dummy tail group_prefill appended
+            c.k[l], c.v[l] = c.k[l][:, :-1], c.v[l][:, :-1]
+        caches.append(c)
+        start += n
+    merged = O.OracleCache(spec_o.n_layers)
+    for c in caches:
+        for l in range(spec_o.n_layers):
+            merged.append(l, c.k[l], c.v[l])
+    h = embeds[start:]
+    cos, sin = O.mrope_cos_sin(post[:, start:], spec_o, embeds.dtype)
+    for l in range(spec_o.n_layers):
+        h, _, cos, sin = O.decoder_layer(h, w, l, spec_o, merged, cos, sin, None)
+    assert eng.arena.len == [merged.length(l) for l in range(spec_o.n_layers)]
+    ref = torch.nn.functional.linear(O.rmsnorm(h[-1:], w["norm.weight"], spec_o.rms_eps), w["lm_head.weight"])[0].float()
+    check_logits(logits.numpy(), ref.numpy())
+    # and it differs from the default (cross-group attention on): the switch is not a no-op
+    eng2, logits2 = run_gpu(TINY, w, plan, pos, embeds, LVUConfig("x", top_p=0.5, video_group_size=8))
+    assert float((logits - logits2).abs().max()) > 1e-3
+
+
+def test_engine_72b_tp8_rank_slice_vs_oracle():
+    """cfg5's per-rank problem (Qwen2-VL-72B under TP=8: d=8192, 8 q heads + 1 kv head per GPU, I/8 = 3696 MLP columns), two layers,
+    through forward_segment: 2 groups of 480 tokens + tail vs the oracle on a model with exactly those dims (the rank's partial sums
+    are what the all-reduce would add; here the single 'rank' is the whole model, so the outputs are comparable as they are)."""
+    dims = dict(hidden=8192, n_heads=8, n_kv_heads=1, head_dim=128, intermediate=3696, n_layers=2, vocab=1024)
+    spec, spec_o = TextSpec(**dims), O.TextSpec(**dims)
+    # std 0.01: at d = 8192 the usual 0.02 gives q.k/sqrt(D) a std of ~3.3, i.e. attention so peaky that ONE token moving across the
+    # prune threshold (2 of 240 kept tokens differ between hipBLASLt's and the CPU's K rounding) moves the logits by 0.6
+    # (tools/probe/dbg_slice.py); with 0.01 the same two differences move them by 0.02
+    w = O.hashed_text_weights(spec_o, seed=21, device="cuda", norm_jitter=0.05, std=0.01)
+    frames, gh, gw, gs, prefix, tail = 16, 16, 30, 8, 15, 24       # 8 frame pairs x 120 tokens -> 2 groups of 480
+    T = prefix + (frames // 2) * (gh // 2) * (gw // 2) + tail
+    plan = planner.plan_groups(frames, gs, gh, gw, prefix, T)
+    pos, _ = planner.mrope_positions(prefix, (frames // 2, gh, gw), tail)
+    embeds = O.hashed_normal((T, spec.hidden), 22, 0.5)
+    eng, logits = run_gpu(spec, w, plan, pos, embeds, LVUConfig("x", top_p=0.5, video_group_size=gs))
+    ref = O.group_prefill({k: v.cpu() for k, v in w.items()}, spec_o, embeds, pos, plan.tokens, O.PruneCfg(top_p=0.5))
+    assert eng.arena.len == ref["cache_len"]
+    check_logits(logits.numpy(), ref["logits"].numpy())
+
+
 def test_no_gpu_fallback_is_loud():
     """The product refuses to run without the HIP library (no silent CPU path)."""
     from quickvideo_amd import native

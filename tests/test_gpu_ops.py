@@ -487,9 +487,11 @@ def test_vit_kernels_match_torch_path(ops):
         ops.add_layernorm(torch.zeros(2, 12, dtype=torch.bfloat16, device="cuda"), None, wl, bl, torch.zeros(2, 12, dtype=torch.bfloat16, device="cuda"), 1e-6)
 
 
-@pytest.mark.parametrize("n,P,hq,hkv", [(5760, 8647, 28, 4), (2240, 60000, 28, 4), (960, 7000, 8, 1), (5775, 0, 12, 2)])
+@pytest.mark.parametrize("n,P,hq,hkv", [(5760, 8647, 28, 4), (2240, 60000, 28, 4), (960, 7000, 8, 1), (5775, 0, 12, 2),
+                                        (2880, 5040, 28, 4), (2240, 502887, 28, 4)])
 def test_prefill_attn_full_size_properties(ops, n, P, hq, hkv):
-    """BASELINE.json sizes (cfg2 / cfg4 / cfg5-per-rank / 2B): the production kernel (XCD map + kv split + deferred rescale)
+    """BASELINE.json sizes (cfg2 / cfg4 / cfg5-per-rank / 2B / cfg3's last group: n=2880 over 7 x 720 kept rows / cfg4's LAST group:
+    2240 tokens over the 502 887-row pruned prefix of the 1-hour video): the production kernel (XCD map + kv split + deferred rescale)
     vs (a) the independent v1 kernel on every element and (b) an fp32 torch reference on the last 256 query rows;
     plus linearity in V (attention is linear in V for fixed q, k): attn(q,k,2v) == 2 attn(q,k,v) up to bf16 rounding."""
     g = torch.Generator(device="cuda"); g.manual_seed(n + P)
