@@ -149,6 +149,17 @@ int qp_prune_keys(qp_ctx* ctx, const uint16_t* norm_keys, int64_t n, int64_t k, 
                   int64_t src_head_stride, int n_kv_heads, int head_dim, void* k_dst, void* v_dst, int64_t dst_head_stride,
                   int64_t dst_row0, int32_t* kept_idx_out, void* stream);
 
+/* Query-attention-score pruning (top_k_predict_type "query_attention_weights[_by_value_norm]"; LVUCache.update in query-based
+ * mode, lvu_cache.py:97-117, and utils.py:55-62): q_prompt bf16 [m][n_q][128] = the RoPE'd queries of the m prompt tokens the
+ * reference appends to every video group (qwen25_lvu.py:684-686), k_group = the group's own RoPE'd keys [n_kv][n][128] (head
+ * stride k_head_stride).  score[t] = bf16(mean_h bf16(sum_q bf16(softmax_fp32(bf16(bf16(q.k)/sqrt(128))))))  -> scores_out
+ * (uint16 [n], may be NULL); norm_keys_out[t] = ~pattern(score) — or ~pattern(bf16(score * ||v_t||)) when value_sumsq (fp32
+ * [n_kv][n], from qp_key_sumsq over the value rows) is given — ready for qp_prune_keys: k largest scores, ties -> lowest index. */
+size_t qp_query_scores_workspace_bytes(int64_t n, int64_t m, int n_q_heads);
+int qp_query_scores(qp_ctx* ctx, const void* q_prompt, const void* k_group, int64_t k_head_stride, int64_t n, int64_t m,
+                    int n_q_heads, int n_kv_heads, int head_dim, const float* value_sumsq, uint16_t* norm_keys_out,
+                    uint16_t* scores_out, void* workspace, size_t workspace_bytes, void* stream);
+
 /* In-place drop-in for post_process_kv_cache's KV part on the arena (utils.py:266-342):
  * rows [past_len, past_len+n) are the group's new tokens; on return rows [past_len, past_len+k) hold the
  * kept ones in original order and kept_idx_out[k] lists them.  workspace >= qp_prune_workspace_bytes(). */

@@ -505,10 +505,54 @@ def gen_e2e_deep(ref):
     print(meta)
 
 
+
+# ---------------------------------------------------------------- GV9: query-attention-score mode
+
+QUERY_CASES = [  # (Hq, Hkv, n group tokens, m prompt tokens, k)
+    (4, 2, 64, 5, 32), (28, 4, 720, 30, 360), (28, 4, 2240, 30, 1120), (8, 1, 960, 24, 480), (12, 2, 333, 1, 100), (28, 4, 5760, 30, 2880),
+]
+
+
+def make_query_case(ci):
+    hq, hkv, n, m, k = QUERY_CASES[ci]
+    rs = np.random.RandomState(3000 + ci)
+    bf = lambda *s, sc=1.0: torch.from_numpy((rs.standard_normal(s) * sc).astype(np.float32)).to(torch.bfloat16)
+    return bf(1, hq, n + m, 128, sc=1.3), bf(1, hkv, n + m, 128, sc=1.3), bf(1, hkv, n + m, 128)
+
+
+def gen_query_scores(ref):
+    """GV9: the reference's own LVUCache.update in query-based mode (lvu_cache.py:97-117: prompt K/V stripped, softmax(QK^T) of the
+    prompt queries over the group's keys, summed over queries, averaged over heads) on seeded q/k/v, then
+    get_top_k_mask_to_predict for both query predict types (utils.py:55-62; argsort forced stable = deployment device)."""
+    U, LC = ref["utils"], ref["lvu_cache"]
+    out, meta = {}, []
+    for ci, (hq, hkv, n, m, k) in enumerate(QUERY_CASES):
+        q, kk, vv = make_query_case(ci)
+        cache = LC.LVUCache()
+        cache.set_prompt_length(m)
+        k_all, v_all = cache.update(kk, vv, 0, {"query_states": q})
+        assert k_all.shape[2] == n and torch.equal(k_all, kk[:, :, :n])              # prompt K/V never enter the cache
+        score = cache.accum_attn_scores[0][-1]
+        assert score.shape == (1, n) and score.dtype == torch.bfloat16
+        out[f"c{ci}_score_bits"] = O.torch_bf16_to_bits(score[0])
+        hid = torch.zeros(1, n, 8)
+        for mode in ("query_attention_weights", "query_attention_weights_by_value_norm"):
+            with force_stable_argsort():
+                mask = U.get_top_k_mask_to_predict(score, k_all, v_all, hid, top_k=k, predict_type=mode)
+            idx = torch.nonzero(mask[0], as_tuple=True)[0].numpy().astype(np.int32)
+            assert len(idx) == k
+            out[f"c{ci}_{mode}"] = idx
+        meta.append(dict(case=ci, hq=hq, hkv=hkv, n=n, m=m, k=k, seed=3000 + ci, score_max=float(score.float().max()),
+                         distinct_scores=int(len(np.unique(out[f"c{ci}_score_bits"])))))
+        print(meta[-1])
+    np.savez_compressed(os.path.join(OUT, "gv9_query_scores.npz"), **out)
+    json.dump(meta, open(os.path.join(OUT, "gv9_query_scores.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     ref = load_reference()
-    which = sys.argv[1:] or ["select", "modes", "effk", "compact", "e2e", "e2e_modes", "e2e_decode", "rope"]
+    which = sys.argv[1:] or ["select", "modes", "effk", "compact", "e2e", "e2e_modes", "e2e_decode", "rope", "query"]
     if "select" in which: gen_select(ref)
     if "modes" in which: gen_select_modes(ref)
     if "effk" in which: gen_effective_k(ref)
@@ -517,4 +561,5 @@ if __name__ == "__main__":
     if "e2e_modes" in which: gen_e2e_modes(ref)
     if "e2e_decode" in which: gen_e2e_decode(ref)
     if "rope" in which: gen_rope_index()
+    if "query" in which: gen_query_scores(ref)
     if "deep" in which: gen_e2e_deep(ref)       # ~20 min of CPU and 40 GB of RAM: not in the default list

@@ -305,7 +305,8 @@ class PruneCfg:
     enable: bool = True
     prefill_prune_starting_layer: Optional[int] = None
     top_k_starting_layer: Optional[int] = None
-    top_k_predict_type: str = "key_norms_small"       # or key_norms / vector_norms_small / vector_norms (utils.py:117-136)
+    top_k_predict_type: str = "key_norms_small"       # or key_norms / vector_norms_small / vector_norms (utils.py:117-136),
+                                                      # or query_attention_weights[_by_value_norm] (utils.py:55-62; query_based)
 
 
 def rmsnorm(x: torch.Tensor, w: torch.Tensor, eps: float) -> torch.Tensor:
@@ -357,8 +358,33 @@ def attention_bottom_right(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, sc
         s = (q[h].float() @ k[h // g].float().T) * scale
         s = s.masked_fill(~mask, float("-inf"))
         pr = torch.softmax(s, dim=-1)
+        pr = torch.nan_to_num(pr, nan=0.0)             # a query that sees no key at all (kv < n: query-based groups) -> 0, like flash-attn
         out[:, h] = (pr @ v[h // g].float()).to(q.dtype)
     return out
+
+
+def query_attention_scores(q_prompt: torch.Tensor, k_group: torch.Tensor) -> torch.Tensor:
+    """The query-based scoring of LVUCache.update (lvu_cache.py:100-116), op for op: q_prompt [Hq, m, D] = the RoPE'd queries of
+    the prompt tokens appended to the group, k_group [Hkv, n, D] = the group's own RoPE'd keys (NOT the past).  Scores q.k^T/sqrt(D)
+    in the model dtype, softmax over the n keys in fp32, cast back, summed over the m queries, averaged over the heads -> [n]."""
+    hq, m, d = q_prompt.shape
+    kr = k_group.repeat_interleave(hq // k_group.shape[0], dim=0)          # repeat_kv
+    a = torch.einsum("hqd,hkd->hqk", q_prompt, kr) / (d ** 0.5)
+    p = torch.softmax(a, dim=-1, dtype=torch.float32).to(q_prompt.dtype)
+    return p.sum(-2).mean(0)
+
+
+def query_score_keys(score: torch.Tensor, v_group: Optional[torch.Tensor] = None) -> np.ndarray:
+    """Sort keys (uint16 patterns, larger = kept first) for predict types query_attention_weights (utils.py:55-57) and, with
+    v_group [Hkv, n, D], query_attention_weights_by_value_norm (utils.py:58-62: score * ||v_t|| over all kv heads, bf16 product).
+    Scores are non-negative, so the bf16 bit pattern orders like the value; the reference's argsort(descending=True) on its
+    deployment device is stable, i.e. ties -> lowest index = select_k_largest."""
+    if v_group is not None:
+        vn = v_group.transpose(0, 1).flatten(1, 2).norm(2, dim=-1)
+        score = score * vn
+    if score.dtype == torch.bfloat16:
+        return torch_bf16_to_bits(score)
+    return score.float().numpy()
 
 
 class OracleCache:
@@ -389,7 +415,7 @@ def _norm_keys_of(k_new: torch.Tensor) -> np.ndarray:
 
 def decoder_layer(h: torch.Tensor, w: dict, layer: int, spec: TextSpec, cache: OracleCache,
                   cos: torch.Tensor, sin: torch.Tensor, k_keep: Optional[int],
-                  prune_hidden: bool = False, trace: Optional[dict] = None, predict_type: str = "key_norms_small"):
+                  prune_hidden: bool = False, trace: Optional[dict] = None, predict_type: str = "key_norms_small", prompt_len: int = 0):
     """One patched decoder layer (qwen25_lvu.py:122-212) on h [n, d].
 
     Returns (h_out, kept_idx or None).  When ``prune_hidden`` (prune_for_next_layer,
@@ -406,14 +432,26 @@ def decoder_layer(h: torch.Tensor, w: dict, layer: int, spec: TextSpec, cache: O
     k = k.view(n, spec.n_kv_heads, spec.head_dim).transpose(0, 1)
     v = v.view(n, spec.n_kv_heads, spec.head_dim).transpose(0, 1)
     q, k = apply_rope(q, cos, sin), apply_rope(k, cos, sin)
+    qscore = None
+    if prompt_len:                                          # query-based group (qwen25_lvu.py:663-664, 684-686; lvu_cache.py:99-116):
+        ng = n - prompt_len                                 # the last prompt_len rows are the prompt; their K/V never enter the cache
+        qscore = query_attention_scores(q[:, ng:], k[:, :ng].contiguous())
+        k, v = k[:, :ng], v[:, :ng]
     k_all, v_all = cache.append(layer, k.contiguous(), v.contiguous())
+    # n queries over kv = past + (n - prompt_len) keys, flash-attn bottom-right alignment: query i sees keys j <= i + kv - n
     att = attention_bottom_right(q, k_all, v_all, spec.head_dim ** -0.5)
     h = h + torch.nn.functional.linear(att.reshape(n, -1), w[p + "o_proj.weight"])
     kept = None
     if k_keep is not None:                                  # post_process_kv_cache, utils.py:257-342
-        past = k_all.shape[1] - n
-        source, order = NORM_PRUNE_MODES[predict_type]
-        norms = _norm_keys_of((v_all if source else k_all)[:, past:])
+        past = k_all.shape[1] - (n - prompt_len)            # utils.py:236-238: q_len -= prompt_length
+        if prompt_len:
+            if prune_hidden:
+                raise NotImplementedError("query-based scoring + hidden-state pruning: the reference drops the prompt rows there")
+            norms = query_score_keys(qscore, v_all[:, past:] if predict_type == "query_attention_weights_by_value_norm" else None)
+            source, order = 0, 1
+        else:
+            source, order = NORM_PRUNE_MODES[predict_type]
+            norms = _norm_keys_of((v_all if source else k_all)[:, past:])
         kept = select_k_largest(norms, k_keep) if order else select_k_smallest(norms, k_keep)
         ti = torch.from_numpy(kept.astype(np.int64))
         cache.k[layer] = torch.cat([k_all[:, :past], k_all[:, past:][:, ti]], dim=1)
@@ -443,21 +481,26 @@ def group_prefill(w: dict, spec: TextSpec, embeds: torch.Tensor, pos: np.ndarray
     start = 0
     post = torch.from_numpy(pos)
     segments = list(group_tokens) + [embeds.shape[0] - sum(group_tokens)]
+    query_based = "query" in cfg.top_k_predict_type          # lvu_config.py:31-33
+    m = segments[-1] if query_based else 0                   # prompt = everything after the last video token (qwen25_lvu.py:661)
     h = None
     for gi, n in enumerate(segments):
         is_tail = gi == len(segments) - 1
+        pl = 0 if is_tail else m
         h = embeds[start:start + n]
-        cos, sin = mrope_cos_sin(post[:, start:start + n], spec, dt)
+        if pl:                                               # group tokens + the prompt tokens; positions = the next n+m of the sequence (:684-689)
+            h = torch.cat([h, embeds[-m:]], 0)
+        cos, sin = mrope_cos_sin(post[:, start:start + n + pl], spec, dt)
         kept_g = []
         for l in range(spec.n_layers):
-            q_len = h.shape[0]
+            q_len = h.shape[0] - pl
             k_keep = None if is_tail else effective_k(q_len, cfg.top_k, cfg.top_p, cfg.top_k_decay_type,
                                                       cfg.top_k_decay_factor, l, spec.n_layers, cfg.enable,
                                                       cfg.top_k_starting_layer)
             ph = (not is_tail and cfg.enable and isinstance(cfg.prefill_prune_starting_layer, int)
                   and cfg.prefill_prune_starting_layer >= 0 and l >= cfg.prefill_prune_starting_layer)
             h, kept, cos, sin = decoder_layer(h, w, l, spec, cache, cos, sin, k_keep, prune_hidden=ph,
-                                              predict_type=cfg.top_k_predict_type)
+                                              predict_type=cfg.top_k_predict_type, prompt_len=pl)
             kept_g.append(kept)
         kept_all.append(kept_g)
         start += n

@@ -22,7 +22,7 @@ from typing import List, Optional
 
 import torch
 
-from .lvu_config import LVUConfig, NORM_PRUNE_MODES, effective_k
+from .lvu_config import LVUConfig, NORM_PRUNE_MODES, QUERY_PRUNE_MODES, effective_k
 from .weights import DecoderWeights
 
 
@@ -113,10 +113,13 @@ class QuickPrefillEngine:
             self._probe_key = e(8, dtype=torch.int16)
         self.b_h2 = e(n, d)
         # norm-based predict type (utils.py:117-136): which rows are scored (keys / values) and which end is kept
-        if cfg.top_k_predict_type not in NORM_PRUNE_MODES:
+        self.query_mode = cfg.top_k_predict_type in QUERY_PRUNE_MODES     # query-attention-score pruning (lvu_cache.py:97-117)
+        if cfg.top_k_predict_type not in NORM_PRUNE_MODES and not self.query_mode:
             raise ValueError(f"Unknown predict type: {cfg.top_k_predict_type} (the native engine implements the norm-based modes "
-                             f"{sorted(NORM_PRUNE_MODES)}; lvu/utils.py:117-136)")
-        self.norm_source, self.norm_order = NORM_PRUNE_MODES[cfg.top_k_predict_type]
+                             f"{sorted(NORM_PRUNE_MODES)} and the query-score modes {sorted(QUERY_PRUNE_MODES)}; lvu/utils.py:55-62, 117-136)")
+        self.norm_source, self.norm_order = NORM_PRUNE_MODES.get(cfg.top_k_predict_type, (0, 1))
+        if self.query_mode and not hasattr(self, "b_keys"):
+            self.b_keys = e(n, dtype=torch.int16)
         self.ops.set_prune_mode(self.norm_source, self.norm_order)
         env = os.environ.get("QP_SPLIT_GATE_UP_ROWS")                                  # developer override, see _gate_up_swiglu
         self.split_gate_up_rows = tuple(int(v) for v in env.split(",")) if env else None
@@ -381,6 +384,87 @@ class QuickPrefillEngine:
         ops.add_inplace(h, delta)                                            # last residual                  (:198)
         return h
 
+    # ------------------------------------------------------------------ query-attention-score groups
+    def _forward_segment_query(self, embeds: torch.Tensor, pos: torch.Tensor, m: int) -> torch.Tensor:
+        """One video group in the reference's query-based mode (top_k_predict_type "query_attention_weights[_by_value_norm]"):
+        the m prompt tokens are appended to the group's n tokens (qwen25_lvu.py:684-689), their K/V never enter the cache and their
+        queries score the group's keys (LVUCache.update, lvu_cache.py:97-117); post_process_kv_cache keeps the k highest-scoring of
+        the n group tokens (utils.py:55-62, 236-238).  Attention is what flash-attn computes for n+m queries over past+n keys with
+        its bottom-right aligned causal mask (:102-112): query i sees keys j <= i + past - m — the first m queries see only part
+        of the prefix, query i >= m sees the whole prefix and the group's keys up to i - m.  embeds [n+m, d], pos [3, n+m]."""
+        s, ops, cfg, D = self.spec, self.ops, self.cfg, self.D
+        nt = pos.shape[1]
+        n = nt - m
+        assert embeds.shape[0] == nt and n > 0 and nt <= self.n_max, f"group of {n}+{m} tokens exceeds max_group_tokens={self.n_max}"
+        if self.tp_size > 1 or self.sp_size > 1 or self.pp_size > 1:
+            raise NotImplementedError("query-attention-score pruning runs on one GPU (no tensor / group-token / layer-pipeline parallel form)")
+        if cfg.enable and isinstance(cfg.prefill_prune_starting_layer, int) and cfg.prefill_prune_starting_layer >= 0:
+            raise NotImplementedError("query-attention-score pruning + hidden-state pruning: the reference drops the prompt rows there")
+        if n > getattr(ops, "PRUNE_KEYS_MAX_N", 8192):
+            raise NotImplementedError(f"query-attention-score pruning: groups of at most {ops.PRUNE_KEYS_MAX_N} tokens (got {n})")
+        by_vnorm = QUERY_PRUNE_MODES[cfg.top_k_predict_type]
+        L = self.n_layers_total
+        cos, sin = ops.mrope_table(pos.contiguous(), s.mrope_section, s.rope_theta, D)
+        h = self.b_h[:nt]
+        h.copy_(embeds)
+        delta, scale, hs = None, D ** -0.5, self.arena.head_stride
+        for l, lw in enumerate(self.w.layers):
+            x = self.b_x[:nt]
+            ops.add_rmsnorm(h, delta, lw.ln1, x, s.rms_eps)
+            qkv = self.b_qkv[:nt]
+            self._linear("qkv", x, lw.w_qkv, qkv, lw.b_qkv)
+            k_keep = effective_k(n, cfg, self.l0 + l, L)                     # utils.py:236-255: q_len -= prompt_length
+            past = self.arena.len[l]
+            q = self.b_q[:nt]
+            if k_keep is not None:                                           # group + prompt K/V to staging; only the group's rows are read again
+                kn = self.b_stage[0].view(-1)[: self.hkv * nt * D].view(self.hkv, nt, D)
+                vn = self.b_stage[1].view(-1)[: self.hkv * nt * D].view(self.hkv, nt, D)
+                stride = nt * D
+                ops.rope_append(qkv, cos, sin, self.hq, self.hkv, D, q, kn, vn, stride, 0, None)
+            else:                                                            # no pruning in this layer: the prompt rows land behind the group's
+                assert past + nt <= self.arena.capacity, "KV arena overflow"  # and are overwritten by the next append
+                kc, vc = self.arena.k(l), self.arena.v(l)
+                ops.rope_append(qkv, cos, sin, self.hq, self.hkv, D, q, kc, vc, hs, past, None)
+                kn, vn, stride = kc[:, past:], vc[:, past:], hs
+            assert past + (k_keep if k_keep is not None else n) <= self.arena.capacity, "KV arena overflow"
+            att = self.b_att[:nt]
+            pa = past if cfg.adaptive_local_attention else 0
+            # queries m .. n+m-1: whole prefix + the group's keys j <= i - m  == the standard launch on the query rows shifted by m
+            ops.prefill_attn(q[m:], self.arena.k(l), self.arena.v(l), hs, pa, kn, vn, stride, n, self.hq, self.hkv, D, scale, att[m:])
+            # queries 0 .. m-1: prefix keys j <= pa - m + i only (none at all for i < m - pa)
+            z = max(0, m - pa)
+            if z:
+                att[:z].zero_()
+            if m > z:
+                ops.prefill_attn(q[z:m], None, None, hs, 0, self.arena.k(l), self.arena.v(l), hs, pa, self.hq, self.hkv, D, scale, att[z:m],
+                                 q_row0=pa - (m - z), nq=m - z)
+            o = self.b_o[:nt]
+            self._linear("o", att.view(nt, self.hq * D), lw.w_o, o)
+            if k_keep is not None:
+                vss = None
+                if by_vnorm:
+                    ops.key_sumsq(vn, stride, 0, n, self.hkv, D, self.b_ss)
+                    vss = self.b_ss
+                ops.query_scores(q[n:], kn, stride, n, self.hq, self.hkv, D, self.b_keys, value_sumsq=vss)
+                idx = self.b_idx[:k_keep]
+                ops.prune_keys(self.b_keys, n, k_keep, kn, vn, stride, self.hkv, D, self.arena.k(l), self.arena.v(l), hs, past, idx)
+                self.arena.len[l] = past + k_keep
+                if self.kept_trace is not None:
+                    self.kept_trace.append((l, idx.clone()))
+            else:
+                self.arena.len[l] = past + n
+                if self.kept_trace is not None:
+                    self.kept_trace.append((l, None))
+            x2 = self.b_x[:nt]
+            ops.add_rmsnorm(h, o, lw.ln2, x2, s.rms_eps)
+            act = self.b_act[:nt]
+            self._gate_up_swiglu(x2, lw, act)
+            dn = self.b_dn[:nt]
+            self._linear("down", act, lw.w_down, dn)
+            delta = dn
+        ops.add_inplace(h, delta)
+        return h
+
     # ------------------------------------------------------------------ group-token parallel variant of forward_segment
     def _forward_segment_sp(self, embeds: torch.Tensor, pos: torch.Tensor, prune: bool, video_group: bool = False) -> torch.Tensor:
         """Rank r runs its token rows of the segment through every layer; per layer ONE all-gather moves the ranks' new K/V rows
@@ -513,9 +597,19 @@ class QuickPrefillEngine:
     def is_last_stage(self) -> bool:
         return self.pp_rank == self.pp_size - 1
 
-    def prefill_group(self, embeds: torch.Tensor, pos: torch.Tensor):
+    def prefill_group(self, embeds: torch.Tensor, pos: torch.Tensor, prompt_embeds: Optional[torch.Tensor] = None):
         """One video group (qwen25_lvu.py:671-717): KV appended + pruned; hidden output is discarded like the
-        reference discards the group's logits (:697-699).  (Layer pipeline: `embeds` only matters on stage 0.)"""
+        reference discards the group's logits (:697-699).  (Layer pipeline: `embeds` only matters on stage 0.)
+        Query-based predict types: pass the prompt's embedding rows [m, d] and positions for n+m tokens (the group's and the NEXT m
+        of the sequence, :684-689); only the group's n tokens count towards the sequence position."""
+        if self.query_mode and self.cfg.enable:
+            if prompt_embeds is None:
+                raise ValueError("query-based top_k_predict_type: prefill_group needs the prompt embeddings (qwen25_lvu.py:684-686)")
+            m = prompt_embeds.shape[0]
+            assert pos.shape[1] == embeds.shape[0] + m, "positions for the group's tokens AND the appended prompt tokens are required"
+            self._forward_segment_query(torch.cat([embeds, prompt_embeds], 0), pos, m)
+            self.seq_pos += embeds.shape[0]
+            return
         h = self.forward_segment(self._pp_in(embeds), pos, prune=True, video_group=True)
         self._pp_out(h)
         self.seq_pos += embeds.shape[0]

@@ -57,6 +57,10 @@ class LVULayerConfig:
 NORM_PRUNE_MODES = {"key_norms_small": (0, 0), "key_norms": (0, 1), "vector_norms_small": (1, 0), "vector_norms": (1, 1)}
 
 
+# query-based predict types (utils.py:55-62; lvu_config.py:31-33 sets query_based): name -> weight the score by the value norm?
+QUERY_PRUNE_MODES = {"query_attention_weights": False, "query_attention_weights_by_value_norm": True}
+
+
 def effective_k(q_len: int, cfg: LVUConfig, layer_idx: int, total_layers: int) -> Optional[int]:
     """How many of the group's q_len new tokens this layer keeps; None = this layer does not prune.
 

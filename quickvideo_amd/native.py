@@ -41,6 +41,8 @@ SIGNATURES = {
     "qp_mrope_table": (_i32, [_vp, _vp, _i64, _c.POINTER(_c.c_int32), _f32, _i32, _vp, _vp, _vp]),
     "qp_rope_append": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _vp, _vp]),
     "qp_rope_append_keys": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
+    "qp_query_scores_workspace_bytes": (_sz, [_i64, _i64, _i32]),
+    "qp_query_scores": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "qp_norm_keys": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp]),
     "qp_prune_keys": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _i64, _vp, _vp]),
     "qp_prefill_attn": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _f32, _vp, _vp, _sz, _vp]),
@@ -162,6 +164,16 @@ class QuickPrefillOps:
         return n_kv == 1 or (n_kv == 2 and rpt % 2 == 0 and n_q % 2 == 0) or (n_kv == 4 and rpt % 4 == 0 and n_q % 4 == 0)
 
     PRUNE_KEYS_MAX_N = 8192
+
+    def query_scores(self, q_prompt, k_group, k_head_stride, n, n_q, n_kv, head_dim, norm_keys, value_sumsq=None, scores=None):
+        """Query-based scoring (lvu_cache.py:97-117): q_prompt [m, n_q, D], the group's keys -> complemented score keys for prune_keys."""
+        m = q_prompt.shape[0]
+        need = int(self.lib.qp_query_scores_workspace_bytes(n, m, n_q))
+        if getattr(self, "_qs_ws", None) is None or self._qs_ws.numel() < need:
+            self._qs_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        self._check(self.lib.qp_query_scores(self.ctx, q_prompt.data_ptr(), k_group.data_ptr(), k_head_stride, n, m, n_q, n_kv, head_dim,
+                                             _ptr(value_sumsq), norm_keys.data_ptr(), _ptr(scores), self._qs_ws.data_ptr(), self._qs_ws.numel(),
+                                             self._stream()))
 
     def norm_keys(self, head_sumsq, n_heads_total, n, norm_keys):
         self._check(self.lib.qp_norm_keys(self.ctx, head_sumsq.data_ptr(), n_heads_total, n, norm_keys.data_ptr(), self._stream()))

@@ -172,6 +172,8 @@ class PrefillPipeline:
         kept = sum((effective_k(n, cfg, 0, spec.n_layers) or n) for n in plan.tokens)
         need_cap = kept + plan.tail_len + max(256, max_new_tokens + 8)        # room for every token that will be decoded
         n_max = max(plan.tokens + [plan.tail_len, 1])
+        if cfg.query_based:                                   # the prompt tokens ride along with every group (qwen25_lvu.py:684-686)
+            n_max += plan.tail_len
         eng = self.model.engine
         if eng is None or eng.arena.capacity < need_cap or eng.n_max < n_max or eng.cfg is not cfg:
             eng = QuickPrefillEngine(self.model.text, cfg, capacity=need_cap, max_group_tokens=n_max, device=self.model.device, ops=self.ops)
@@ -231,6 +233,10 @@ class PrefillPipeline:
 
         t_pre = time.perf_counter()
         start, vit_events = 0, []
+        # query-based predict types: the prompt (everything after the last video token) is appended to every group and scores its
+        # keys (qwen25_lvu.py:661-664, 684-689); positions are then the group's AND the next tail_len of the sequence
+        q_m = plan.tail_len if (self.cfg.query_based and self.cfg.enable) else 0
+        tail_emb = eng.embed_tokens(tail) if q_m else None
         nxt = vit_group(0)
         for g, n in enumerate(plan.tokens):
             feats, evs, read_done = nxt
@@ -245,7 +251,7 @@ class PrefillPipeline:
             assert emb.shape[0] == n, (emb.shape, n)
             if g + 1 < len(plan.tokens):
                 nxt = vit_group(g + 1)                                # ViT of the next group runs ahead on its own stream
-            eng.prefill_group(emb, pos[:, start:start + n])
+            eng.prefill_group(emb, pos[:, start:start + n + q_m], prompt_embeds=tail_emb)
             prod.release(g, read_done)
             start += n
         sync()

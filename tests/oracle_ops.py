@@ -85,6 +85,22 @@ class OracleOps:
         self.select_k_smallest(head_sumsq, n_heads_total, n, k, kept_idx)
         self.gather_kv(k_src, v_src, src_head_stride, kept_idx, k, n_kv, D, k_dst, v_dst, dst_head_stride, dst_row0)
 
+    PRUNE_KEYS_MAX_N = 8192
+
+    def query_scores(self, q_prompt, k_group, k_head_stride, n, n_q, n_kv, D, norm_keys, value_sumsq=None, scores=None):
+        kg = torch.stack([self._rows(k_group, h, k_head_stride, 0, n, D) for h in range(n_kv)])
+        sc = O.query_attention_scores(q_prompt.transpose(0, 1).contiguous(), kg)
+        if value_sumsq is not None:                      # * bf16 value norm (utils.py:58-62)
+            vn = O.bits_to_torch_bf16(O.key_norms_bf16(value_sumsq.reshape(-1)[: n_kv * n].view(n_kv, n).numpy()))
+            sc = sc * vn
+        bits = O.torch_bf16_to_bits(sc)
+        norm_keys[:n].copy_(torch.from_numpy((~bits).astype(np.uint16).view(np.int16)))
+
+    def prune_keys(self, norm_keys, n, k, k_src, v_src, src_head_stride, n_kv, D, k_dst, v_dst, dst_head_stride, dst_row0, kept_idx):
+        keys = norm_keys[:n].numpy().view(np.uint16)
+        kept_idx[:k].copy_(torch.from_numpy(O.select_k_smallest(keys, k)))
+        self.gather_kv(k_src, v_src, src_head_stride, kept_idx, k, n_kv, D, k_dst, v_dst, dst_head_stride, dst_row0)
+
     def sp_unpack(self, gathered, world, n_kv, m2, head_dim, n, k_stage, v_stage, stage_head_stride, sumsq_out):
         m = 2 * m2
         kv_bytes = n_kv * m * head_dim * 2

@@ -53,9 +53,11 @@ def test_generate_end_to_end_cpu(model_type, capsys):
     assert obj2.generate("What happens in the video?", video, max_new_tokens=3) == out
 
 
-def test_pipeline_matches_oracle_first_token():
+@pytest.mark.parametrize("predict_type", ["key_norms_small", "query_attention_weights"])
+def test_pipeline_matches_oracle_first_token(predict_type):
     """Pipeline (frames -> patchify -> ViT -> scatter -> group prefill) vs the oracle's group_prefill fed with the same
-    ViT features: same first token and logits (same math through the ops double)."""
+    ViT features: same first token and logits (same math through the ops double).  Also in the query-based mode, where the
+    pipeline appends the prompt rows (and the next tail_len positions) to every group (qwen25_lvu.py:684-689)."""
     import lvu
     from quickvideo_amd.frames import open_video
     from quickvideo_amd.lvu import load_native_model
@@ -63,7 +65,7 @@ def test_pipeline_matches_oracle_first_token():
     from quickvideo_amd.processor import SyntheticProcessor
     from quickvideo_amd.vit import VisionTower, patchify_frames
     m = load_native_model("synthetic:tiny", device="cpu", seed=3)
-    cfg = lvu.LVUConfig("synthetic:tiny", top_p=0.5, video_group_size=4, num_frames=8)
+    cfg = lvu.LVUConfig("synthetic:tiny", top_p=0.5, video_group_size=4, num_frames=8, top_k_predict_type=predict_type)
     pipe = PrefillPipeline(m, cfg, SyntheticProcessor(m.spec), ops=OracleOps())
     video = "synthetic://?frames=16&h=56&w=84&seed=5&pattern=gradient"
     ids = pipe.generate("Describe the scene", video, max_new_tokens=1)
@@ -86,7 +88,7 @@ def test_pipeline_matches_oracle_first_token():
         w[p + "mlp.down_proj.weight"] = lw.w_down
     so = O.TextSpec(hidden=s.hidden, n_heads=s.n_heads, n_kv_heads=s.n_kv_heads, head_dim=s.head_dim, intermediate=s.intermediate,
                     n_layers=s.n_layers, vocab=s.vocab)
-    ref = O.group_prefill(w, so, emb, P["pos"], P["plan"].tokens, O.PruneCfg(top_p=0.5))
+    ref = O.group_prefill(w, so, emb, P["pos"], P["plan"].tokens, O.PruneCfg(top_p=0.5, top_k_predict_type=predict_type))
     assert int(torch.argmax(ref["logits"])) == ids[0]
     assert m.engine.arena.len == ref["cache_len"]
 

@@ -212,3 +212,33 @@ def test_split_gate_up_path_equals_fused(monkeypatch):
             eng.prefill_group(embeds[st:st + n], post[:, st:st + n]); st += n
         outs.append(eng.prefill_tail(embeds[st:], post[:, st:]))
     assert torch.allclose(outs[0], outs[1], atol=2e-2) and int(outs[0].argmax()) == int(outs[1].argmax())
+
+
+@pytest.mark.parametrize("pt", ["query_attention_weights", "query_attention_weights_by_value_norm"])
+def test_query_based_groups_host_logic(pt):
+    """prompt tokens appended to every group, their K/V kept out of the cache, flash-attn's bottom-right alignment for
+    n+m queries over past+n keys done as two launches (prefix-only rows + the standard launch shifted by m), k highest scores kept.
+    Engine (oracle-backed ops) == the oracle's monolithic restatement: identical kept lists, cache lengths and logits."""
+    spec_o, w, plan, pos, delta, embeds = make_case(24, 12, 16, 8, 15, 20)
+    m = plan.tail_len
+    cfg = LVUConfig("x", top_p=0.5, video_group_size=8, top_k_predict_type=pt)
+    assert cfg.query_based
+    eng = QuickPrefillEngine(DecoderWeights.from_named(TINY, w, "cpu"), cfg, capacity=embeds.shape[0] + 8 + m, max_group_tokens=max(plan.tokens) + m,
+                             device="cpu", ops=OracleOps())
+    eng.kept_trace = []
+    post, start, tail = torch.from_numpy(pos), 0, embeds[-m:]
+    with pytest.raises(ValueError):
+        eng.prefill_group(embeds[:plan.tokens[0]], post[:, :plan.tokens[0]])            # the prompt rows are mandatory in this mode
+    for n in plan.tokens:
+        eng.prefill_group(embeds[start:start + n], post[:, start:start + n + m], prompt_embeds=tail)
+        start += n
+    logits = eng.prefill_tail(embeds[start:], post[:, start:])
+    ref = O.group_prefill(w, spec_o, embeds, pos, plan.tokens, O.PruneCfg(top_p=0.5, top_k_predict_type=pt))
+    assert eng.arena.len == ref["cache_len"] and eng.seq_pos == embeds.shape[0]
+    flat = [k for g in ref["kept"] for k in g]
+    for (l, got), want in zip(eng.kept_trace, flat):
+        assert (got is None) == (want is None) and (want is None or np.array_equal(got.numpy(), want))
+    assert float((logits - ref["logits"]).abs().max()) == 0.0
+    # and the mode is not the key-norm mode in disguise
+    base = O.group_prefill(w, spec_o, embeds, pos, plan.tokens, O.PruneCfg(top_p=0.5))
+    assert any(not np.array_equal(a, b) for a, b in zip(flat, [k for g in base["kept"] for k in g]) if a is not None)

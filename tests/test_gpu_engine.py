@@ -147,6 +147,34 @@ def test_engine_72b_tp8_rank_slice_vs_oracle():
     check_logits(logits.numpy(), ref["logits"].numpy())
 
 
+@pytest.mark.parametrize("pt", ["query_attention_weights", "query_attention_weights_by_value_norm"])
+def test_engine_query_based_vs_oracle(pt):
+    """SURVEY 8 f4 on the GPU: prompt-appended groups, qp_query_scores + qp_prune_keys, the shifted causal alignment as two attention
+    launches — vs the oracle's restatement of the reference's query-based mode (pinned op by op on GV9)."""
+    spec_o, w, plan, pos, delta, embeds = make_case(24, 12, 16, 8, 15, 20)
+    m = plan.tail_len
+    cfg = LVUConfig("x", top_p=0.5, video_group_size=8, top_k_predict_type=pt)
+    dw = DecoderWeights.from_named(TINY, w, "cuda:0")
+    eng = QuickPrefillEngine(dw, cfg, capacity=embeds.shape[0] + 8 + m, max_group_tokens=max(plan.tokens) + m, device="cuda:0")
+    eng.kept_trace = []
+    post, e, start = torch.from_numpy(pos).cuda(), embeds.cuda(), 0
+    for n in plan.tokens:
+        eng.prefill_group(e[start:start + n], post[:, start:start + n + m], prompt_embeds=e[-m:])
+        start += n
+    logits = eng.prefill_tail(e[start:], post[:, start:]).cpu()
+    ref = O.group_prefill(w, spec_o, embeds, pos, plan.tokens, O.PruneCfg(top_p=0.5, top_k_predict_type=pt))
+    assert eng.arena.len == ref["cache_len"]
+    check_logits(logits.numpy(), ref["logits"].numpy())
+    flat = [k for g in ref["kept"] for k in g]
+    tot = same = 0
+    for (l, got), want in zip(eng.kept_trace, flat):
+        if want is not None:
+            g = got.cpu().numpy()
+            assert len(g) == len(want) and np.all(np.diff(g) > 0)
+            tot += len(want); same += len(set(g.tolist()) & set(want.tolist()))
+    assert same / tot >= 0.9, same / tot
+
+
 def test_no_gpu_fallback_is_loud():
     """The product refuses to run without the HIP library (no silent CPU path)."""
     from quickvideo_amd import native

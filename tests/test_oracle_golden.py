@@ -292,3 +292,17 @@ def test_deep_fixture_first_layers_match_oracle(golden_dir):
             want = gold[f"kept_g0_l{l}"].astype(np.int64)
             ov = len(set(kept.tolist()) & set(want.tolist())) / len(want)
             assert ov >= (0.99 if l == 0 else 0.95), (l, ov)
+
+
+def test_query_scores_match_reference(golden_dir):
+    """GV9: LVUCache.update's query-based scores (lvu_cache.py:97-117) and the kept lists of both query predict types
+    (utils.py:55-62, argsort forced stable) — the oracle restatement reproduces the reference's own outputs bit for bit."""
+    import json
+    from oracle.make_golden import QUERY_CASES, make_query_case
+    data = np.load(os.path.join(golden_dir, "gv9_query_scores.npz"))
+    for ci, (hq, hkv, n, m, k) in enumerate(QUERY_CASES):
+        q, kk, vv = make_query_case(ci)
+        sc = O.query_attention_scores(q[0, :, n:], kk[0, :, :n].contiguous())
+        assert np.array_equal(O.torch_bf16_to_bits(sc), data[f"c{ci}_score_bits"])
+        assert np.array_equal(O.select_k_largest(O.query_score_keys(sc), k), data[f"c{ci}_query_attention_weights"])
+        assert np.array_equal(O.select_k_largest(O.query_score_keys(sc, vv[0, :, :n]), k), data[f"c{ci}_query_attention_weights_by_value_norm"])
