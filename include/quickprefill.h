@@ -237,6 +237,11 @@ int qp_vit_rope(qp_ctx* ctx, void* qkv, const float* cos, const float* sin, int6
  * reference), head_dim 80, MFMA kernel shared with qp_prefill_attn.  out bf16 [n][heads][80]. */
 int qp_vit_attn(qp_ctx* ctx, const void* qkv, int64_t n_seq, int64_t seq_len, int heads, int head_dim, float scale, void* out,
                 void* stream);
+/* Same for a ragged batch — the window attention of the Qwen2.5-VL tower (28 of its 32 blocks; transformers
+ * get_vision_window_index [3P]): sequence i = rows [cu_seqlens[i], cu_seqlens[i+1]) of the packed, window-major qkv tensor
+ * (cu_seqlens int32 [n_seq+1] on the device, lengths <= max_seq_len), full attention inside every window. */
+int qp_vit_attn_varlen(qp_ctx* ctx, const void* qkv, const int32_t* cu_seqlens, int64_t n_seq, int64_t max_seq_len, int heads,
+                       int head_dim, float scale, void* out, void* stream);
 /* Residual add of a vision block fused with the LayerNorm after it: if delta != NULL, x = bf16(x + delta) (written back);
  * out = bf16((x - mean) * rstd * w + b) with fp32 statistics over the row (torch layer_norm).  x, delta, out bf16 [n][hidden]. */
 int qp_add_layernorm(qp_ctx* ctx, void* x, const void* delta, const void* w, const void* b, void* out, int64_t n, int hidden,

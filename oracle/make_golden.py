@@ -549,10 +549,60 @@ def gen_query_scores(ref):
     json.dump(meta, open(os.path.join(OUT, "gv9_query_scores.json"), "w"), indent=1)
 
 
+
+# ---------------------------------------------------------------- GV10: vision towers at head_dim 80 from installed transformers
+
+VIT_CASES = {
+    # name: (arch, grid_thw, kwargs)
+    "qwen2": ("qwen2", (2, 20, 28), dict(depth=3, embed_dim=1280, num_heads=16, mlp_ratio=4.0, out_hidden=256)),
+    "qwen25": ("qwen2.5", (2, 20, 28), dict(depth=3, embed_dim=1280, num_heads=16, out_hidden=256, intermediate=3420, window_size=112,
+                                           fullatt_blocks=(1,))),
+}
+
+
+def gen_vit_towers():
+    """GV10: output of transformers' Qwen2VisionTransformerPretrainedModel / Qwen2_5_VisionTransformerPretrainedModel (fp32 math on
+    bf16-rounded, hash-generated weights and pixel rows; 3 blocks at the real width 1280 / 16 heads = head_dim 80, the shape the HIP
+    kernels serve; the Qwen2.5 case has ragged border windows and one full-attention block) — the GPU test pins the HIP tower to
+    THIS, not to the product's own torch tower."""
+    from transformers.models.qwen2_vl.configuration_qwen2_vl import Qwen2VLVisionConfig
+    from transformers.models.qwen2_vl.modeling_qwen2_vl import Qwen2VisionTransformerPretrainedModel
+    from transformers.models.qwen2_5_vl.configuration_qwen2_5_vl import Qwen2_5_VLVisionConfig
+    from transformers.models.qwen2_5_vl.modeling_qwen2_5_vl import Qwen2_5_VisionTransformerPretrainedModel
+    out, meta = {}, {}
+    for name, (arch, grid, kw) in VIT_CASES.items():
+        if arch == "qwen2":
+            cfg = Qwen2VLVisionConfig(depth=kw["depth"], embed_dim=kw["embed_dim"], hidden_size=kw["out_hidden"], num_heads=kw["num_heads"],
+                                      mlp_ratio=int(kw["mlp_ratio"]), patch_size=14, spatial_merge_size=2, temporal_patch_size=2,
+                                      hidden_act="quick_gelu")
+            cfg._attn_implementation = "eager"
+            m = Qwen2VisionTransformerPretrainedModel(cfg).eval().float()
+        else:
+            cfg = Qwen2_5_VLVisionConfig(depth=kw["depth"], hidden_size=kw["embed_dim"], intermediate_size=kw["intermediate"], num_heads=kw["num_heads"],
+                                         out_hidden_size=kw["out_hidden"], window_size=kw["window_size"], fullatt_block_indexes=list(kw["fullatt_blocks"]),
+                                         patch_size=14, spatial_merge_size=2, temporal_patch_size=2, hidden_act="silu")
+            cfg._attn_implementation = "eager"
+            m = Qwen2_5_VisionTransformerPretrainedModel(cfg).eval().float()
+        names_shapes = [(k, list(v.shape)) for k, v in m.state_dict().items()]
+        seed = 40 + len(meta)
+        sd = O.hashed_state_dict(names_shapes, seed)
+        m.load_state_dict({k: v.float() for k, v in sd.items()})
+        t, h, w = grid
+        pix = O.hashed_normal((t * h * w, 1176), 900 + seed, 1.0)
+        with torch.no_grad():
+            ref = m(pix.float(), grid_thw=torch.tensor([list(grid)])).pooler_output
+        out[f"{name}_out"] = ref.numpy().astype(np.float32)
+        meta[name] = dict(arch=arch, grid=list(grid), spec=dict(kw, fullatt_blocks=list(kw.get("fullatt_blocks", ()))), weight_seed=seed,
+                          pixel_seed=900 + seed, names_shapes=names_shapes, out_absmax=float(ref.abs().max()))
+        print(name, ref.shape, float(ref.abs().max()))
+    np.savez_compressed(os.path.join(OUT, "gv10_vit_towers.npz"), **out)
+    json.dump(meta, open(os.path.join(OUT, "gv10_vit_towers.json"), "w"))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     ref = load_reference()
-    which = sys.argv[1:] or ["select", "modes", "effk", "compact", "e2e", "e2e_modes", "e2e_decode", "rope", "query"]
+    which = sys.argv[1:] or ["select", "modes", "effk", "compact", "e2e", "e2e_modes", "e2e_decode", "rope", "query", "vit"]
     if "select" in which: gen_select(ref)
     if "modes" in which: gen_select_modes(ref)
     if "effk" in which: gen_effective_k(ref)
@@ -562,4 +612,5 @@ if __name__ == "__main__":
     if "e2e_decode" in which: gen_e2e_decode(ref)
     if "rope" in which: gen_rope_index()
     if "query" in which: gen_query_scores(ref)
+    if "vit" in which: gen_vit_towers()
     if "deep" in which: gen_e2e_deep(ref)       # ~20 min of CPU and 40 GB of RAM: not in the default list

@@ -601,3 +601,16 @@ def hashed_text_weights(spec: TextSpec, seed: int = 0, device="cpu", dtype=torch
         w["embed_tokens.weight"] = hn((spec.vocab, d), seed * 100_003 + 11, std)
         w["lm_head.weight"] = w["embed_tokens.weight"] if spec.tie_embeddings else hn((spec.vocab, d), seed * 100_003 + 13, std)
     return w
+
+
+def hashed_state_dict(names_shapes, seed: int, device="cpu", dtype=torch.bfloat16, std: float = 0.03, norm_jitter: float = 0.05) -> dict:
+    """name -> hashed_normal tensor for a list of (name, shape); 1-D tensors whose name says "norm" / "ln_q" get 1 + jitter (weights) or
+    plain jitter (biases).  Used for the vision-tower fixtures (GV10): the same bits wherever they are generated."""
+    out = {}
+    for i, (name, shape) in enumerate(names_shapes):
+        is_norm = ("norm" in name or "ln_q" in name) and len(shape) == 1
+        t = hashed_normal(tuple(shape), seed * 7919 + i, norm_jitter if is_norm else std, device, torch.float32)
+        if is_norm and name.endswith("weight"):
+            t = t + 1.0
+        out[name] = t.to(dtype)
+    return out

@@ -357,7 +357,18 @@ int qp_vit_attn(qp_ctx* ctx, const void* qkv, int64_t n_seq, int64_t seq_len, in
   QP_REQUIRE(seq_len * 3 * heads * head_dim * 2 < (1ll << 31), QP_ERR_UNSUPPORTED, "qp_vit_attn: sequence too long");
   QP_REQUIRE(aligned16(qkv) && aligned16(out), QP_ERR_INVALID, "qp_vit_attn: alignment");
   if (n_seq == 0 || seq_len == 0) return QP_OK;
-  return qp_launch_vit_attn(ctx, qkv, n_seq, seq_len, heads, scale, out, (hipStream_t)stream);
+  return qp_launch_vit_attn(ctx, qkv, n_seq, seq_len, heads, scale, out, nullptr, (hipStream_t)stream);
+}
+
+int qp_vit_attn_varlen(qp_ctx* ctx, const void* qkv, const int32_t* cu_seqlens, int64_t n_seq, int64_t max_seq_len, int heads, int head_dim,
+                       float scale, void* out, void* stream) {
+  QP_REQUIRE(ctx && qkv && out && cu_seqlens, QP_ERR_INVALID, "qp_vit_attn_varlen: NULL argument");
+  QP_REQUIRE(head_dim == 80, QP_ERR_UNSUPPORTED, "qp_vit_attn_varlen: head_dim=%d (only 80)", head_dim);
+  QP_REQUIRE(n_seq >= 0 && max_seq_len >= 0 && heads > 0 && n_seq * heads < (1ll << 24), QP_ERR_INVALID, "qp_vit_attn_varlen: bad sizes");
+  QP_REQUIRE(max_seq_len * 3 * heads * head_dim * 2 < (1ll << 31), QP_ERR_UNSUPPORTED, "qp_vit_attn_varlen: sequence too long");
+  QP_REQUIRE(aligned16(qkv) && aligned16(out), QP_ERR_INVALID, "qp_vit_attn_varlen: alignment");
+  if (n_seq == 0 || max_seq_len == 0) return QP_OK;
+  return qp_launch_vit_attn(ctx, qkv, n_seq, max_seq_len, heads, scale, out, cu_seqlens, (hipStream_t)stream);
 }
 
 int qp_quick_gelu(qp_ctx* ctx, const void* x, void* out, int64_t n_elems, void* stream) {

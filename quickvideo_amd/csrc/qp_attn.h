@@ -28,6 +28,7 @@ struct AttnParams {
   int heads_per_seq;            // "kv head" index = seq * heads_per_seq + head
   int64_t seq_stride16;         // uint4 between consecutive sequences (K/V and Q)
   int kv_row_bytes;             // byte stride between consecutive K/V (and Q) rows
+  const int* cu_seqlens;        // ragged batch (Qwen2.5-VL window attention): sequence s = rows [cu[s], cu[s+1]); NULL = n_seq x S
   // query sub-range (group-token parallel ranks): q/out hold rows [q_row0, q_row0+nq) of the group's n new tokens
   int q_row0; int nq;
   int qb_rows;                  // query rows per workgroup / work item (128 or 256); partials hold partial_floats(qb_rows) floats

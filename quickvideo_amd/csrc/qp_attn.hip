@@ -69,7 +69,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel_s4(AttnParams p) {
   const int qi = q0l + (lane & 31);
   const int q0w = p.q_row0 + q0l;                            // row inside the group's new segment (causal mask)
   const int hi = lane >> 5, l31 = lane & 31;
-  const int n = (int)p.n, P = (int)p.P, nq = p.nq;
+  const int n = (int)p.n;
+  int P = (int)p.P, nq = p.nq;
+  const int seq = kVit ? kvh / p.heads_per_seq : 0;
+  int64_t seq_row0 = kVit ? (int64_t)seq * n : 0;            // first row of this sequence in the packed [rows][3][H][D] tensor
+  if (kVit && p.cu_seqlens) {                              // ragged batch: this sequence's rows and length
+    const int a = p.cu_seqlens[seq];
+    seq_row0 = a;
+    P = nq = p.cu_seqlens[seq + 1] - a;
+    if (qb * kQB >= nq) return;                            // workgroup-uniform, before any barrier
+  }
 
   int blk_end = qb * kQB + kQB;
   if (blk_end > nq) blk_end = nq;
@@ -78,8 +87,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel_s4(AttnParams p) {
   int ti_lo = 0, ti_hi = nt;
   if (partial) { ti_lo = (int)((int64_t)split * nt / p.nsplit); ti_hi = (int)((int64_t)(split + 1) * nt / p.nsplit); }
   const int row_bytes = kVit ? p.kv_row_bytes : 256;
-  const int seq = kVit ? kvh / p.heads_per_seq : 0;
-  const int64_t kv_base16 = kVit ? (int64_t)seq * p.seq_stride16 + (int64_t)(kvh % p.heads_per_seq) * SLOTS : (int64_t)kvh * p.pre_hs16;
+  const int64_t kv_base16 = kVit ? seq_row0 * (row_bytes / 16) + (int64_t)(kvh % p.heads_per_seq) * SLOTS : (int64_t)kvh * p.pre_hs16;
   const __amdgpu_buffer_rsrc_t rkp = __builtin_amdgcn_make_buffer_rsrc((void*)(p.kp + kv_base16), 0, P * row_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rvp = __builtin_amdgcn_make_buffer_rsrc((void*)(p.vp + kv_base16), 0, P * row_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rkn = __builtin_amdgcn_make_buffer_rsrc((void*)(p.kn + (int64_t)kvh * p.new_hs16), 0, kVit ? 0 : n * 256, 0x00020000);
@@ -99,7 +107,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel_s4(AttnParams p) {
   bf16x8_t qf[KSTEPS];
   {
     const int qrow = qi < nq ? qi : nq - 1;
-    const uint4* qp = kVit ? p.q + (int64_t)seq * p.seq_stride16 + (int64_t)qrow * (row_bytes / 16) + (int64_t)(kvh % p.heads_per_seq) * SLOTS
+    const uint4* qp = kVit ? p.q + (seq_row0 + qrow) * (row_bytes / 16) + (int64_t)(kvh % p.heads_per_seq) * SLOTS
                            : p.q + ((int64_t)qrow * p.hq + head) * 16;
 #pragma unroll
     for (int kk = 0; kk < KSTEPS; ++kk) qf[kk] = __builtin_bit_cast(bf16x8_t, qp[kk * 2 + hi]);
@@ -229,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel_s4(AttnParams p) {
   if (qi < nq) {
     const float inv = 1.0f / l_run;
     // LLM: out [nq][hq][128]; ViT: out [seq][S][heads][D]  (D/4 x 8 B per row)
-    uint2* op = kVit ? p.out + (((int64_t)seq * n + qi) * p.heads_per_seq + (kvh % p.heads_per_seq)) * (D / 4)
+    uint2* op = kVit ? p.out + ((seq_row0 + qi) * p.heads_per_seq + (kvh % p.heads_per_seq)) * (D / 4)
                      : p.out + ((int64_t)qi * p.hq + head) * 32;
 #pragma unroll
     for (int db = 0; db < NDB; ++db)
@@ -553,7 +561,7 @@ int qp_launch_prefill_attn(const qp_ctx* ctx, const void* q, const void* k_prefi
   p.hq = hq; p.group = hq / hkv; p.c = scale * 1.4426950408889634f;
   p.nqb = (int)((nq + kQB - 1) / kQB); p.hkv = hkv; p.ws = (float*)workspace;
   p.items = p.nqb * p.group; p.n_whole = p.items; p.nsplit = 1;
-  p.heads_per_seq = hkv; p.seq_stride16 = 0; p.kv_row_bytes = 256;
+  p.heads_per_seq = hkv; p.seq_stride16 = 0; p.kv_row_bytes = 256; p.cu_seqlens = nullptr;
   p.q_row0 = (int)q_row0; p.nq = (int)nq; p.qb_rows = kQB;
   const char* var = getenv("QP_ATTN_VARIANT");        // developer A/B switch (tools/bench_attn.py); default = production kernel
   const int variant = var ? atoi(var) : 0;
@@ -608,8 +616,10 @@ int qp_launch_prefill_attn(const qp_ctx* ctx, const void* q, const void* k_prefi
 // Batched non-causal attention of the ViT tower: qkv bf16 [n_seq*S][3][H][80] (after the rotary), out [n_seq*S][H][80].
 // Every (sequence, head) pair is its own "kv head" with one q head; 1-D grid with all q blocks of a pair on one XCD (neutral
 // at the video shapes, where the whole qkv fits the MALL), no kv split (n_seq*H*ceil(S/128) workgroups is several rounds).
+// cu_seqlens != NULL: ragged batch (Qwen2.5-VL window attention) — n_seq sequences of at most S rows, sequence i = rows
+// [cu[i], cu[i+1]) of the packed tensor; workgroups past a sequence's end exit at once.
 int qp_launch_vit_attn(const qp_ctx* ctx, const void* qkv, int64_t n_seq, int64_t S, int heads, float scale, void* out,
-                       hipStream_t s) {
+                       const int* cu_seqlens, hipStream_t s) {
   (void)ctx;
   constexpr int D = 80;
   AttnParams p;
@@ -620,7 +630,7 @@ int qp_launch_vit_attn(const qp_ctx* ctx, const void* qkv, int64_t n_seq, int64_
   const int hk = (int)(n_seq * heads);
   p.hq = hk; p.group = 1; p.c = scale * 1.4426950408889634f;
   p.nqb = (int)((S + kQB - 1) / kQB); p.hkv = hk; p.ws = nullptr;
-  p.heads_per_seq = heads; p.seq_stride16 = S * row16; p.kv_row_bytes = row16 * 16;
+  p.heads_per_seq = heads; p.seq_stride16 = S * row16; p.kv_row_bytes = row16 * 16; p.cu_seqlens = cu_seqlens;
   p.items = p.nqb; p.n_whole = p.nqb; p.nsplit = 1; p.q_row0 = 0; p.nq = (int)S; p.qb_rows = kQB;
   const char* var = getenv("QP_ATTN_VARIANT");        // 3: plain 2-D grid (A/B of the XCD mapping)
   if (var && atoi(var) == 3) attn_fwd_kernel_s4<false, D, true><<<dim3((unsigned)p.nqb, (unsigned)hk), 256, 0, s>>>(p);

@@ -74,7 +74,7 @@ int qp_launch_prefill_attn(const qp_ctx* ctx, const void* q, const void* k_prefi
                            void* workspace, size_t workspace_bytes, hipStream_t s);
 size_t qp_attn_workspace_bytes_impl(const qp_ctx* ctx, int64_t n, int64_t prefix_len, int hq, int hkv);
 int qp_launch_vit_attn(const qp_ctx* ctx, const void* qkv, int64_t n_seq, int64_t S, int heads, float scale, void* out,
-                       hipStream_t s);
+                       const int* cu_seqlens, hipStream_t s);
 int qp_launch_vit_rope(void* qkv, const float* cos_t, const float* sin_t, int64_t n, int heads, int head_dim, hipStream_t s);
 int qp_launch_quick_gelu(const void* x, void* out, int64_t n_elems, hipStream_t s);
 int qp_launch_add_layernorm(void* x, const void* delta, const void* w, const void* b, void* out, int64_t n, int hidden, float eps,

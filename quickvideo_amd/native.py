@@ -70,6 +70,7 @@ SIGNATURES = {
     "qp_decode_advance": (_i32, [_vp, _vp, _i64, _vp]),
     "qp_vit_rope": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "qp_vit_attn": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _f32, _vp, _vp]),
+    "qp_vit_attn_varlen": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _f32, _vp, _vp]),
     "qp_quick_gelu": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "qp_linear_tune": (_i32, [_vp, _vp, _c.POINTER(_vp), _i32, _vp, _i32, _f32, _vp, _i64, _i64, _i64, _i32, _vp, _sz, _vp]),
     "qp_linear_act": (_i32, [_vp, _vp, _vp, _vp, _i32, _f32, _vp, _i64, _i64, _i64, _i32, _vp, _sz, _vp]),
@@ -294,6 +295,12 @@ class QuickPrefillOps:
 
     def vit_attn(self, qkv, n_seq, seq_len, heads, head_dim, scale, out):
         self._check(self.lib.qp_vit_attn(self.ctx, qkv.data_ptr(), n_seq, seq_len, heads, head_dim, float(scale), out.data_ptr(), self._stream()))
+
+    def vit_attn_varlen(self, qkv, cu_seqlens, max_seq_len, heads, head_dim, scale, out):
+        """Ragged batch (window attention): cu_seqlens int32 [n_seq+1] on the device."""
+        assert cu_seqlens.dtype == torch.int32 and cu_seqlens.is_cuda
+        self._check(self.lib.qp_vit_attn_varlen(self.ctx, qkv.data_ptr(), cu_seqlens.data_ptr(), cu_seqlens.numel() - 1, max_seq_len, heads,
+                                                head_dim, float(scale), out.data_ptr(), self._stream()))
 
     def add_layernorm(self, x, delta, w, b, out, eps):
         n, hidden = x.shape

@@ -284,7 +284,15 @@ class VisionTower:
         n, seq, unit = pixel_rows.shape[0], h * wd, s.spatial_merge_size ** 2
         H, hd, d = s.num_heads, s.head_dim, s.embed_dim
         x = F.linear(pixel_rows.to(w.patch_w.dtype), w.patch_w)
-        win, lens = self.window_index(grid_thw, s.spatial_merge_size, s.window_size, s.patch_size, x.device)
+        # the window permutation depends only on the grid: built once per (grid, device) — it is host work + an H2D copy
+        wk = (tuple(grid_thw), str(x.device))
+        cache = self.__dict__.setdefault("_win_cache", {})
+        if wk not in cache:
+            win_, lens_ = self.window_index(grid_thw, s.spatial_merge_size, s.window_size, s.patch_size, x.device)
+            cu_ = torch.zeros(lens_.numel() + 1, dtype=torch.int32, device=x.device)
+            cu_[1:] = torch.cumsum(lens_, 0).to(torch.int32)
+            cache[wk] = (win_, lens_, cu_, int(lens_.max()), torch.argsort(win_))
+        win, lens, cu_win, lmax_win, win_inv = cache[wk]
         x = x.reshape(n // unit, unit, d)[win].reshape(n, d)                             # window-major token order
         pos = vision_pos_ids(grid_thw, s.spatial_merge_size, x.device)
         rd = hd // 2
@@ -327,9 +335,13 @@ class VisionTower:
             full = li in s.fullatt_blocks
             if ops is not None:
                 ops.vit_rope(qkv, cos_h, sin_h, H, hd)
+            varlen = ops is not None and hasattr(ops, "vit_attn_varlen") and os.environ.get("QP_VIT_WINDOW_HIP", "1") == "1"
             if ops is not None and full:
                 a = torch.empty(n, H * hd, dtype=x.dtype, device=x.device)
                 ops.vit_attn(qkv, t, seq, H, hd, hd ** -0.5, a)
+            elif varlen:                                                               # 28 of 32 blocks: ragged windows, same MFMA kernel
+                a = torch.empty(n, H * hd, dtype=x.dtype, device=x.device)
+                ops.vit_attn_varlen(qkv, cu_win, lmax_win, H, hd, hd ** -0.5, a)
             else:
                 q3 = qkv.view(n, 3, H, hd)
                 q, k, v = q3[:, 0], q3[:, 1], q3[:, 2]
@@ -352,4 +364,4 @@ class VisionTower:
             pend = F.linear(y, b.down_w, b.down_b)
         y = rms(w.ln_q_w).view(-1, d * unit)
         y = F.linear(F.gelu(F.linear(y, w.m1_w, w.m1_b)), w.m2_w, w.m2_b)
-        return y[torch.argsort(win)]                                                   # back to raster (t, h/2, w/2) order
+        return y[win_inv]                                                              # back to raster (t, h/2, w/2) order

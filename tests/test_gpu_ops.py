@@ -739,3 +739,53 @@ def test_query_scores_vs_reference_golden(ops, golden_dir):
             want = data[f"c{ci}_{mode}"]
             assert len(set(ii.tolist()) & set(want.tolist())) / k >= 0.98, (ci, mode)
             assert torch.equal(kc.cpu(), kk[0, :, :n][:, torch.from_numpy(ii.astype(np.int64))])
+
+
+@pytest.mark.parametrize("name", ["qwen2", "qwen25"])
+def test_hip_towers_vs_hf_fixture(ops, golden_dir, name, monkeypatch):
+    """f1 pinned to the installed transformers towers (GV10), not to the product's own torch tower: 3 blocks at width 1280 / head_dim
+    80, bf16 on the GPU through qp_vit_rope / qp_vit_attn / qp_vit_attn_varlen (Qwen2.5: ragged 64- and 32-patch windows) /
+    qp_add_layernorm|qp_add_rmsnorm / the fused fc1+GELU GEMM, vs the fp32 HF output on the same bf16 weights.
+    Tolerance: 2.5 % of the output range (bf16 activations through 3 blocks + merger)."""
+    from quickvideo_amd.vit import VisionSpec, VisionTower, VisionWeights
+    meta = json.load(open(os.path.join(golden_dir, "gv10_vit_towers.json")))[name]
+    ref = torch.from_numpy(np.load(os.path.join(golden_dir, "gv10_vit_towers.npz"))[f"{name}_out"])
+    kw = dict(meta["spec"]); kw["fullatt_blocks"] = tuple(kw.get("fullatt_blocks", ()))
+    spec = VisionSpec(arch=meta["arch"], **{k: v for k, v in kw.items() if k != "fullatt_blocks" or meta["arch"] == "qwen2.5"})
+    sd = O.hashed_state_dict([(n, tuple(s)) for n, s in meta["names_shapes"]], meta["weight_seed"], device="cuda")
+    w = VisionWeights.from_named(spec, sd, "cuda:0")
+    t, h, wd = meta["grid"]
+    pix = O.hashed_normal((t * h * wd, 1176), meta["pixel_seed"], 1.0, device="cuda")
+    tower = VisionTower(w, ops=ops)
+    assert tower.ops is not None                                  # the HIP path, not the torch fallback
+    got = tower.forward(pix, tuple(meta["grid"])).float().cpu()
+    torch.cuda.synchronize()
+    assert got.shape == ref.shape and torch.isfinite(got).all()
+    err = (got - ref).abs().max().item()
+    assert err <= 2.5e-2 * meta["out_absmax"], (err, meta["out_absmax"])
+    if name == "qwen25":                                          # the window layers really went through the HIP kernel: same result
+        monkeypatch.setenv("QP_VIT_WINDOW_HIP", "0")              # as the padded-SDPA form up to bf16 rounding, but not bit-identical
+        alt = VisionTower(w, ops=ops).forward(pix, tuple(meta["grid"])).float().cpu()
+        assert (alt - ref).abs().max().item() <= 2.5e-2 * meta["out_absmax"]
+        assert not torch.equal(alt, got)
+
+
+def test_vit_attn_varlen_vs_torch(ops):
+    """qp_vit_attn_varlen on a ragged batch (lengths 1..200, incl. lengths that are not multiples of the 64-key tile) vs fp32 softmax."""
+    rs = np.random.RandomState(4)
+    H, hd = 16, 80
+    lens = [64, 32, 1, 200, 63, 65, 128, 17, 64, 64]
+    n = sum(lens)
+    qkv = torch.from_numpy(rs.standard_normal((n, 3, H, hd)).astype(np.float32)).to(torch.bfloat16).cuda()
+    cu = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int32, device="cuda")
+    out = torch.full((n, H * hd), float("nan"), dtype=torch.bfloat16, device="cuda")
+    ops.vit_attn_varlen(qkv, cu, max(lens), H, hd, hd ** -0.5, out)
+    torch.cuda.synchronize()
+    st = 0
+    for L in lens:
+        q, k, v = (qkv[st:st + L, i].float().transpose(0, 1) for i in range(3))       # [H, L, hd]
+        ref = torch.softmax(q @ k.transpose(1, 2) * hd ** -0.5, -1) @ v
+        got = out[st:st + L].float().view(L, H, hd).transpose(0, 1)
+        assert torch.isfinite(got).all()
+        assert ((got - ref).abs() <= 1.5e-2 + 1.5e-2 * ref.abs()).all(), (L, (got - ref).abs().max().item())
+        st += L

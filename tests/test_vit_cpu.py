@@ -81,3 +81,22 @@ def test_qwen25_tower_matches_hf(grid):
     got = VisionTower(w).forward(pix, grid)
     assert got.shape == ref.shape
     assert torch.allclose(got, ref, atol=3e-5, rtol=1e-4), (got - ref).abs().max()
+
+
+@pytest.mark.parametrize("name", ["qwen2", "qwen25"])
+def test_towers_match_hf_fixture_at_real_width(name, golden_dir):
+    """GV10 (made by oracle/make_golden.py from the installed transformers towers at width 1280 / head_dim 80): the product's torch
+    tower on the CPU in fp32 from the same hash-generated bf16 weights.  The GPU test pins the HIP tower to the same file."""
+    import json, os
+    from oracle import qp_oracle as O
+    meta = json.load(open(os.path.join(golden_dir, "gv10_vit_towers.json")))[name]
+    ref = np.load(os.path.join(golden_dir, "gv10_vit_towers.npz"))[f"{name}_out"]
+    kw = dict(meta["spec"]); kw["fullatt_blocks"] = tuple(kw.get("fullatt_blocks", ()))
+    spec = VisionSpec(arch=meta["arch"], **{k: v for k, v in kw.items() if k != "fullatt_blocks" or meta["arch"] == "qwen2.5"})
+    sd = O.hashed_state_dict([(n, tuple(s)) for n, s in meta["names_shapes"]], meta["weight_seed"])
+    w = VisionWeights.from_named(spec, {k: v.float() for k, v in sd.items()}, "cpu", dtype=torch.float32)
+    t, h, wd = meta["grid"]
+    pix = O.hashed_normal((t * h * wd, 1176), meta["pixel_seed"], 1.0).float()
+    got = VisionTower(w).forward(pix, tuple(meta["grid"])).numpy()
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() <= 2e-3 * meta["out_absmax"], np.abs(got - ref).max()
