@@ -51,6 +51,12 @@ const char* qp_last_error(void);
 const char* qp_version(void);
 int qp_device_cus(const qp_ctx* ctx);
 
+/* Host helper of the overlap producer (no device work): memcpy `bytes` from src to dst (e.g. decoded uint8 frames into a pinned
+ * ring slot), split over up to `threads` std::threads.  Callable with the GIL released (ctypes / cgo drop it around foreign
+ * calls) and independent of torch's process-wide intra-op thread setting; the reference's producer thread fills its queue with
+ * `.float()` + the HF processor under the GIL (qwen25_lvu_interleaved.py:303-340). */
+int qp_host_memcpy(void* dst, const void* src, size_t bytes, int threads);
+
 /* ---- seam 2: M-RoPE + KV append  (qwen25_lvu.py:46-58) -------------------------------------- */
 /* cos/sin tables for one group: pos int64 [3][n] (temporal, height, width streams of get_rope_index,
  * qwen25_lvu.py:613-619, 689); sections = mrope_section (e.g. {16,24,24}, sum = head_dim/2);

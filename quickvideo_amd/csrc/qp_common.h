@@ -41,6 +41,20 @@ __device__ __forceinline__ float round_bf16(float f) { return bf16_bits_to_f32(f
 // rounded once to fp32 is exact because sqrt of an fp32 value is never within 2^-48 of an fp32 rounding boundary.
 __device__ __forceinline__ float sqrt_rn_f32(float s) { return (float)sqrt((double)s); }
 
+// Kernels that need more than 64 KB of dynamic LDS opt in with hipFuncSetAttribute — per DEVICE (the attribute lives in the
+// per-device function object), so the guard is a bit per device ordinal, not one flag per process.
+#include <atomic>
+static inline int qp_opt_in_lds(std::atomic<unsigned long long>& done, const void* fn, int bytes, const char* what) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  const unsigned long long bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_relaxed) & bit) return 0;
+  hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return qp_fail(QP_ERR_HIP, "hipFuncSetAttribute(%s): %s", what, hipGetErrorString(e));
+  done.fetch_or(bit, std::memory_order_relaxed);
+  return 0;
+}
+
 // kernel launchers (one per .hip file)
 int qp_launch_mrope_table(const int64_t* pos, int64_t n, const int32_t* sections, float theta, int head_dim, void* cos_out,
                           void* sin_out, hipStream_t s);

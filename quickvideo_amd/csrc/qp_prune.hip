@@ -398,12 +398,8 @@ int qp_launch_prune_fused(const float* head_sumsq, int n_heads, int64_t n, int64
                           int32_t* kept, uint16_t* norm_bits, int cus, int largest, hipStream_t s) {
   const size_t smem = prune_fused_smem(n, k);
   if (smem > 150 * 1024) return 1;             // caller falls back to select + gather
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)prune_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-    if (e != hipSuccess) return qp_fail(QP_ERR_HIP, "hipFuncSetAttribute(prune_fused): %s", hipGetErrorString(e));
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> lds_ok{0};
+  if (int rc = qp_opt_in_lds(lds_ok, (const void*)prune_fused_kernel, 160 * 1024 - 64, "prune_fused")) return rc;
   int64_t rows = 2 * (int64_t)hkv * k;
   int grid = (int)((rows + 255) / 256);          // >= 256 rows (64 KB) per workgroup
   if (grid > cus) grid = cus;
@@ -424,12 +420,8 @@ int qp_launch_select(const float* head_sumsq, int n_heads, int64_t n, int64_t k,
     return qp_check_launch("select(global keys)");
   }
   size_t smem = select_smem_bytes(n);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)select_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-    if (e != hipSuccess) return qp_fail(QP_ERR_HIP, "hipFuncSetAttribute(select): %s", hipGetErrorString(e));
-    attr_set = true;
-  }
+  static std::atomic<unsigned long long> lds_ok{0};
+  if (int rc = qp_opt_in_lds(lds_ok, (const void*)select_kernel<true>, 160 * 1024 - 64, "select")) return rc;
   select_kernel<true><<<1, 1024, smem, s>>>(head_sumsq, n_heads, (int)n, (int)k, kept, norm_bits, nullptr, largest);
   return qp_check_launch("select");
 }

@@ -85,13 +85,10 @@ __global__ __launch_bounds__(256) void qscore_reduce_kernel(const uint16_t* __re
 
 int qp_launch_query_scores(const void* q_prompt, const void* k_group, int64_t k_head_stride, int64_t n, int64_t m, int hq, int hkv,
                            const float* value_sumsq, uint16_t* keys_out, uint16_t* scores_out, void* workspace, hipStream_t s) {
-  static bool attr_set = false;
+  static std::atomic<unsigned long long> lds_ok{0};
   const size_t smem = (size_t)n * 4;
-  if (smem > 48 * 1024 && !attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)qscore_prob_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-    if (e != hipSuccess) return qp_fail(QP_ERR_HIP, "hipFuncSetAttribute(qscore_prob): %s", hipGetErrorString(e));
-    attr_set = true;
-  }
+  if (smem > 48 * 1024)
+    if (int rc = qp_opt_in_lds(lds_ok, (const void*)qscore_prob_kernel, 160 * 1024 - 256, "qscore_prob")) return rc;
   qscore_prob_kernel<<<dim3((unsigned)m, (unsigned)hq), 256, smem, s>>>((const uint4*)q_prompt, (const uint4*)k_group, k_head_stride / 8,
                                                                         (int)n, (int)m, hq, hkv, sqrtf(128.0f), (uint16_t*)workspace);
   int rc = qp_check_launch("qscore_prob");

@@ -116,6 +116,14 @@ class ArrayVideoReader(VideoReaderBase):
 def open_video(path, num_threads: Optional[int] = None, num_intervals: Optional[int] = None) -> VideoReaderBase:
     if isinstance(path, VideoReaderBase):
         return path
+    # any object with the InterleavedVideoReader contract (deepcodec [3P], qwen25_lvu_interleaved.py:385-410, 438-442, 513-515) is a
+    # reader: len(), get_fps(), process(idx), __next__ -> uint8 [g,3,H,W], settable height / width / interpolation / frame_iter
+    if not isinstance(path, (str, bytes, os.PathLike)):
+        missing = [m for m in ("__len__", "__next__", "get_fps", "process") if not callable(getattr(path, m, None))]
+        if missing:
+            raise TypeError(f"video reader object lacks {missing}: the contract is len(), get_fps(), process(idx), next() -> uint8 [g,3,H,W] "
+                            f"and settable height / width / interpolation / frame_iter")
+        return path
     nt = num_threads if num_threads is not None else int(os.environ.get("QUICKCODEC_CORES", "8"))
     ni = num_intervals if num_intervals is not None else int(os.environ.get("QUICKCODEC_INTERVALS", "64"))
     p = str(path)

@@ -47,9 +47,20 @@ def _load_hf_dir(path: str, device) -> QwenVLNative:
                     video_token_id=cfg.get("video_token_id", 151656), vision_start_token_id=cfg.get("vision_start_token_id", 151652),
                     vision_end_token_id=cfg.get("vision_end_token_id", 151653))
     vc = cfg["vision_config"]
-    vspec = VisionSpec(depth=vc["depth"], embed_dim=vc["embed_dim"], num_heads=vc["num_heads"], mlp_ratio=vc.get("mlp_ratio", 4),
-                       patch_size=vc.get("patch_size", 14), temporal_patch_size=vc.get("temporal_patch_size", 2),
-                       spatial_merge_size=vc.get("spatial_merge_size", 2), out_hidden=vc.get("hidden_size", spec.hidden))
+    if "embed_dim" in vc:                                     # Qwen2-VL tower
+        vspec = VisionSpec(depth=vc["depth"], embed_dim=vc["embed_dim"], num_heads=vc["num_heads"], mlp_ratio=vc.get("mlp_ratio", 4),
+                           patch_size=vc.get("patch_size", 14), temporal_patch_size=vc.get("temporal_patch_size", 2),
+                           spatial_merge_size=vc.get("spatial_merge_size", 2), out_hidden=vc.get("hidden_size", spec.hidden))
+    else:                                                     # Qwen2.5-VL tower (the reference's family, lvu.py:60): hidden_size is the ViT width
+        vspec = VisionSpec(arch="qwen2.5", depth=vc["depth"], embed_dim=vc["hidden_size"], num_heads=vc["num_heads"],
+                           patch_size=vc.get("patch_size", 14), temporal_patch_size=vc.get("temporal_patch_size", 2),
+                           spatial_merge_size=vc.get("spatial_merge_size", 2), out_hidden=vc.get("out_hidden_size", spec.hidden),
+                           intermediate=vc["intermediate_size"], window_size=vc.get("window_size", 112),
+                           fullatt_blocks=tuple(vc.get("fullatt_block_indexes", (7, 15, 23, 31))))
+        # temporal M-RoPE ids advance by second_per_grid_t * tokens_per_second per temporal patch (get_rope_index [3P]); the
+        # pipeline derives second_per_grid_t from the sampled fps; -1 = "per video" marker resolved in PrefillPipeline.plan
+        from dataclasses import replace
+        spec = replace(spec, temporal_scale=-float(vc.get("tokens_per_second", 2)))
     sd = {}
     for f in sorted(os.listdir(path)):
         if f.endswith(".safetensors"):

@@ -3,8 +3,6 @@ lvu/models/qwen25_lvu_interleaved.py behind the same init/run/chat triple."""
 from ..lvu_config import LVUConfig
 from ..pipeline import PrefillPipeline, QwenVLNative
 
-OVERLAP = True
-
 
 def init_lvu_model(model: QwenVLNative, config: LVUConfig):
     """Reference: rebinding every decoder layer's forward (qwen25_lvu.py:467-502).  Here the model object already is
@@ -30,14 +28,23 @@ def _content_question(messages):
     return video, question
 
 
-def chat_lvu_model(self, messages, **generation_kwargs):
+def chat_lvu_model(self, messages, _overlap: bool = True, **generation_kwargs):
+    """`_overlap` is how the sequential plugin (qwen2vl_mi355x_sequential) reuses this function: an argument, not a module global,
+    so two LVU objects of different plugins can generate concurrently."""
     video, question = _content_question(messages)
     pipe = getattr(self, "_pipeline", None)
     if pipe is None or pipe.cfg is not self.config or pipe.model is not self.model:
         pipe = PrefillPipeline(self.model, self.config, self.processor, ops=getattr(self, "_ops", None))
         self._pipeline = pipe
     mnt = generation_kwargs.pop("max_new_tokens", 16)
-    ids = pipe.generate(question, video, max_new_tokens=mnt, overlap=OVERLAP, **generation_kwargs)
+    if "eos_token_id" not in generation_kwargs:              # HF generate stops at the generation config's EOS (qwen25_lvu.py:740)
+        eos = getattr(self.processor, "eos_token_id", None)
+        if eos is None:
+            eos = getattr(getattr(self.processor, "tokenizer", None), "eos_token_id", None)
+        if eos is None:
+            eos = getattr(self.processor, "im_end", None)   # Qwen2-VL chat models end a turn with <|im_end|>
+        generation_kwargs["eos_token_id"] = eos
+    ids = pipe.generate(question, video, max_new_tokens=mnt, overlap=_overlap, **generation_kwargs)
     t = pipe.last_timings
     # the reference prints these six lines (qwen25_lvu.py:748-753); ours are device-synchronised
     print(f"total time spent fetching frames was: {t.fetch}")

@@ -6,12 +6,7 @@ init_lvu_model = _m.init_lvu_model
 
 
 def chat_lvu_model(self, messages, **generation_kwargs):
-    old = _m.OVERLAP
-    _m.OVERLAP = False
-    try:
-        return _m.chat_lvu_model(self, messages, **generation_kwargs)
-    finally:
-        _m.OVERLAP = old
+    return _m.chat_lvu_model(self, messages, _overlap=False, **generation_kwargs)
 
 
 def run_lvu_model(self, question, video_path, **generation_kwargs):

@@ -38,6 +38,7 @@ SIGNATURES = {
     "qp_last_error": (_c.c_char_p, []),
     "qp_version": (_c.c_char_p, []),
     "qp_device_cus": (_i32, [_vp]),
+    "qp_host_memcpy": (_i32, [_vp, _vp, _sz, _i32]),
     "qp_mrope_table": (_i32, [_vp, _vp, _i64, _c.POINTER(_c.c_int32), _f32, _i32, _vp, _vp, _vp]),
     "qp_rope_append": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _vp, _vp]),
     "qp_rope_append_keys": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
@@ -89,6 +90,22 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
         fn = getattr(lib, name)            # AttributeError if the .so does not export a declared symbol
         fn.restype, fn.argtypes = res, args
     return lib
+
+
+_HOST_LIB = None
+
+
+def host_memcpy(dst: torch.Tensor, src: torch.Tensor, threads: int = 4):
+    """dst[...] = src[...] for contiguous CPU tensors of equal byte size, through qp_host_memcpy: native and GIL-free (needs only
+    the shared library, no GPU)."""
+    global _HOST_LIB
+    if _HOST_LIB is None:
+        _HOST_LIB = load_library()
+    nbytes = src.numel() * src.element_size()
+    assert dst.is_contiguous() and src.is_contiguous() and dst.numel() * dst.element_size() == nbytes and not dst.is_cuda and not src.is_cuda
+    rc = _HOST_LIB.qp_host_memcpy(dst.data_ptr(), src.data_ptr(), nbytes, threads)
+    if rc != QP_OK:
+        raise QuickPrefillError(rc, _HOST_LIB.qp_last_error().decode())
 
 
 def _ptr(t: Optional[torch.Tensor]):

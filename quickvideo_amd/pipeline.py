@@ -22,6 +22,7 @@ from . import planner
 from .engine import QuickPrefillEngine
 from .decode import GraphDecoder
 from .frames import open_video, smart_nframes
+from .native import host_memcpy
 from .lvu_config import LVUConfig, effective_k
 from .spec import TextSpec
 from .vit import VisionTower, VisionWeights, patchify_frames
@@ -97,7 +98,9 @@ class _Producer(threading.Thread):
                     # consumer hands that event back through release() and the copy stream waits on it.
                     if self.h2d_done[slot] is not None:
                         self.h2d_done[slot].synchronize()
-                    host[: frames.shape[0]].copy_(frames)           # torch releases the GIL inside copy_ (measured: tests/test_api_cpu.py)
+                    # native, GIL-free fill of the pinned slot (qp_host_memcpy through ctypes; 2-10x faster than Tensor.copy_ here,
+                    # whose speed follows torch's process-wide intra-op thread count): the launching thread is never starved
+                    host_memcpy(host[: frames.shape[0]], frames.contiguous())
                     with torch.cuda.stream(self.copy_stream):
                         if self.read_done[slot] is not None:
                             self.copy_stream.wait_event(self.read_done[slot])
@@ -163,8 +166,12 @@ class PrefillPipeline:
         T = len(prompt.prefix_ids) + n_video + len(prompt.tail_ids)
         gs = cfg.video_group_size
         plan = planner.plan_groups(nframes, gs, gh, gw, len(prompt.prefix_ids), T, vs.temporal_patch_size, vs.spatial_merge_size)
+        tscale = spec.temporal_scale
+        if tscale < 0:          # Qwen2.5-VL checkpoint: tokens_per_second * second_per_grid_t, second_per_grid_t = temporal_patch / sampled fps
+            sample_fps = nframes / max(total / vfps, 1e-9)         # qwen-vl-utils: video_sample_fps = nframes / total_frames * video_fps
+            tscale = -tscale * vs.temporal_patch_size / sample_fps
         pos, delta = planner.mrope_positions(len(prompt.prefix_ids), (nframes // vs.temporal_patch_size, gh, gw), len(prompt.tail_ids),
-                                             vs.spatial_merge_size, spec.temporal_scale)
+                                             vs.spatial_merge_size, tscale)
         return dict(nframes=nframes, H=H, W=W, idx=idx, prompt=prompt, plan=plan, pos=pos, delta=delta, T=T, gh=gh, gw=gw)
 
     def _engine(self, plan, T, max_new_tokens: int = 0) -> QuickPrefillEngine:

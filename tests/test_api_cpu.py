@@ -426,3 +426,122 @@ def test_layer_pipeline_of_group_token_parallel_stages_gloo():
     assert np.array_equal(ret["logits2"], ret["logits3"])                        # both sp ranks of the last stage agree exactly
     assert np.max(np.abs(ret["logits2"] - ret["ref_logits"])) <= 4e-2
     assert ret["len0"] + ret["len2"] == ret["ref_len"] and ret["len1"] == ret["len0"] and ret["len3"] == ret["len2"]
+
+
+def test_duck_typed_reader_and_eos_default():
+    """A third-party reader with the InterleavedVideoReader contract (no VideoReaderBase inheritance) is accepted; an object without
+    it is refused with a TypeError naming the contract; chat() stops at the processor's end-of-turn token by default."""
+    import lvu
+    from quickvideo_amd.frames import open_video
+    from quickvideo_amd.lvu import load_native_model
+
+    class ThirdPartyReader:                       # the five members, nothing else
+        height = width = None
+        interpolation = "LANCZOS"
+        frame_iter = 4
+
+        def __init__(self, n=40, h=56, w=84):
+            self.n, self.src_h, self.src_w, self._idx, self._cur = n, h, w, None, 0
+
+        def __len__(self): return self.n
+        def get_fps(self): return 2.0
+        def process(self, idx): self._idx, self._cur = list(idx), 0
+
+        def __next__(self):
+            if self._cur >= len(self._idx):
+                raise StopIteration
+            sel = self._idx[self._cur:self._cur + self.frame_iter]
+            self._cur += len(sel)
+            rs = np.random.RandomState(7)
+            return torch.from_numpy(np.stack([rs.randint(0, 256, (3, self.height, self.width), dtype=np.uint8) for _ in sel]))
+
+    r = ThirdPartyReader()
+    assert open_video(r) is r
+    with pytest.raises(TypeError):
+        open_video(object())
+    m = load_native_model("synthetic:tiny", device="cpu")
+    obj = lvu.LVU(lvu.LVUConfig("synthetic:tiny", top_p=0.5, video_group_size=4, num_frames=8), model=m)
+    obj._ops = OracleOps()
+    out = obj.generate("What happens?", ThirdPartyReader(), max_new_tokens=3)
+    assert len(out) == 1 and 1 <= out[0].count("<tok_") <= 3
+    # EOS default: make the first generated token the end-of-turn token -> decoding stops after it
+    first = int(out[0].split("<tok_")[1].split(">")[0])
+    obj.processor.im_end = first
+    out2 = obj.generate("What happens?", ThirdPartyReader(), max_new_tokens=3)
+    assert out2[0].count("<tok_") == 1
+    assert obj.generate("What happens?", ThirdPartyReader(), max_new_tokens=3, eos_token_id=None)[0].count("<tok_") == 3
+
+
+def test_load_qwen25_vl_checkpoint_directory(tmp_path):
+    """A Qwen2.5-VL checkpoint directory (the reference's model family, lvu.py:60): vision_config carries hidden_size /
+    out_hidden_size / intermediate_size / fullatt_block_indexes instead of embed_dim; the temporal M-RoPE scale follows the sampled
+    fps (tokens_per_second * temporal_patch_size / fps) instead of a hard-coded 2.0."""
+    import json
+    from safetensors.torch import save_file
+    from transformers.models.qwen2_5_vl.configuration_qwen2_5_vl import Qwen2_5_VLConfig
+    from transformers.models.qwen2_5_vl.modeling_qwen2_5_vl import Qwen2_5_VLForConditionalGeneration
+    from quickvideo_amd.frames import open_video
+    from quickvideo_amd.lvu import load_native_model
+    from quickvideo_amd.pipeline import PrefillPipeline
+    from quickvideo_amd.processor import SyntheticProcessor
+    import lvu
+    cfg = Qwen2_5_VLConfig(
+        text_config=dict(hidden_size=256, num_attention_heads=2, num_key_value_heads=1, intermediate_size=512, num_hidden_layers=2,
+                         vocab_size=320, rms_norm_eps=1e-6, tie_word_embeddings=False,
+                         rope_parameters=dict(rope_type="default", mrope_section=[16, 24, 24], rope_theta=1_000_000.0)),
+        vision_config=dict(depth=2, hidden_size=64, intermediate_size=80, num_heads=4, out_hidden_size=256, window_size=112,
+                           fullatt_block_indexes=[1], patch_size=14, spatial_merge_size=2, temporal_patch_size=2, tokens_per_second=2),
+        video_token_id=300, vision_start_token_id=301, vision_end_token_id=302)
+    torch.manual_seed(0)
+    hf = Qwen2_5_VLForConditionalGeneration(cfg).eval()
+    save_file({k: v.contiguous() for k, v in hf.state_dict().items()}, str(tmp_path / "model.safetensors"))
+    d = cfg.to_dict()
+    d["text_config"]["rope_scaling"] = {"mrope_section": [16, 24, 24]}
+    d["text_config"]["rope_theta"] = 1_000_000.0
+    json.dump(d, open(tmp_path / "config.json", "w"), default=str)
+    m = load_native_model(str(tmp_path), device="cpu")
+    vs = m.vision.spec
+    assert (vs.arch, vs.depth, vs.embed_dim, vs.intermediate, vs.out_hidden, vs.fullatt_blocks) == ("qwen2.5", 2, 64, 80, 256, (1,))
+    assert m.spec.temporal_scale == -2.0                                # "derive from the sampled fps" marker
+    pipe = PrefillPipeline(m, lvu.LVUConfig("x", top_p=0.5, video_group_size=4, num_frames=8), SyntheticProcessor(m.spec), ops=OracleOps())
+    # 40 frames at 2 fps = 20 s, 8 frames sampled -> 0.4 fps -> second_per_grid = 2 / 0.4 = 5 s -> 10 temporal ids per grid step
+    P = pipe.plan(open_video("synthetic://?frames=40&h=56&w=84&fps=2"), "q")
+    t_ids = P["pos"][0, len(P["prompt"].prefix_ids):len(P["prompt"].prefix_ids) + (P["nframes"] // 2) * (P["gh"] // 2) * (P["gw"] // 2)]
+    per_grid = (P["gh"] // 2) * (P["gw"] // 2)
+    assert int(t_ids[per_grid] - t_ids[0]) == 10
+
+
+def test_producer_ring_fill_is_native_and_gil_free():
+    """SURVEY 8b threading row: the producer's copy into the pinned ring must not starve the thread that launches the kernels.
+    qp_host_memcpy through ctypes (the GIL is dropped around the foreign call): correct for odd sizes, and the main thread keeps
+    its Python iteration rate while a second thread copies 50 MB blocks back to back."""
+    import threading
+    import time
+    from quickvideo_amd.native import host_memcpy
+    a = torch.randint(0, 255, (8, 3, 1080, 1920), dtype=torch.uint8)
+    b = torch.empty_like(a)
+    host_memcpy(b, a)
+    assert torch.equal(a, b)
+    c, d = torch.empty(5, dtype=torch.uint8), torch.arange(5, dtype=torch.uint8)
+    host_memcpy(c, d, 8)
+    assert torch.equal(c, d)
+
+    def rate(worker, dur=0.5):
+        stop = [False]
+
+        def loop():
+            while not stop[0] and worker is not None:
+                worker()
+        th = threading.Thread(target=loop)
+        th.start()
+        time.sleep(0.05)
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < dur:
+            n += 1
+        stop[0] = True
+        th.join()
+        return n
+
+    alone = rate(None)
+    native = rate(lambda: host_memcpy(b, a, 2))
+    assert native > 0.3 * alone, (native, alone)        # a GIL-holding 10 ms copy loop would leave ~1/3 or less (5 ms switch interval)

@@ -789,3 +789,36 @@ def test_vit_attn_varlen_vs_torch(ops):
         assert torch.isfinite(got).all()
         assert ((got - ref).abs() <= 1.5e-2 + 1.5e-2 * ref.abs()).all(), (L, (got - ref).abs().max().item())
         st += L
+
+
+# ---------------------------------------------------------------- round 2: the reference-side adapter of INTEGRATION.md §1 runs as written
+@pytest.mark.parametrize("ci", range(len(COMPACT_CASES)))
+def test_reference_adapter_post_process_kv_cache(ops, golden_dir, ci):
+    """ArenaLVUCache.update (in-place append) + post_process_kv_cache with the reference's 8-argument signature (utils.py:197-206)
+    through the C ABI: the cache rows after the call hash to the REFERENCE's own output (GV2), the hidden-state hand-off too."""
+    from quickvideo_amd.lvu_config import LVUConfig, LVULayerConfig
+    from quickvideo_amd.reference_adapter import ArenaLVUCache, post_process_kv_cache
+    meta = json.load(open(os.path.join(golden_dir, "gv2_compaction.json")))[ci]
+    past, n, k, hkv = COMPACT_CASES[ci]
+    rs = np.random.RandomState(meta["seed"])
+    keys = torch.from_numpy(rs.standard_normal((1, hkv, past + n, D)).astype(np.float32)).to(torch.bfloat16).cuda()
+    vals = torch.from_numpy(rs.standard_normal((1, hkv, past + n, D)).astype(np.float32)).to(torch.bfloat16).cuda()
+    hid = torch.from_numpy(rs.standard_normal((1, n, 16)).astype(np.float32)).cuda()
+    cache = ArenaLVUCache(n_layers=4, n_kv_heads=hkv, capacity=past + n + 9, device="cuda", ops=ops)
+    if past:
+        cache.update(keys[:, :, :past], vals[:, :, :past], 0)
+    k_all, v_all = cache.update(keys[:, :, past:], vals[:, :, past:], 0)                  # what the patched attention forward calls
+    assert k_all.shape == (1, hkv, past + n, D) and torch.equal(k_all, keys)
+    cfg = LVUConfig(model_name_or_path="x", top_k=k, prefill_prune_starting_layer=0)
+    lc = LVULayerConfig(layer_idx=0, total_layers=4, lvu_config=cfg)
+    pos_ids = (torch.arange(n)[None, None].repeat(3, 1, 1) + 7).cuda()
+    cache_pos = (torch.arange(n) + past).cuda()
+    pe = (torch.from_numpy(rs.standard_normal((3, 1, n, 8)).astype(np.float32)).cuda(), torch.from_numpy(rs.standard_normal((3, 1, n, 8)).astype(np.float32)).cuda())
+    h2, am2, pi2, cp2, pe2, c2 = post_process_kv_cache(hid, None, pos_ids, cache_pos, pe, None, cache, lc)
+    torch.cuda.synchronize()
+    assert c2 is cache and cache.get_seq_length(0) == meta["out_len"]
+    ko, vo = cache[0]
+    assert sha(dev_bits(ko[0])) == meta["k_sha"] and sha(dev_bits(vo[0])) == meta["v_sha"]
+    assert list(h2.shape) == meta["hidden_shape"] and sha(h2.cpu().numpy()) == meta["hidden_sha"]
+    assert sha(pi2.cpu().numpy()) == meta["pos_sha"] and sha(cp2.cpu().numpy()) == meta["cache_pos_sha"]
+    assert sha(pe2[0].cpu().numpy(), pe2[1].cpu().numpy()) == meta["pe_sha"]
