@@ -504,6 +504,14 @@ AttnPlan plan_items(int64_t n, int64_t P, int hq, int hkv, int cus, int split_mo
   const double tstep = qb_rows == 256 ? 0.95 : 1.0;              // measured: an 8-wave tile step is ~5 % shorter (half the DMA pieces per wave)
   a.cost = simulate_makespan(n, P, group, nqb, qb_rows, slots, a.items, 1, c0) * tstep;
   if (split_mode == 0) return a;
+  if (const char* fs = getenv("QP_ATTN_FORCE_SPLIT")) {          // experiment: EVERY item cut into ns kv ranges.  With 2 XCDs per kv head and
+    const int ns = atoi(fs);                                       // ns = 2, split s of every item runs on XCD parity s (item index = 2*slot +
+    if (ns >= 2 && ns <= kMaxSplit) {                              // xcd%2), so each XCD streams only half of the K/V rows: HBM reads halve.
+      a.n_whole = 0; a.nsplit = ns;
+      a.cost = (simulate_makespan(n, P, group, nqb, qb_rows, slots, 0, ns, c0) + 3.0) * tstep;
+      return a;
+    }
+  }
   const int64_t tiles_min = (P + kKV - 1) / kKV + 2;              // tiles of the lightest item (q block 0)
   int64_t cap = tiles_min / 4; if (cap < 1) cap = 1;              // keep >= 4 tiles per piece
   if (cap > kMaxSplit) cap = kMaxSplit;
@@ -562,6 +570,7 @@ int qp_launch_prefill_attn(const qp_ctx* ctx, const void* q, const void* k_prefi
   p.nqb = (int)((nq + kQB - 1) / kQB); p.hkv = hkv; p.ws = (float*)workspace;
   p.items = p.nqb * p.group; p.n_whole = p.items; p.nsplit = 1;
   p.heads_per_seq = hkv; p.seq_stride16 = 0; p.kv_row_bytes = 256; p.cu_seqlens = nullptr;
+  { const char* pm = getenv("QP_S6_PRIO"); p.prio_mode = pm ? atoi(pm) : 0; }
   p.q_row0 = (int)q_row0; p.nq = (int)nq; p.qb_rows = kQB;
   const char* var = getenv("QP_ATTN_VARIANT");        // developer A/B switch (tools/bench_attn.py); default = production kernel
   const int variant = var ? atoi(var) : 0;
@@ -630,7 +639,7 @@ int qp_launch_vit_attn(const qp_ctx* ctx, const void* qkv, int64_t n_seq, int64_
   const int hk = (int)(n_seq * heads);
   p.hq = hk; p.group = 1; p.c = scale * 1.4426950408889634f;
   p.nqb = (int)((S + kQB - 1) / kQB); p.hkv = hk; p.ws = nullptr;
-  p.heads_per_seq = heads; p.seq_stride16 = S * row16; p.kv_row_bytes = row16 * 16; p.cu_seqlens = cu_seqlens;
+  p.heads_per_seq = heads; p.seq_stride16 = S * row16; p.kv_row_bytes = row16 * 16; p.cu_seqlens = cu_seqlens; p.prio_mode = 0;
   p.items = p.nqb; p.n_whole = p.nqb; p.nsplit = 1; p.q_row0 = 0; p.nq = (int)S; p.qb_rows = kQB;
   const char* var = getenv("QP_ATTN_VARIANT");        // 3: plain 2-D grid (A/B of the XCD mapping)
   if (var && atoi(var) == 3) attn_fwd_kernel_s4<false, D, true><<<dim3((unsigned)p.nqb, (unsigned)hk), 256, 0, s>>>(p);

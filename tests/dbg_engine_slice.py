@@ -1,6 +1,6 @@
 """Debug: engine vs oracle on odd layer dims, varying one thing at a time (GPU)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from oracle import qp_oracle as O
 from quickvideo_amd import planner

@@ -134,7 +134,7 @@ def test_engine_72b_tp8_rank_slice_vs_oracle():
     spec, spec_o = TextSpec(**dims), O.TextSpec(**dims)
     # std 0.01: at d = 8192 the usual 0.02 gives q.k/sqrt(D) a std of ~3.3, i.e. attention so peaky that ONE token moving across the
     # prune threshold (2 of 240 kept tokens differ between hipBLASLt's and the CPU's K rounding) moves the logits by 0.6
-    # (tools/probe/dbg_slice.py); with 0.01 the same two differences move them by 0.02
+    # (tests/dbg_engine_slice.py); with 0.01 the same two differences move them by 0.02
     w = O.hashed_text_weights(spec_o, seed=21, device="cuda", norm_jitter=0.05, std=0.01)
     frames, gh, gw, gs, prefix, tail = 16, 16, 30, 8, 15, 24       # 8 frame pairs x 120 tokens -> 2 groups of 480
     T = prefix + (frames // 2) * (gh // 2) * (gw // 2) + tail
@@ -173,6 +173,60 @@ def test_engine_query_based_vs_oracle(pt):
             assert len(g) == len(want) and np.all(np.diff(g) > 0)
             tot += len(want); same += len(set(g.tolist()) & set(want.tolist()))
     assert same / tot >= 0.9, same / tot
+
+
+def test_engine_cfg3_shape_two_layers_vs_oracle():
+    """BASELINE.json configs[2] as a whole-engine run at the real layer width: groups of 2880 tokens (32 frames of 280x504), rho = 0.25
+    (k = 720), three groups + tail through two 7B-dim layers vs the oracle: cache lengths exact, logits within tolerance, kept sets."""
+    dims = dict(hidden=3584, n_heads=28, n_kv_heads=4, head_dim=128, intermediate=18944, n_layers=2, vocab=2048)
+    spec, spec_o = TextSpec(**dims), O.TextSpec(**dims)
+    w = O.hashed_text_weights(spec_o, seed=31, device="cuda", norm_jitter=0.05)
+    frames, gh, gw, gs, prefix, tail = 96, 20, 36, 32, 15, 30         # 280x504 -> 20x36 patches -> 180 tokens per frame pair; 3 groups
+    T = prefix + (frames // 2) * (gh // 2) * (gw // 2) + tail
+    plan = planner.plan_groups(frames, gs, gh, gw, prefix, T)
+    assert plan.tokens == [2895, 2880, 2880]
+    pos, _ = planner.mrope_positions(prefix, (frames // 2, gh, gw), tail)
+    embeds = O.hashed_normal((T, spec.hidden), 32, 0.5)
+    eng, logits = run_gpu(spec, w, plan, pos, embeds, LVUConfig("x", top_p=0.25, video_group_size=gs))
+    ref = O.group_prefill({k: v.cpu() for k, v in w.items()}, spec_o, embeds, pos, plan.tokens, O.PruneCfg(top_p=0.25))
+    assert eng.arena.len == ref["cache_len"] == [723 + 720 + 720 + 30] * 2
+    check_logits(logits.numpy(), ref["logits"].numpy())
+    flat = [k for g in ref["kept"] for k in g]
+    tot = same = 0
+    for (l, got), want in zip(eng.kept_trace, flat):
+        if want is not None:
+            tot += len(want); same += len(set(got.cpu().numpy().tolist()) & set(want.tolist()))
+    assert same / tot >= 0.97, same / tot
+
+
+def test_pipeline_ring_reuse_under_a_slow_main_stream():
+    """Many groups through the overlapped pipeline while the main stream is artificially slow (a spin kernel in front of every group's
+    prefill), so the producer and the ViT stream run as far ahead as the 3-slot ring lets them: without the explicit slot / cross-stream
+    ordering (read-done events handed back to the producer, record_stream on the ViT output) a slot or a feature block would be
+    recycled before the main stream has read it.  The tokens must equal the everything-fetched-first run."""
+    import lvu
+    from quickvideo_amd.engine import QuickPrefillEngine as E
+    from quickvideo_amd.lvu import load_native_model
+    from quickvideo_amd.pipeline import PrefillPipeline
+    from quickvideo_amd.processor import SyntheticProcessor
+    m = load_native_model("synthetic:tiny", device="cuda:0", seed=5)
+    cfg = lvu.LVUConfig("synthetic:tiny", top_p=0.5, video_group_size=4, num_frames=96)           # 24 groups
+    video = "synthetic://?frames=400&h=112&w=168&seed=9"
+    pipe = PrefillPipeline(m, cfg, SyntheticProcessor(m.spec))
+    ref = pipe.generate("What is shown?", video, max_new_tokens=4, overlap=False)
+    orig = E.prefill_group
+
+    def slow(self, *a, **kw):
+        torch.cuda._sleep(40_000_000)                                  # ~20 ms of GPU spin on the main stream
+        return orig(self, *a, **kw)
+    E.prefill_group = slow
+    try:
+        for _ in range(2):
+            got = pipe.generate("What is shown?", video, max_new_tokens=4, overlap=True)
+            assert got == ref
+    finally:
+        E.prefill_group = orig
+    assert pipe.last_timings.groups == 24
 
 
 def test_no_gpu_fallback_is_loud():

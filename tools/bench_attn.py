@@ -14,6 +14,8 @@ if os.environ.get("QP_SHAPES") == "one":
     shapes = shapes[2:3]
 if os.environ.get("QP_SHAPES") == "long":
     shapes = shapes[3:4]
+if os.environ.get("QP_SHAPES") == "cfg4":           # steady state of the 1-hour video (group 228 of 450)
+    shapes = [(2240, 255367, 28, 4)]
 if os.environ.get("QP_SHAPES") == "sweep":          # 4- vs 8-wave workgroup crossover
     shapes = [(n, P, 28, 4) for n in (2240, 5760) for P in (16000, 32000, 64000)]
 
