@@ -231,7 +231,7 @@ def build_workload(name, device, rank, world, seed=0, parallel="single", layout=
     n_video = (frames // 2) * (gh // 2) * (gw // 2)
     T = prefix + n_video + tail
     plan = planner.plan_groups(frames, gs, gh, gw, prefix, T)
-    pos, delta = planner.mrope_positions(prefix, (frames // 2, gh, gw), tail, temporal_scale=spec.temporal_scale)
+    pos, delta = planner.mrope_positions(prefix, (frames // 2, gh, gw), tail, temporal_scale=spec.resolved_temporal_scale(2.0))   # configs sample 2 fps
     cfg = lvu_config_for(name)
     tp = parallel == "tp" and world > 1
     pp_n, sp_n = layout

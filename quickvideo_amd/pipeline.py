@@ -166,10 +166,9 @@ class PrefillPipeline:
         T = len(prompt.prefix_ids) + n_video + len(prompt.tail_ids)
         gs = cfg.video_group_size
         plan = planner.plan_groups(nframes, gs, gh, gw, len(prompt.prefix_ids), T, vs.temporal_patch_size, vs.spatial_merge_size)
-        tscale = spec.temporal_scale
-        if tscale < 0:          # Qwen2.5-VL checkpoint: tokens_per_second * second_per_grid_t, second_per_grid_t = temporal_patch / sampled fps
-            sample_fps = nframes / max(total / vfps, 1e-9)         # qwen-vl-utils: video_sample_fps = nframes / total_frames * video_fps
-            tscale = -tscale * vs.temporal_patch_size / sample_fps
+        # Qwen2.5-VL: tokens_per_second * second_per_grid_t with second_per_grid_t = temporal_patch / sampled fps
+        sample_fps = nframes / max(total / vfps, 1e-9)             # qwen-vl-utils: video_sample_fps = nframes / total_frames * video_fps
+        tscale = spec.resolved_temporal_scale(sample_fps, vs.temporal_patch_size)
         pos, delta = planner.mrope_positions(len(prompt.prefix_ids), (nframes // vs.temporal_patch_size, gh, gw), len(prompt.tail_ids),
                                              vs.spatial_merge_size, tscale)
         return dict(nframes=nframes, H=H, W=W, idx=idx, prompt=prompt, plan=plan, pos=pos, delta=delta, T=T, gh=gh, gw=gw)

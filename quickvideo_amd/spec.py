@@ -20,8 +20,15 @@ class TextSpec:
     video_token_id: int = 151656
     vision_start_token_id: int = 151652
     vision_end_token_id: int = 151653
-    # Qwen2.5-VL scales the temporal position by second_per_grid * tokens_per_second; 1.0 = Qwen2-VL
+    # temporal M-RoPE step per temporal patch.  Qwen2-VL: 1.0.  Qwen2.5-VL: second_per_grid_t * tokens_per_second with
+    # second_per_grid_t = temporal_patch_size / sampled fps (get_rope_index [3P]) — stored as MINUS tokens_per_second and resolved per
+    # video by resolved_temporal_scale(); a positive value is used as is.
     temporal_scale: float = 1.0
+
+    def resolved_temporal_scale(self, sample_fps: float, temporal_patch_size: int = 2) -> float:
+        if self.temporal_scale >= 0:
+            return self.temporal_scale
+        return -self.temporal_scale * temporal_patch_size / sample_fps
 
     @property
     def q_dim(self) -> int:
@@ -48,4 +55,4 @@ TINY = TextSpec(hidden=256, n_heads=2, n_kv_heads=1, head_dim=128, intermediate=
                 video_token_id=300, vision_start_token_id=301, vision_end_token_id=302)
 
 PRESETS = {"qwen2-vl-2b": QWEN2_VL_2B, "qwen2-vl-7b": QWEN2_VL_7B, "qwen2-vl-72b": QWEN2_VL_72B, "tiny": TINY,
-           "qwen2.5-vl-7b": replace(QWEN2_VL_7B, temporal_scale=2.0)}
+           "qwen2.5-vl-7b": replace(QWEN2_VL_7B, temporal_scale=-2.0)}           # tokens_per_second = 2: 2.0 per grid step only at 2 fps
