@@ -125,17 +125,24 @@ class DecoderWeights:
     def synthetic(spec: TextSpec, device, seed: int = 0, dtype=torch.bfloat16, std: float = 0.02, tp_rank: int = 0,
                   tp_size: int = 1, n_layers: Optional[int] = None, layer_range: Optional[Tuple[int, int]] = None) -> "DecoderWeights":
         """Seeded random weights at the real dims, generated on the device (no checkpoint offline).
-        Under TP every rank draws only its own shard (seeded by (seed, layer, rank)); a layer-pipeline stage draws only the
-        layers of layer_range = (l0, l1) (each layer has its own seed, so stages agree with the single-process model)."""
+        Every layer has its own seed and is drawn in FULL (the single-GPU tensors), then cut down to this rank's tensor-parallel
+        shard with the same head / column partition as `from_named` — so every TP degree, every layer-pipeline stage and the
+        single-process model are the SAME model (a TP run must reproduce the single-GPU first token)."""
         D, hq, hkv, I, d = spec.head_dim, spec.n_heads, spec.n_kv_heads, spec.intermediate, spec.hidden
         assert I % tp_size == 0
-        q_idx, _, lkv = tp_head_partition(hq, hkv, tp_rank, tp_size)
-        lq = len(q_idx)
+        q_idx, kv_lo, lkv = tp_head_partition(hq, hkv, tp_rank, tp_size)
         li = I // tp_size
+        i_lo = tp_rank * li
         gen = torch.Generator(device=device)
 
         def mat(*shape, s=std):
             return (torch.randn(*shape, generator=gen, device=device, dtype=torch.float32) * s).to(dtype)
+
+        def q_rows(w):            # rows of a [hq*D, ...] matrix / vector for this rank's q heads (zero rows for pad heads)
+            return torch.cat([w[h * D:(h + 1) * D] if h >= 0 else torch.zeros_like(w[:D]) for h in q_idx], 0)
+
+        def q_cols(w):            # columns of o_proj [d, hq*D]
+            return torch.cat([w[:, h * D:(h + 1) * D] if h >= 0 else torch.zeros_like(w[:, :D]) for h in q_idx], 1)
 
         gen.manual_seed(seed)
         embed = mat(spec.vocab, d)
@@ -145,8 +152,16 @@ class DecoderWeights:
         total = spec.n_layers if n_layers is None else n_layers
         l0, l1 = layer_range if layer_range is not None else (0, total)
         for l in range(l0, l1):
-            gen.manual_seed(seed * 1_000_003 + l * 1009 + tp_rank + 1)
-            layers.append(LayerWeights(
-                ln1=torch.ones(d, device=device, dtype=dtype), w_qkv=mat((lq + 2 * lkv) * D, d), b_qkv=mat((lq + 2 * lkv) * D),
-                w_o=mat(d, lq * D), ln2=torch.ones(d, device=device, dtype=dtype), w_gate_up=mat(2 * li, d), w_down=mat(d, li)))
+            gen.manual_seed(seed * 1_000_003 + l * 1009 + 1)
+            w_qkv, b_qkv, w_o, w_gu, w_dn = mat((hq + 2 * hkv) * D, d), mat((hq + 2 * hkv) * D), mat(d, hq * D), mat(2 * I, d), mat(d, I)
+            if tp_size > 1:
+                kq, kk = hq * D, (hq + hkv) * D
+                ksl, vsl = slice(kq + kv_lo * D, kq + (kv_lo + lkv) * D), slice(kk + kv_lo * D, kk + (kv_lo + lkv) * D)
+                w_qkv = torch.cat([q_rows(w_qkv[:kq]), w_qkv[ksl], w_qkv[vsl]], 0).contiguous()
+                b_qkv = torch.cat([q_rows(b_qkv[:kq]), b_qkv[ksl], b_qkv[vsl]], 0).contiguous()
+                w_o = q_cols(w_o).contiguous()
+                w_gu = torch.cat([w_gu[i_lo:i_lo + li], w_gu[I + i_lo:I + i_lo + li]], 0).contiguous()
+                w_dn = w_dn[:, i_lo:i_lo + li].contiguous()
+            layers.append(LayerWeights(ln1=torch.ones(d, device=device, dtype=dtype), w_qkv=w_qkv, b_qkv=b_qkv, w_o=w_o,
+                                       ln2=torch.ones(d, device=device, dtype=dtype), w_gate_up=w_gu, w_down=w_dn))
         return DecoderWeights(spec, embed, layers, norm, lm_head, tp_rank, tp_size, l0, total)
