@@ -316,6 +316,10 @@ class QuickPrefillEngine:
             qkv = self.b_qkv[:n]
             self._linear("qkv", x, lw.w_qkv, qkv, lw.b_qkv)                  # q/k/v proj + bias             (:42-44)
             k_keep = effective_k(n, cfg, self.l0 + l, L) if prune else None  # utils.py:231-255
+            if k_keep is not None and self.query_mode:
+                # a query-score predict type outside a prompt-appended video group (do_top_k_for_query on the tail / decode): the
+                # reference has no scores there and trips its own assertion (utils.py:56, 59)
+                raise AssertionError("attn_weights_i should be 1D, but got None (query-based pruning needs the prompt-appended groups)")
             past = self.arena.len[l]
             assert past + (k_keep if k_keep is not None else n) <= self.arena.capacity, "KV arena overflow"
             q = self.b_q[:n]

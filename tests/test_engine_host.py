@@ -239,6 +239,11 @@ def test_query_based_groups_host_logic(pt):
     for (l, got), want in zip(eng.kept_trace, flat):
         assert (got is None) == (want is None) and (want is None or np.array_equal(got.numpy(), want))
     assert float((logits - ref["logits"]).abs().max()) == 0.0
+    # pruning the prompt tail in this mode: the reference asserts (no scores outside the prompt-appended groups, utils.py:56)
+    cfg2 = LVUConfig("x", top_p=0.5, video_group_size=8, top_k_predict_type=pt, do_top_k_for_query=True)
+    eng2 = QuickPrefillEngine(DecoderWeights.from_named(TINY, w, "cpu"), cfg2, capacity=64, max_group_tokens=64, device="cpu", ops=OracleOps())
+    with pytest.raises(AssertionError):
+        eng2.prefill_tail(embeds[:20], post[:, :20])
     # and the mode is not the key-norm mode in disguise
     base = O.group_prefill(w, spec_o, embeds, pos, plan.tokens, O.PruneCfg(top_p=0.5))
     assert any(not np.array_equal(a, b) for a, b in zip(flat, [k for g in base["kept"] for k in g]) if a is not None)
