@@ -116,6 +116,8 @@ def gen_p(b):
         if m % 2 == 0:
             p.emit(f"S6_WAIT({p.wait_for(('v', m + 1))}); PIN();")
         p.emit(f"S6_PV({m % RING}, {m >> 2}, {m & 3}); PIN();")
+        if (m & 3) == 3:                      # hook after the four d blocks of a 16-key chunk (experiment: row sum on the matrix pipe)
+            p.emit(f"S6_SUMP({m >> 2});")
         if m + RING < 16:
             vread(p, m + RING, "vrd_main")
         if m < 8:
