@@ -546,6 +546,30 @@ def test_prune_full_size_round_trip(ops):
     idx2 = torch.empty(k, dtype=torch.int32, device="cuda")
     ops.select_k_smallest(ss2, hkv, k, k, idx2)
     assert torch.equal(idx2.long(), torch.arange(k, device="cuda"))
+    # the engine's one-launch path (norm keys -> qp_prune_keys) at the BASELINE.json group sizes: same list, same rows, idempotent,
+    # and nothing written outside rows [past, past + k)
+    for (n2, k2) in ((5775, 2887), (2240, 1120), (2880, 720)):
+        keys = torch.zeros(n2, dtype=torch.int16, device="cuda")
+        ss3 = torch.empty(hkv, n2, dtype=torch.float32, device="cuda")
+        ops.key_sumsq(ks[:, :n2].contiguous(), n2 * D, 0, n2, hkv, D, ss3)
+        ops.norm_keys(ss3, hkv, n2, keys)
+        idx_s = torch.empty(k2, dtype=torch.int32, device="cuda")
+        ops.select_k_smallest(ss3, hkv, n2, k2, idx_s)
+        past = 11
+        kc3 = torch.zeros(hkv, past + k2 + 7, D, dtype=torch.bfloat16, device="cuda"); vc3 = torch.zeros_like(kc3)
+        idx_k = torch.empty(k2, dtype=torch.int32, device="cuda")
+        ksn, vsn = ks[:, :n2].contiguous(), vs[:, :n2].contiguous()
+        ops.prune_keys(keys, n2, k2, ksn, vsn, n2 * D, hkv, D, kc3, vc3, (past + k2 + 7) * D, past, idx_k)
+        torch.cuda.synchronize()
+        assert torch.equal(idx_k, idx_s)
+        assert torch.equal(kc3[:, past:past + k2], ksn[:, idx_k.long()]) and torch.equal(vc3[:, past:past + k2], vsn[:, idx_k.long()])
+        assert torch.count_nonzero(kc3[:, :past]).item() == 0 and torch.count_nonzero(kc3[:, past + k2:]).item() == 0
+        keys2 = keys[idx_k.long()].contiguous()
+        idx_i = torch.empty(k2, dtype=torch.int32, device="cuda")
+        kc4 = torch.zeros(hkv, k2, D, dtype=torch.bfloat16, device="cuda"); vc4 = torch.zeros_like(kc4)
+        ops.prune_keys(keys2, k2, k2, kc3[:, past:past + k2].contiguous(), vc3[:, past:past + k2].contiguous(), k2 * D, hkv, D, kc4, vc4, k2 * D, 0, idx_i)
+        torch.cuda.synchronize()
+        assert torch.equal(idx_i.long(), torch.arange(k2, device="cuda")) and torch.equal(kc4, kc3[:, past:past + k2])
 
 
 def test_qwen25_tower_hip_vs_torch(ops):
