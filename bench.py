@@ -647,7 +647,12 @@ def measure(args, name, device, rank, world, parallel, layout, group, weights=No
                            "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None, "launches": att_n,
                            "avg_launch_ms": round(att_ms / max(att_n, 1), 4), "algorithmic_flops_per_launch": att_local / max(att_n, 1),
                            "algorithmic_flops_per_pass": att_local, "kernel_ms_per_pass": round(att_ms, 2),
-                           "timing": "HIP events on the launch stream, " + ("inside the timed region" if fraction else "one extra pass")}
+                           "timing": "HIP events on the launch stream, " + ("inside the timed region" if fraction else "one extra pass"),
+                           "power_limited_reference": {
+                               "source": "profiles/r2_mfma_power_probe.txt (tools/probe/probe_mfma_power.hip, committed measurement, not taken in this run)",
+                               "tflops_all_zero_operands": 2467.4, "tflops_random_bf16_register_operands": 1845.2,
+                               "tflops_random_bf16_one_lds_fetch_per_mfma": 1543.0, "tflops_plus_softmax_valu_per_mfma": 1208.5,
+                               "note": "the 2.5 PF peak is reached on all-zero data only; on random bf16 data the chip is at its power cap at these rates"}}
         pr_ms = sum(tot[t][0] for t in PRUNE_OPS if t in tot)
         pr_n = max([tot[t][1] for t in PRUNE_OPS if t in tot] + [0])
         if pr_ms > 0:

@@ -1,0 +1,166 @@
+// Power probe: what the chip sustains on dense bf16 MFMA streams with RANDOM operands, by instruction shape and with / without the
+// LDS fragment reads an attention kernel needs — TFLOP/s, socket power and shader clock (sysfs hwmon), i.e. energy per FLOP.
+//   hipcc --offload-arch=gfx950 -O3 -o probe_mfma_power probe_mfma_power.hip && ./probe_mfma_power
+// modes: 0 = v_mfma_f32_32x32x16_bf16, operands in registers       1 = v_mfma_f32_16x16x32_bf16, operands in registers
+//        2 = 32x32x16 + one ds_read_b128 (A operand) per MFMA       3 = 16x16x32 + one ds_read_b128 per MFMA
+//        4 = mode 0 with all-zero operands (toggling-free reference)
+//        5 = 32x32x16, one ds_read_b128 per TWO MFMAs (a 64-query-rows-per-wave kernel: every fragment feeds two MFMAs)
+//        6 = mode 2 + the softmax's VALU per MFMA (1 v_exp_f32, 1 v_fma_f32, 1 v_add_f32, 1/2 v_cvt_pk_bf16_f32, 1/2 v_max3_f32)
+//        7 = mode 5 + the same VALU per MFMA
+#include <hip/hip_runtime.h>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <dirent.h>
+#include <string>
+#include <thread>
+#include <vector>
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef float f32x16_t __attribute__((ext_vector_type(16)));
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+template <int kMode>
+__global__ __launch_bounds__(256, 2) void mfma_loop(const uint4* __restrict__ in, float* __restrict__ out, int iters) {
+  __shared__ __attribute__((aligned(16))) uint4 lds[4096];              // 64 KB of operand fragments
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 4096; i += 256) lds[i] = in[(blockIdx.x * 4096 + i) & 0xffff];
+  __syncthreads();
+  bf16x8_t a[4], b[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a[i] = __builtin_bit_cast(bf16x8_t, in[(tid * 8 + i) & 0xffff]);
+    b[i] = __builtin_bit_cast(bf16x8_t, in[(tid * 8 + 4 + i) & 0xffff]);
+  }
+  f32x16_t c32[4];
+  f32x4_t c16[8];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) c32[i] = (f32x16_t){0};
+#pragma unroll
+  for (int i = 0; i < 8; ++i) c16[i] = (f32x4_t){0};
+  int off = tid;
+  float vx[4] = {0.3f + tid * 1e-3f, 0.7f, 1.1f, 1.9f}, vs = 0.f, vm = 0.f;
+  unsigned vpk = 0;
+  for (int it = 0; it < iters; ++it) {
+    if (kMode == 0 || kMode == 4) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) c32[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i & 3], b[(i >> 1) & 3], c32[i & 3], 0, 0, 0);
+    } else if (kMode == 1) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) c16[i & 7] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i & 3], b[(i >> 2) & 3], c16[i & 7], 0, 0, 0);
+    } else if (kMode == 2 || kMode == 6) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const bf16x8_t al = __builtin_bit_cast(bf16x8_t, lds[(off + i * 256) & 4095]);
+        c32[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b[i & 3], c32[i & 3], 0, 0, 0);
+        if (kMode == 6) {                 // softmax-like filler on values that stay in range
+          const float x = __builtin_fmaf(vx[i & 3], 0.25f, -1.0f);
+          const float e = __builtin_amdgcn_exp2f(x);
+          vs += e;
+          vx[i & 3] = e + 0.5f;
+          if (i & 1) { vm = fmaxf(fmaxf(vm, e), x); typedef __bf16 bf2 __attribute__((ext_vector_type(2))); bf2 pk = {(__bf16)e, (__bf16)x}; vpk ^= __builtin_bit_cast(unsigned, pk); }
+        }
+      }
+      off += 7;
+    } else if (kMode == 5 || kMode == 7) {
+#pragma unroll
+      for (int i = 0; i < 8; i += 2) {
+        const bf16x8_t al = __builtin_bit_cast(bf16x8_t, lds[(off + i * 256) & 4095]);
+        c32[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b[i & 3], c32[i & 3], 0, 0, 0);
+        c32[(i + 1) & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b[(i + 1) & 3], c32[(i + 1) & 3], 0, 0, 0);
+        if (kMode == 7) {
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const float x = __builtin_fmaf(vx[(i + j) & 3], 0.25f, -1.0f);
+            const float e = __builtin_amdgcn_exp2f(x);
+            vs += e;
+            vx[(i + j) & 3] = e + 0.5f;
+            if (j) { vm = fmaxf(fmaxf(vm, e), x); typedef __bf16 bf2 __attribute__((ext_vector_type(2))); bf2 pk = {(__bf16)e, (__bf16)x}; vpk ^= __builtin_bit_cast(unsigned, pk); }
+          }
+        }
+      }
+      off += 7;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const bf16x8_t al = __builtin_bit_cast(bf16x8_t, lds[(off + i * 256) & 4095]);
+        c16[i & 7] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, b[i & 3], c16[i & 7], 0, 0, 0);
+      }
+      off += 7;
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) s += c32[i][0] + c32[i][7];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) s += c16[i][0];
+  s += vs + vm + vx[0] + vx[1] + vx[2] + vx[3] + (float)vpk;
+  if (s == 123.456f) out[tid] = s;
+}
+
+static std::string find_hwmon() {
+  hipDeviceProp_t p; hipGetDeviceProperties(&p, 0);
+  char want[32]; snprintf(want, sizeof want, "%04x:%02x:%02x.0", p.pciDomainID, p.pciBusID, p.pciDeviceID);
+  for (int c = 0; c < 64; ++c) {
+    char link[256], real[512];
+    snprintf(link, sizeof link, "/sys/class/drm/card%d/device", c);
+    if (!realpath(link, real)) continue;
+    std::string r(real);
+    if (r.substr(r.find_last_of('/') + 1) != want) continue;
+    std::string hw = std::string(link) + "/hwmon";
+    if (DIR* d = opendir(hw.c_str())) {
+      while (dirent* e = readdir(d)) if (!strncmp(e->d_name, "hwmon", 5)) { closedir(d); return hw + "/" + e->d_name; }
+      closedir(d);
+    }
+  }
+  return "";
+}
+static double read_num(const std::string& path) { FILE* f = fopen(path.c_str(), "r"); if (!f) return -1; double v = -1; if (fscanf(f, "%lf", &v) != 1) v = -1; fclose(f); return v; }
+
+template <int kMode>
+void run(const uint4* in, float* out, const std::string& hw, const char* name, double flop_per_iter_per_wave) {
+  const int grid = 256 * 2, iters = 20000;
+  mfma_loop<kMode><<<grid, 256>>>(in, out, 100);
+  hipDeviceSynchronize();
+  std::atomic<bool> stop{false};
+  std::vector<double> pw, ck;
+  std::thread t([&] { while (!stop) { double p = read_num(hw + "/power1_average"); if (p <= 0) p = read_num(hw + "/power1_input"); double c = read_num(hw + "/freq1_input"); if (p > 0) pw.push_back(p / 1e6); if (c > 0) ck.push_back(c / 1e6);
+                      std::this_thread::sleep_for(std::chrono::milliseconds(50)); } });
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  int launches = 0;
+  auto t0 = std::chrono::steady_clock::now();
+  hipEventRecord(e0);
+  while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 3.0) { for (int i = 0; i < 4; ++i) mfma_loop<kMode><<<grid, 256>>>(in, out, iters); launches += 4; hipDeviceSynchronize(); }
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  stop = true; t.join();
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  const double flops = (double)launches * grid * 4 * iters * flop_per_iter_per_wave;
+  double p = 0, c = 0; size_t skip = pw.size() / 3;                         // steady state: drop the first third of the samples
+  for (size_t i = skip; i < pw.size(); ++i) p += pw[i]; p /= (pw.size() - skip > 0 ? pw.size() - skip : 1);
+  for (size_t i = skip; i < ck.size(); ++i) c += ck[i]; c /= (ck.size() - skip > 0 ? ck.size() - skip : 1);
+  const double tf = flops / (ms * 1e-3) / 1e12;
+  printf("%-46s %8.1f TFLOP/s  %7.1f W  %6.0f MHz  %6.2f pJ/FLOP\n", name, tf, p, c, p / (tf * 1e12) * 1e12);
+}
+
+int main() {
+  const std::string hw = find_hwmon();
+  printf("hwmon: %s\n", hw.c_str());
+  uint4* in; float* out;
+  hipMalloc(&in, 65536 * 16); hipMalloc(&out, 4096);
+  std::vector<unsigned> h(65536 * 4);
+  unsigned x = 12345;
+  for (auto& v : h) { x = x * 1664525u + 1013904223u; unsigned lo = 0x3f00u | ((x >> 8) & 0xff) | ((x >> 1) & 0x8000u), hi = 0x3f00u | ((x >> 16) & 0xff) | (x & 0x8000u); v = lo | (hi << 16); }   // bf16 values in +-[0.5, 1)
+  hipMemcpy(in, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+  run<0>(in, out, hw, "32x32x16 bf16, register operands, random data", 8 * 32768.0);
+  run<1>(in, out, hw, "16x16x32 bf16, register operands, random data", 16 * 16384.0);
+  run<2>(in, out, hw, "32x32x16 bf16 + 1 ds_read_b128 per MFMA", 8 * 32768.0);
+  run<3>(in, out, hw, "16x16x32 bf16 + 1 ds_read_b128 per MFMA", 16 * 16384.0);
+  run<5>(in, out, hw, "32x32x16 bf16 + 1 ds_read_b128 per TWO MFMAs", 8 * 32768.0);
+  run<6>(in, out, hw, "32x32x16 + 1 LDS read + softmax VALU per MFMA", 8 * 32768.0);
+  run<7>(in, out, hw, "32x32x16 + 1/2 LDS read + softmax VALU per MFMA", 8 * 32768.0);
+  hipMemset(in, 0, 65536 * 16);
+  run<4>(in, out, hw, "32x32x16 bf16, register operands, ALL-ZERO data", 8 * 32768.0);
+  return 0;
+}
