@@ -1,0 +1,44 @@
+"""bench.py as the driver runs it: the JSON contract at N = 1 and the multi-rank path (self-launch under torch.distributed.run,
+TP block + auto layout) with two ranks sharing the one GPU of the test box (QP_BENCH_SINGLE_DEVICE=1, gloo)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(args, env_extra=None, timeout=600):
+    env = dict(os.environ)
+    env.update(env_extra or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]                       # ONE JSON line
+    return json.loads(lines[0])
+
+
+def test_bench_contract_fields_single_gpu():
+    d = run_bench(["--config", "cfg4s", "--steps", "5", "--warmup", "1", "--no-pipeline", "--no-secondary", "--no-decode"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 5 and d["unit"] == "tokens/s" and d["dtype"] == "bf16" and "workload" in d["config"]
+    assert abs(d["ms_per_step"] * d["steps"] - d["full_prefill_ms"]) < 1.0                     # the K steps ARE one full prefill
+    assert abs(d["value"] - d["config"]["prefill_tokens"] / (d["full_prefill_ms"] * 1e-3)) < 1.0
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.2 < r["frac"] < 0.8
+    assert d["roofline_prune"]["empty_launch_floor_us"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c.get("extrapolated") and len(c["points"]) == 3
+
+
+def test_bench_two_ranks_on_one_gpu_reproduce_the_single_gpu_token():
+    one = run_bench(["--config", "cfg4s", "--steps", "5", "--warmup", "1", "--lean"])
+    two = run_bench(["--gpus", "2", "--config", "cfg4s", "--steps", "5", "--warmup", "1"], {"QP_BENCH_SINGLE_DEVICE": "1"}, timeout=900)
+    assert two["n_gpus"] == 2 and two["rccl_ranks"]["world_size"] == 2 and two["rccl_ranks"]["backend"] == "gloo"
+    assert two["tp"]["parallelism"] == "tp2" and "sp_efficiency_probe" in two
+    assert two["first_token"] == one["first_token"] == two["tp"]["first_token"]              # same model under every layout
