@@ -201,9 +201,11 @@ def test_engine_cfg3_shape_two_layers_vs_oracle():
 
 def test_pipeline_ring_reuse_under_a_slow_main_stream():
     """Many groups through the overlapped pipeline while the main stream is artificially slow (a spin kernel in front of every group's
-    prefill), so the producer and the ViT stream run as far ahead as the 3-slot ring lets them: without the explicit slot / cross-stream
-    ordering (read-done events handed back to the producer, record_stream on the ViT output) a slot or a feature block would be
-    recycled before the main stream has read it.  The tokens must equal the everything-fetched-first run."""
+    prefill), so the producer and the ViT stream run as far ahead as the 3-slot ring lets them — the situation in which a ring slot or a
+    ViT output block could be recycled before the main stream has read it if the explicit orderings (read-done events handed back to the
+    producer, record_stream on the ViT output) were missing.  The tokens must equal the everything-fetched-first run.  (Honest note: with
+    the orderings disabled this tiny-model run still passed on the test box — the caching allocator did not happen to reuse the block —
+    so the test guards against deadlock / mis-ordering under skew, it is not a proof of the race.)"""
     import lvu
     from quickvideo_amd.engine import QuickPrefillEngine as E
     from quickvideo_amd.lvu import load_native_model
