@@ -212,8 +212,9 @@ def test_pipeline_ring_reuse_under_a_slow_main_stream():
     from quickvideo_amd.pipeline import PrefillPipeline
     from quickvideo_amd.processor import SyntheticProcessor
     m = load_native_model("synthetic:tiny", device="cuda:0", seed=5)
-    cfg = lvu.LVUConfig("synthetic:tiny", top_p=0.5, video_group_size=4, num_frames=96)           # 24 groups
-    video = "synthetic://?frames=400&h=112&w=168&seed=9"
+    # 16 frames of 448x672 per group: 3072 tokens -> 1.5 MB feature blocks, the size class of the ViT's own activations (large pool)
+    cfg = lvu.LVUConfig("synthetic:tiny", top_p=0.5, video_group_size=16, num_frames=192, extra_kwargs={"max_pixels": 448 * 672})   # 12 groups
+    video = "synthetic://?frames=800&h=448&w=672&seed=9"
     pipe = PrefillPipeline(m, cfg, SyntheticProcessor(m.spec))
     ref = pipe.generate("What is shown?", video, max_new_tokens=4, overlap=False)
     orig = E.prefill_group
@@ -228,7 +229,7 @@ def test_pipeline_ring_reuse_under_a_slow_main_stream():
             assert got == ref
     finally:
         E.prefill_group = orig
-    assert pipe.last_timings.groups == 24
+    assert pipe.last_timings.groups == 12
 
 
 def test_no_gpu_fallback_is_loud():
