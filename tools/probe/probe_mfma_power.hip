@@ -7,6 +7,7 @@
 //        5 = 32x32x16, one ds_read_b128 per TWO MFMAs (a 64-query-rows-per-wave kernel: every fragment feeds two MFMAs)
 //        6 = mode 2 + the softmax's VALU per MFMA (1 v_exp_f32, 1 v_fma_f32, 1 v_add_f32, 1/2 v_cvt_pk_bf16_f32, 1/2 v_max3_f32)
 //        7 = mode 5 + the same VALU per MFMA
+//        10 = mode 6 without the fma (exp, add, 1/2 cvt, 1/2 max3): what folding the max subtraction into the MFMA accumulator would leave
 //        8 = mode 2 + ONLY the v_exp_f32 per MFMA        9 = mode 2 + ONLY the plain VALU (fma, add, 1/2 cvt_pk, 1/2 max3) per MFMA
 #include <hip/hip_runtime.h>
 #include <atomic>
@@ -66,16 +67,16 @@ __global__ __launch_bounds__(256, 2) void mfma_loop(const uint4* __restrict__ in
         }
       }
       off += 7;
-    } else if (kMode == 2 || kMode == 6) {
+    } else if (kMode == 2 || kMode == 6 || kMode == 10) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
         const bf16x8_t al = __builtin_bit_cast(bf16x8_t, lds[(off + i * 256) & 4095]);
         c32[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, b[i & 3], c32[i & 3], 0, 0, 0);
-        if (kMode == 6) {                 // softmax-like filler on values that stay in range
-          const float x = __builtin_fmaf(vx[i & 3], 0.25f, -1.0f);
+        if (kMode == 6 || kMode == 10) {                 // softmax-like filler on values that stay in range
+          const float x = kMode == 6 ? __builtin_fmaf(vx[i & 3], 0.25f, -1.0f) : vx[i & 3];
           const float e = __builtin_amdgcn_exp2f(x);
           vs += e;
-          vx[i & 3] = e + 0.5f;
+          if (kMode == 6) vx[i & 3] = e + 0.5f; else vx[i & 3] = -e;          // mode 10: exp feeds the next exp's input directly (bounded in [-1, 0])
           if (i & 1) { vm = fmaxf(fmaxf(vm, e), x); typedef __bf16 bf2 __attribute__((ext_vector_type(2))); bf2 pk = {(__bf16)e, (__bf16)x}; vpk ^= __builtin_bit_cast(unsigned, pk); }
         }
       }
@@ -176,6 +177,7 @@ int main() {
   run<5>(in, out, hw, "32x32x16 bf16 + 1 ds_read_b128 per TWO MFMAs", 8 * 32768.0);
   run<6>(in, out, hw, "32x32x16 + 1 LDS read + softmax VALU per MFMA", 8 * 32768.0);
   run<7>(in, out, hw, "32x32x16 + 1/2 LDS read + softmax VALU per MFMA", 8 * 32768.0);
+  run<10>(in, out, hw, "32x32x16 + 1 LDS read + softmax VALU WITHOUT the fma", 8 * 32768.0);
   run<8>(in, out, hw, "32x32x16 + 1 LDS read + ONLY v_exp_f32 (+mul) per MFMA", 8 * 32768.0);
   run<9>(in, out, hw, "32x32x16 + 1 LDS read + ONLY the plain VALU per MFMA", 8 * 32768.0);
   hipMemset(in, 0, 65536 * 16);
