@@ -157,6 +157,9 @@ class QuickPrefillEngine:
     # by > 3 %.  Rows are independent in a GEMM, so every decomposition computes the same projection (fp32 accumulation order
     # may differ between kernels, like between any two hipBLASLt algorithms).
     def _run_linear(self, plan, x, w, out, bias):
+        if plan == "lt":                              # hipBLASLt algorithm picked by qp_linear_tune for this problem
+            self.ops.linear_act(x, w, bias, out, self.ops.ACT_NONE)
+            return
         for r0, r1 in plan:
             if bias is None:
                 torch.mm(x[r0:r1], w.t(), out=out[r0:r1])
@@ -220,6 +223,19 @@ class QuickPrefillEngine:
                         best, whole = (ms, cand), ms
                     elif ms < best[0] and ms < 0.97 * whole:
                         best = (ms, cand)
+                # ... and hipBLASLt's other heuristic candidates for the same problem (qp_linear_tune times them over every layer's
+                # copy of the projection): torch.mm takes the library's FIRST candidate, which for the down projection at M = 2240 is
+                # 357 us (0.85 PF) where another one runs 243 us (1.25 PF)  (tools/probe/probe_big_algos.py 2240)
+                if (os.environ.get("QP_TUNE_LT", "1") == "1" and hasattr(self.ops, "linear_tune") and x.is_contiguous() and w.is_contiguous()
+                        and out.is_contiguous()):
+                    try:
+                        ws = [getattr(lw, self._WKEY[key]) for lw in self.w.layers]
+                        self.ops.linear_tune(x, ws, bias, out, self.ops.ACT_NONE)
+                        ms = self._time(lambda: self.ops.linear_act(x, w, bias, out, self.ops.ACT_NONE))
+                        if ms < best[0] and ms < 0.97 * whole:
+                            best = (ms, "lt")
+                    except Exception:                 # no usable candidate for this shape: keep torch.mm
+                        pass
                 plan = best[1]
                 if os.environ.get("QP_ENGINE_DEBUG"):
                     print(f"[engine] {key} n={n}: whole {whole * 1e3:.0f} us -> {plan} {best[0] * 1e3:.0f} us", flush=True)

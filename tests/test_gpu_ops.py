@@ -846,3 +846,25 @@ def test_reference_adapter_post_process_kv_cache(ops, golden_dir, ci):
     assert list(h2.shape) == meta["hidden_shape"] and sha(h2.cpu().numpy()) == meta["hidden_sha"]
     assert sha(pi2.cpu().numpy()) == meta["pos_sha"] and sha(cp2.cpu().numpy()) == meta["cache_pos_sha"]
     assert sha(pe2[0].cpu().numpy(), pe2[1].cpu().numpy()) == meta["pe_sha"]
+
+
+def test_linear_tuned_candidate_at_group_size(ops):
+    """The engine may replace torch.mm by another hipBLASLt heuristic candidate for a projection (qp_linear_tune: at M = 2240 the
+    down projection's default pick runs at 0.85 PF, another candidate at 1.25 PF).  Whatever candidate is picked computes the same
+    product: vs an fp32 reference on a row sample, and vs torch.mm everywhere, within bf16 output rounding."""
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    for (m, k, n) in ((2240, 18944, 3584), (2240, 3584, 4608)):
+        x = torch.randn(m, k, generator=g, device="cuda").to(torch.bfloat16)
+        ws = [(torch.randn(n, k, generator=g, device="cuda") * 0.02).to(torch.bfloat16) for _ in range(3)]
+        bias = (torch.randn(n, generator=g, device="cuda") * 0.02).to(torch.bfloat16) if n == 4608 else None
+        out = torch.empty(m, n, dtype=torch.bfloat16, device="cuda")
+        ops.linear_tune(x, ws, bias, out, ops.ACT_NONE)
+        for w in ws:
+            ops.linear_act(x, w, bias, out, ops.ACT_NONE)
+            ref_mm = torch.mm(x, w.t()) if bias is None else torch.addmm(bias, x, w.t())
+            torch.cuda.synchronize()
+            scale = ref_mm.float().abs().max().item()
+            assert (out.float() - ref_mm.float()).abs().max().item() <= 2 ** -7 * scale          # two bf16 roundings of the same fp32 sums
+            rows = torch.arange(0, m, 97, device="cuda")
+            ref32 = x[rows].float() @ w.float().t() + (bias.float() if bias is not None else 0.0)
+            assert (out[rows].float() - ref32).abs().max().item() <= 2 ** -7 * scale

@@ -7,7 +7,7 @@ from quickvideo_amd.native import QuickPrefillOps
 ops = QuickPrefillOps(torch.device("cuda:0"))
 H, QKV, I = 3584, 4608, 18944
 for M in [int(a) for a in (sys.argv[1:] or ["5760"])]:
-    for name, K, N in (("qkv", H, QKV), ("o", H, H), ("gate_up", H, 2 * I), ("down", I, H)):
+    for name, K, N in (("qkv", H, QKV), ("o", H, H), ("gate_up", H, 2 * I), ("gate", H, I), ("down", I, H)):
         copies = 6
         ws = [torch.randn(N, K, device="cuda").to(torch.bfloat16) * 0.02 for _ in range(copies)]
         x = torch.randn(M, K, device="cuda").to(torch.bfloat16); out = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
