@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """bench.py — prefill tokens/s + video->first-token of the QuickPrefill hot path on MI355X.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg4|cfg2|cfg3|cfg4s|cfg5|tiny]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg4|cfg2|cfg3|cfg4s|cfg4x2|cfg5|tiny]
   (N>1: launched by the driver as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...
    bench.py --gpus N ...`; run from a bare shell it re-launches itself that way.)
 
@@ -53,12 +53,22 @@ CONFIGS = {
     "cfg3": ("qwen2-vl-7b", 256, 280, 504, 32, 0.25, 15, 30),
     "cfg4s": ("qwen2-vl-7b", 720, 392, 560, 16, 0.5, 15, 30),     # 1/10 of the 1-hour video (100k tokens)
     "cfg4": ("qwen2-vl-7b", 7200, 392, 560, 16, 0.5, 15, 30),      # synthetic 1-hour video, ~1M vision tokens (the metric's workload)
+    "cfg4x2": ("qwen2-vl-7b", 14400, 392, 560, 16, 0.5, 15, 30),   # 2-hour video, ~2M vision tokens, 57.8 GB of pruned KV: capacity point, not the metric
     "cfg5": ("qwen2-vl-72b", 512, 224, 420, 16, 0.5, 15, 30),      # 72B: TP=8 in BASELINE.json; also fits ONE MI355X (145 GB of 288 GB)
     "tiny": ("tiny", 16, 112, 168, 4, 0.5, 5, 7),
 }
 PEAK_BF16_TFLOPS = 2500.0     # dense MFMA peak, MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
 QUESTION = "Describe what happens in this video in detail."
+
+
+_T0 = time.perf_counter()
+
+
+def progress(msg):
+    """Leg-by-leg progress on stderr of rank 0 (stdout carries exactly one JSON line)."""
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
 def describe(name):
@@ -220,7 +230,7 @@ def lvu_config_for(name):
     model, frames, fh, fw, gs, rho, prefix, tail = CONFIGS[name]
     # the front end's frame size follows the reference's pixel budget from the source size (qwen25_lvu.py:292-306); cfg4's 392x560
     # is SURVEY §8d's deliberate choice (~1M vision tokens), reached with an explicit max_pixels on a 392x560 source
-    extra = {"max_pixels": fh * fw} if name in ("cfg4", "cfg4s") else {}
+    extra = {"max_pixels": fh * fw} if name in ("cfg4", "cfg4s", "cfg4x2") else {}
     return LVUConfig(model, top_p=rho, video_group_size=gs, num_frames=frames, extra_kwargs=extra)
 
 
@@ -502,7 +512,7 @@ def pipeline_leg(name, eng, device, modes=("overlapped", "sequential"), warm_vid
     m = QwenVLNative(eng.w, vis, device, name=model)
     m.engine = eng                                               # same engine (KV arena, tuned GEMM plans) as the headline pass
     pipe = PrefillPipeline(m, eng.cfg, SyntheticProcessor(eng.spec), ops=eng.ops)
-    if name in ("cfg4", "cfg4s"):     # a 1-hour (or 6-minute) video at 8 fps sampled at 2 fps; frames already at the model's size
+    if name in ("cfg4", "cfg4s", "cfg4x2"):     # a 1-hour (or 6-minute) video at 8 fps sampled at 2 fps; frames already at the model's size
         video = f"synthetic://?frames={frames * 4}&h={fh}&w={fw}&fps=8&seed=1"
         warm = f"synthetic://?frames=256&h={fh}&w={fw}&fps=8&seed=2" if warm_video is None else warm_video
     else:
@@ -553,6 +563,7 @@ def measure(args, name, device, rank, world, parallel, layout, group, weights=No
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    progress(f"{name}: workload built ({G} groups, {tokens} tokens)")
     # warm-up: the engine picks its GEMM decompositions / hipBLASLt algorithms the first time a segment size shows up (one-off, like
     # building the weights); with --warmup 0 that first use must still not land in the timed steps
     for _ in range(max(args.warmup, 1)):
@@ -563,6 +574,7 @@ def measure(args, name, device, rank, world, parallel, layout, group, weights=No
         else:
             run_video(eng, plan, starts, embeds, pos)
 
+    progress("warm-up done (GEMM / attention plans chosen)")
     # floor of ANY launch in the prune's position (right after the o_proj GEMM): a 1-thread kernel bracketed the same way.  The
     # prune moves 7-18 MB per launch, i.e. 1-3 us of HBM time, so its bracket is this floor + a latency chain, not bandwidth.
     floor_us = None
@@ -788,7 +800,9 @@ def main():
             layout = {"sp": (1, world), "pp": (world, 1)}[args.parallel]
         parallel = "sp" if layout[0] == 1 else "pp" if layout[1] == 1 else "ppsp"
 
+    progress(f"{name}: build + warm-up + timed pass")
     res, eng, ctx = measure(args, name, device, rank, world, parallel, layout, group, timing=timing, telemetry=(world == 1))
+    progress(f"timed pass done: {res['value']} tok/s, {res['full_prefill_ms']} ms per pass")
     if args.window:
         if rank == 0:
             print(json.dumps({"config": describe(name), **res}))
@@ -797,19 +811,13 @@ def main():
         return
     attach_traffic(res.get("roofline"), name, world)
 
-    decode = pipe_stats = cpu = secondary = None
-    if world == 1:
-        if not args.no_decode:
-            decode = decode_leg(eng, res["first_token"])           # the engine holds the cache of the timed pass (prefill + tail)
-        if not args.no_pipeline:
-            long_video = ctx["fraction"]
-            pipe_stats = pipeline_leg(name, eng, device, modes=("overlapped",) if long_video else ("overlapped", "sequential"))
-        if not args.no_secondary and name != "cfg2" and CONFIGS[name][0] == "qwen2-vl-7b":
-            secondary = secondary_cfg2(args, device, eng.w)
-        if not args.no_cpu_baseline and rank == 0:
-            cpu = cpu_baseline(name)
+    legs = {"decode": None, "video_to_first_token": None, "cfg2": None, "cpu_baseline": None}
+    emitted = threading.Lock()
 
-    if rank == 0:
+    def emit(note=None):
+        """The ONE JSON line (rank 0).  Called once: at the end, or by the watchdog when an auxiliary leg overruns its budget."""
+        if rank != 0 or not emitted.acquire(blocking=False):
+            return
         plan, spec = ctx["plan"], ctx["spec"]
         plan_desc = {"groups": len(plan.tokens), "tokens_per_group": plan.tokens[-1], "prefill_tokens": ctx["tokens"],
                      "tail_tokens": plan.tail_len, "layers": spec.n_layers}
@@ -839,15 +847,42 @@ def main():
                 out["sp_efficiency_probe"] = {str(k): v for k, v in eff_sp.items()}
             if tp_block is not None and parallel != "tp":
                 out["tp"] = tp_block
-        if decode:
-            out["decode"] = decode
-        if pipe_stats:
-            out["video_to_first_token"] = pipe_stats
-        if cpu:
-            out["cpu_baseline"] = cpu
-        if secondary:
-            out["cfg2"] = secondary
-        print(json.dumps(out))
+        for k, v in legs.items():
+            if v:
+                out[k] = v
+        if note:
+            out["note"] = note
+        print(json.dumps(out), flush=True)
+
+    if world == 1:
+        # The auxiliary legs (decode, video -> first token, cfg2 block, CPU baseline) come after the timed region.  Should one of them
+        # overrun its budget (a stuck host thread, a starved box), the line is still printed with what was measured.
+        budget_s = float(os.environ.get("QP_BENCH_AUX_BUDGET_S", "1200"))
+        aux_done = threading.Event()
+
+        def watchdog():
+            if not aux_done.wait(budget_s):
+                progress(f"auxiliary legs exceeded {budget_s:.0f} s: printing the line without the unfinished ones")
+                emit(note=f"auxiliary legs cut off after {budget_s:.0f} s; missing blocks were not measured in this run")
+                sys.stdout.flush()
+                os._exit(0)
+
+        threading.Thread(target=watchdog, daemon=True).start()
+        if not args.no_decode:
+            legs["decode"] = decode_leg(eng, res["first_token"])   # the engine holds the cache of the timed pass (prefill + tail)
+            progress("decode leg done")
+        if not args.no_pipeline:
+            long_video = ctx["fraction"]
+            legs["video_to_first_token"] = pipeline_leg(name, eng, device, modes=("overlapped",) if long_video else ("overlapped", "sequential"))
+            progress("video -> first token leg done")
+        if not args.no_secondary and name != "cfg2" and CONFIGS[name][0] == "qwen2-vl-7b":
+            legs["cfg2"] = secondary_cfg2(args, device, eng.w)
+            progress("secondary cfg2 block done")
+        if not args.no_cpu_baseline and rank == 0:
+            legs["cpu_baseline"] = cpu_baseline(name)
+            progress("cpu baseline done")
+        aux_done.set()
+    emit()
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -42,3 +42,9 @@ def test_bench_two_ranks_on_one_gpu_reproduce_the_single_gpu_token():
     assert two["n_gpus"] == 2 and two["rccl_ranks"]["world_size"] == 2 and two["rccl_ranks"]["backend"] == "gloo"
     assert two["tp"]["parallelism"] == "tp2" and "sp_efficiency_probe" in two
     assert two["first_token"] == one["first_token"] == two["tp"]["first_token"]              # same model under every layout
+
+
+def test_bench_prints_its_line_when_an_auxiliary_leg_overruns():
+    """The decode / video->first-token / cfg2 / CPU-baseline legs run after the timed region; a stuck one must not cost the line."""
+    d = run_bench(["--config", "tiny", "--steps", "2", "--warmup", "1"], {"QP_BENCH_AUX_BUDGET_S": "0.001"})
+    assert d["value"] > 0 and d["roofline"] is not None and "cut off" in d["note"]

@@ -75,6 +75,27 @@ def test_engine_vs_oracle_tiny(top_p, pps):
         assert same / tot >= 0.90, same / tot
 
 
+def test_engine_many_groups_vs_oracle():
+    """24 sequential groups (the 1-hour video has 450): the pruned prefix grows group after group, every group attends over what the
+    earlier prunes kept.  Cache lengths exact after every group, logits within the stated tolerance, kept sets >= 90 % identical."""
+    spec_o, w, plan, pos, delta, embeds = make_case(192, 8, 8, 8, 15, 20)      # 24 groups x 64 tokens (+15 prefix on group 0)
+    assert len(plan.tokens) == 24
+    cfg = LVUConfig("x", top_p=0.5, video_group_size=8)
+    eng, logits = run_gpu(TINY, w, plan, pos, embeds, cfg)
+    ref = O.group_prefill(w, spec_o, embeds, pos, plan.tokens, O.PruneCfg(top_p=0.5))
+    assert eng.arena.len == ref["cache_len"]
+    check_logits(logits.numpy(), ref["logits"].numpy())
+    flat_ref = [k for g in ref["kept"] for k in g]
+    assert len(eng.kept_trace) == len(flat_ref)
+    tot = same = 0
+    for (l, got), want in zip(eng.kept_trace, flat_ref):
+        if want is not None:
+            g = got.cpu().numpy()
+            assert len(g) == len(want) and np.all(np.diff(g) > 0)
+            tot += len(want); same += len(set(g.tolist()) & set(want.tolist()))
+    assert same / tot >= 0.90, same / tot
+
+
 def test_engine_real_dims_one_layer():
     """One decoder layer at Qwen2-VL-7B dimensions (d=3584, 28/4 heads, I=18944), 2 groups of 320 + tail."""
     spec = TextSpec(hidden=3584, n_heads=28, n_kv_heads=4, head_dim=128, intermediate=18944, n_layers=1, vocab=1024)
