@@ -888,4 +888,7 @@ def main():
 
 
 if __name__ == "__main__":
+    import faulthandler
+    # a run that is still going after 15 minutes leaves every thread's Python stack on stderr (and again every 15 minutes)
+    faulthandler.dump_traceback_later(float(os.environ.get("QP_BENCH_STACKS_AFTER_S", "900")), repeat=True, file=sys.stderr)
     main()

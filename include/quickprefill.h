@@ -256,7 +256,9 @@ int qp_add_layernorm(qp_ctx* ctx, void* x, const void* delta, const void* w, con
  * 1 Swish z*sigmoid(z) = SiLU): fp32 accumulate + bias + activation, one rounding to bf16.  bias: bf16, or fp32 when bias_f32,
  * or NULL.  quick-GELU (y*sigmoid(1.702 y), the vision MLP's fc1): alpha = 1.702, bias pre-scaled by 1.702, act = 1 gives
  * 1.702*quick_gelu(y); the 1/1.702 goes onto the alpha of the next GEMM.  workspace: caller-owned scratch for hipBLASLt (128 MB
- * covers every shape tried; the call fails with QP_ERR_WORKSPACE if the chosen algorithm wants more). */
+ * covers every shape tried; the call fails with QP_ERR_WORKSPACE if the chosen algorithm wants more).  ONE BUFFER PER STREAM: stream-K /
+ * split-K algorithms keep partial tiles and flags there, so two GEMMs that may run concurrently (ViT stream and prefill stream) must
+ * not share it — a shared buffer corrupts both and can leave a workgroup waiting on a flag forever. */
 int qp_linear_act(qp_ctx* ctx, const void* x, const void* w, const void* bias, int bias_f32, float alpha, void* out, int64_t m,
                   int64_t n, int64_t k, int act, void* workspace, size_t workspace_bytes, void* stream);
 /* Picks the hipBLASLt algorithm later qp_linear_act calls of this (m, n, k, act, bias kind) use: every heuristic candidate is timed

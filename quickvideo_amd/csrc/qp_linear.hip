@@ -26,7 +26,10 @@ struct Plan {
 };
 
 struct LtState {
-  hipblasLtHandle_t handle = nullptr;
+  // One hipBLASLt handle PER STREAM: the library keeps device-side state per handle (the flag / partial-tile buffer of its stream-K
+  // kernels), so GEMMs of two streams that run concurrently (ViT stream and prefill stream, pipeline.py) must not go through the
+  // same handle — with one shared handle the device stalls for good in the video -> first-token leg (tools/repro_pipeline.py).
+  std::map<hipStream_t, hipblasLtHandle_t> handles;
   std::map<std::tuple<int64_t, int64_t, int64_t, int, int>, Plan> plans;   // (m, n, k, act, bias kind: 0 none, 1 bf16, 2 fp32)
   std::mutex mu;
 };
@@ -42,7 +45,20 @@ LtState& lt() {
     if (st_ != HIPBLAS_STATUS_SUCCESS) return qp_fail(QP_ERR_HIP, "qp_linear_act: %s failed (%d)", #call, (int)st_); \
   } while (0)
 
-int make_plan(Plan& p, int64_t m, int64_t n, int64_t k, int act, int bias_kind, size_t max_ws) {
+int handle_for(LtState& st, hipStream_t s, hipblasLtHandle_t* out) {
+  static const bool shared = getenv("QP_LT_SHARED_HANDLE") != nullptr;     // developer switch: reproduce the stall (tests/concurrent_gemm_check.py)
+  if (shared) s = nullptr;
+  auto it = st.handles.find(s);
+  if (it == st.handles.end()) {
+    hipblasLtHandle_t h = nullptr;
+    LT_CHECK(hipblasLtCreate(&h));
+    it = st.handles.emplace(s, h).first;
+  }
+  *out = it->second;
+  return QP_OK;
+}
+
+int make_plan(hipblasLtHandle_t handle, Plan& p, int64_t m, int64_t n, int64_t k, int act, int bias_kind, size_t max_ws) {
   const bool has_bias = bias_kind != 0;
   LT_CHECK(hipblasLtMatmulDescCreate(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F));
   const hipblasOperation_t ta = HIPBLAS_OP_T, tb = HIPBLAS_OP_N;
@@ -65,7 +81,7 @@ int make_plan(Plan& p, int64_t m, int64_t n, int64_t k, int act, int bias_kind, 
   LT_CHECK(hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &ws64, sizeof(ws64)));
   hipblasLtMatmulHeuristicResult_t res[32];
   int found = 0;
-  hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(lt().handle, p.desc, p.a, p.b, p.d, p.d, pref, 32, res, &found);
+  hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(handle, p.desc, p.a, p.b, p.d, p.d, pref, 32, res, &found);
   hipblasLtMatmulPreferenceDestroy(pref);
   if (st != HIPBLAS_STATUS_SUCCESS || found < 1)
     return qp_fail(QP_ERR_UNSUPPORTED, "qp_linear_act: hipBLASLt has no algorithm for m=%lld n=%lld k=%lld act=%d (status %d)", (long long)m,
@@ -86,13 +102,14 @@ int qp_launch_linear_act(const void* x, const void* w, const void* bias, int bia
                          int64_t k, int act, void* workspace, size_t workspace_bytes, hipStream_t s) {
   LtState& st = lt();
   std::lock_guard<std::mutex> g(st.mu);
-  if (!st.handle) LT_CHECK(hipblasLtCreate(&st.handle));
+  hipblasLtHandle_t handle = nullptr;
+  if (int rc = handle_for(st, s, &handle)) return rc;
   const int bias_kind = bias ? (bias_f32 ? 2 : 1) : 0;
   const auto key = std::make_tuple(m, n, k, act, bias_kind);
   auto it = st.plans.find(key);
   if (it == st.plans.end()) {
     Plan p;
-    int rc = make_plan(p, m, n, k, act, bias_kind, workspace_bytes);
+    int rc = make_plan(handle, p, m, n, k, act, bias_kind, workspace_bytes);
     if (rc) return rc;
     it = st.plans.emplace(key, p).first;
   }
@@ -100,7 +117,7 @@ int qp_launch_linear_act(const void* x, const void* w, const void* bias, int bia
   if (p.ws > workspace_bytes) return qp_fail(QP_ERR_WORKSPACE, "qp_linear_act: workspace %zu < %zu bytes", workspace_bytes, p.ws);
   if (bias) LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)));
   const float beta = 0.f;
-  LT_CHECK(hipblasLtMatmul(st.handle, p.desc, &alpha, w, p.a, x, p.b, &beta, out, p.d, out, p.d, &p.algo, workspace, workspace_bytes, s));
+  LT_CHECK(hipblasLtMatmul(handle, p.desc, &alpha, w, p.a, x, p.b, &beta, out, p.d, out, p.d, &p.algo, workspace, workspace_bytes, s));
   return QP_OK;
 }
 
@@ -112,13 +129,14 @@ int qp_launch_linear_tune(const void* x, const void* const* ws_list, int n_ws, c
                           int64_t m, int64_t n, int64_t k, int act, void* workspace, size_t workspace_bytes, hipStream_t s, int* chosen) {
   LtState& st = lt();
   std::lock_guard<std::mutex> g(st.mu);
-  if (!st.handle) LT_CHECK(hipblasLtCreate(&st.handle));
+  hipblasLtHandle_t handle = nullptr;
+  if (int rc = handle_for(st, s, &handle)) return rc;
   const int bias_kind = bias ? (bias_f32 ? 2 : 1) : 0;
   const auto key = std::make_tuple(m, n, k, act, bias_kind);
   auto it = st.plans.find(key);
   if (it == st.plans.end()) {
     Plan p;
-    int rc = make_plan(p, m, n, k, act, bias_kind, workspace_bytes);
+    int rc = make_plan(handle, p, m, n, k, act, bias_kind, workspace_bytes);
     if (rc) return rc;
     it = st.plans.emplace(key, p).first;
   }
@@ -135,7 +153,7 @@ int qp_launch_linear_tune(const void* x, const void* const* ws_list, int n_ws, c
     for (int rep = -2; rep < n_ws && ok; ++rep) {               // two untimed runs, then one pass over the weight list
       if (rep == 0) (void)hipEventRecord(e0, s);
       const void* w = ws_list[(rep + 2 * n_ws) % n_ws];
-      ok = hipblasLtMatmul(st.handle, p.desc, &alpha, w, p.a, x, p.b, &beta, out, p.d, out, p.d, &p.cands[c].algo, workspace, workspace_bytes,
+      ok = hipblasLtMatmul(handle, p.desc, &alpha, w, p.a, x, p.b, &beta, out, p.d, out, p.d, &p.cands[c].algo, workspace, workspace_bytes,
                            s) == HIPBLAS_STATUS_SUCCESS;
     }
     (void)hipEventRecord(e1, s);

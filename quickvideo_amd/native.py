@@ -126,6 +126,7 @@ class QuickPrefillOps:
         self.ctx = h
         self._select_ws = torch.empty(int(self.lib.qp_select_workspace_bytes(65536)), dtype=torch.uint8, device=self.device)
         self._attn_ws = None
+        self._lt_ws = {}                          # hipBLASLt scratch, one buffer per stream (see _lt_workspace)
 
     def __del__(self):
         try:
@@ -326,26 +327,34 @@ class QuickPrefillOps:
 
     ACT_NONE, ACT_SWISH = 0, 1
 
+    def _lt_workspace(self):
+        """hipBLASLt scratch of the CURRENT stream.  One buffer per stream: stream-K / split-K GEMMs keep partial tiles and flags in it,
+        and the ViT stream's GEMMs run concurrently with the prefill's (pipeline.py) — sharing one buffer between them corrupts both and
+        can leave a stream-K workgroup spinning on a flag forever (seen as a stuck device in the video -> first-token leg)."""
+        key = self._stream()
+        ws = self._lt_ws.get(key)
+        if ws is None:
+            ws = self._lt_ws[key] = torch.empty(128 << 20, dtype=torch.uint8, device=self.device)
+        return ws
+
     def linear_act(self, x, w, bias, out, act, alpha=1.0):
         """out = act(alpha * x w^T + bias) as one hipBLASLt GEMM with the activation in the epilogue (bias bf16 or fp32)."""
         m, k = x.shape
         n = w.shape[0]
-        if getattr(self, "_lt_ws", None) is None:
-            self._lt_ws = torch.empty(128 << 20, dtype=torch.uint8, device=self.device)
+        ws = self._lt_workspace()
         f32 = 1 if (bias is not None and bias.dtype == torch.float32) else 0
         self._check(self.lib.qp_linear_act(self.ctx, x.data_ptr(), w.data_ptr(), _ptr(bias), f32, float(alpha), out.data_ptr(), m, n, k, act,
-                                           self._lt_ws.data_ptr(), self._lt_ws.numel(), self._stream()))
+                                           ws.data_ptr(), ws.numel(), self._stream()))
 
     def linear_tune(self, x, weights, bias, out, act=0, alpha=1.0):
         """Time hipBLASLt's candidates for out = act(alpha x w^T + bias) over the given weight tensors (cold, round-robin); keep the best."""
         m, k = x.shape
         n = weights[0].shape[0]
-        if getattr(self, "_lt_ws", None) is None:
-            self._lt_ws = torch.empty(128 << 20, dtype=torch.uint8, device=self.device)
+        ws = self._lt_workspace()
         arr = (_vp * len(weights))(*[w.data_ptr() for w in weights])
         f32 = 1 if (bias is not None and bias.dtype == torch.float32) else 0
         self._check(self.lib.qp_linear_tune(self.ctx, x.data_ptr(), arr, len(weights), _ptr(bias), f32, float(alpha), out.data_ptr(), m, n, k,
-                                            act, self._lt_ws.data_ptr(), self._lt_ws.numel(), self._stream()))
+                                            act, ws.data_ptr(), ws.numel(), self._stream()))
 
     def quick_gelu(self, x, out):
         self._check(self.lib.qp_quick_gelu(self.ctx, x.data_ptr(), out.data_ptr(), x.numel(), self._stream()))

@@ -9,6 +9,7 @@ built before any pixel exists from (nframes, H, W) alone, like the reference's d
 """
 from __future__ import annotations
 
+import os
 import queue
 import threading
 import time
@@ -55,6 +56,29 @@ class Timings:
     ttft: float = 0.0           # first frame requested -> first token id on the host
     tokens: int = 0
     groups: int = 0
+
+
+class _GpuProgress(threading.Thread):
+    """QP_PIPELINE_DEBUG=1: every 5 s, how many groups the host has enqueued and how many ViT passes / group prefills the GPU has
+    finished (event queries), on stderr — tells a slow device from a stuck one."""
+
+    def __init__(self, n_groups):
+        super().__init__(daemon=True)
+        self.n, self.vit, self.pre, self.halt, self.t0 = n_groups, [], [], threading.Event(), time.perf_counter()
+        self.start()
+
+    def enqueued(self, vit_done, prefill_done):
+        self.vit.append(vit_done); self.pre.append(prefill_done)
+
+    def run(self):
+        import sys
+        while not self.halt.wait(5.0):
+            nv, npf = sum(e.query() for e in list(self.vit)), sum(e.query() for e in list(self.pre))
+            print(f"[pipeline {time.perf_counter() - self.t0:6.1f}s] enqueued {len(self.pre)}/{self.n} groups; finished on the GPU: "
+                  f"{nv} ViT passes, {npf} group prefills", file=sys.stderr, flush=True)
+
+    def stop(self):
+        self.halt.set()
 
 
 class _Producer(threading.Thread):
@@ -239,6 +263,7 @@ class PrefillPipeline:
 
         t_pre = time.perf_counter()
         start, vit_events = 0, []
+        dbg = _GpuProgress(len(plan.tokens)) if (self.use_gpu and os.environ.get("QP_PIPELINE_DEBUG")) else None
         # query-based predict types: the prompt (everything after the last video token) is appended to every group and scores its
         # keys (qwen25_lvu.py:661-664, 684-689); positions are then the group's AND the next tail_len of the sequence
         q_m = plan.tail_len if (self.cfg.query_based and self.cfg.enable) else 0
@@ -260,7 +285,11 @@ class PrefillPipeline:
             eng.prefill_group(emb, pos[:, start:start + n + q_m], prompt_embeds=tail_emb)
             prod.release(g, read_done)
             start += n
+            if dbg is not None:
+                dbg.enqueued(evs[1], torch.cuda.current_stream(dev).record_event())
         sync()
+        if dbg is not None:
+            dbg.stop()
         tm.prefill = time.perf_counter() - t_pre
         tm.tokens, tm.groups = start, len(plan.tokens)
         t_dec = time.perf_counter()

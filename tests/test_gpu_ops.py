@@ -868,3 +868,22 @@ def test_linear_tuned_candidate_at_group_size(ops):
             rows = torch.arange(0, m, 97, device="cuda")
             ref32 = x[rows].float() @ w.float().t() + (bias.float() if bias is not None else 0.0)
             assert (out[rows].float() - ref32).abs().max().item() <= 2 ** -7 * scale
+
+
+def test_linear_act_on_two_streams_concurrently():
+    """The ViT stream's GEMMs overlap the prefill's (pipeline.py).  hipBLASLt keeps device-side state per HANDLE and its stream-K / split-K
+    kernels keep partial tiles in the WORKSPACE, so both are per stream in qp_linear.hip / native.py.  (a) results of interleaved GEMM
+    streams stay exact; (b) the video -> first-token leg of bench.py on the 6-minute video, where ONE shared handle stalled the device
+    for good in 5 runs of 6 (tools/repro_pipeline.py, QP_LT_SHARED_HANDLE=1 brings the old behaviour back).  Subprocesses with a
+    timeout: a regression must not wedge the test session."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PYTHONPATH=root)
+    env.pop("QP_LT_SHARED_HANDLE", None)
+    p = subprocess.run([sys.executable, os.path.join(root, "tests", "concurrent_gemm_check.py"), "40"], capture_output=True, text=True,
+                       timeout=240, cwd=root, env=env)
+    assert p.returncode == 0, (p.stdout[-500:], p.stderr[-1500:])
+    for _ in range(3):
+        p = subprocess.run([sys.executable, os.path.join(root, "tools", "repro_pipeline.py"), "cfg4s"], capture_output=True, text=True,
+                           timeout=180, cwd=root, env=env)
+        assert p.returncode == 0 and '"ttft_ms"' in p.stdout, (p.stdout[-500:], p.stderr[-1500:])
