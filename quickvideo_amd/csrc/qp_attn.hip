@@ -571,7 +571,7 @@ int qp_launch_prefill_attn(const qp_ctx* ctx, const void* q, const void* k_prefi
   p.items = p.nqb * p.group; p.n_whole = p.items; p.nsplit = 1;
   p.heads_per_seq = hkv; p.seq_stride16 = 0; p.kv_row_bytes = 256; p.cu_seqlens = nullptr;
   { const char* pm = getenv("QP_S6_PRIO"); p.prio_mode = pm ? atoi(pm) & 3 : 0; }
-  { const char* eo = getenv("QP_S6_EARLY_OUT"); if (eo) p.prio_mode |= (atoi(eo) & 3) << 2; }     // experiment, see qp_attn_s6.hip
+  { const char* eo = getenv("QP_S6_EARLY_OUT"); p.prio_mode |= ((eo ? atoi(eo) : 3) & 3) << 2; }   // A/B switch, see qp_attn_s6.hip
   p.q_row0 = (int)q_row0; p.nq = (int)nq; p.qb_rows = kQB;
   const char* var = getenv("QP_ATTN_VARIANT");        // developer A/B switch (tools/bench_attn.py); default = production kernel
   const int variant = var ? atoi(var) : 0;
