@@ -87,3 +87,29 @@ def test_pipelined_attention_kernel_does_not_spill(src_name, kernel, min_kernels
         assert int(re.search(r"ScratchSize \[bytes/lane\]: (\d+)", b).group(1)) == 0, b[:400]
         assert int(re.search(r"VGPRs: (\d+)", b).group(1)) <= 256
     assert seen >= min_kernels
+
+
+C_CALLER = os.path.join(ROOT, "tests", "c", "abi_prune_attn.c")
+
+
+def build_c_caller(out):
+    """gcc, plain C99: the boundary is a C ABI (no C++ types, no torch types), and a C program links against the library."""
+    import subprocess
+    from quickvideo_amd import native
+    lib_dir = os.path.dirname(native.LIB_PATH)
+    cmd = ["gcc", "-std=c99", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"), C_CALLER, "-o", out,
+           "-L" + lib_dir, "-lquickprefill", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"]
+    p = subprocess.run(cmd, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+
+
+def test_header_is_plain_c_and_library_has_no_torch_dependency(tmp_path):
+    import subprocess
+    from quickvideo_amd import native
+    p = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", os.path.join(ROOT, "include", "quickprefill.h")],
+                       capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr
+    needed = subprocess.run(["readelf", "-d", native.LIB_PATH], capture_output=True, text=True).stdout
+    libs = re.findall(r"NEEDED.*\[(.*?)\]", needed)
+    assert libs and not [l for l in libs if re.search(r"torch|c10|python", l)], libs
+    build_c_caller(str(tmp_path / "abi_c"))                     # compiles and links here; runs on the GPU box (tests/test_gpu_ops.py)

@@ -887,3 +887,15 @@ def test_linear_act_on_two_streams_concurrently():
         p = subprocess.run([sys.executable, os.path.join(root, "tools", "repro_pipeline.py"), "cfg4s"], capture_output=True, text=True,
                            timeout=180, cwd=root, env=env)
         assert p.returncode == 0 and '"ttft_ms"' in p.stdout, (p.stdout[-500:], p.stderr[-1500:])
+
+
+def test_c_abi_from_a_plain_c_program(tmp_path):
+    """tests/c/abi_prune_attn.c: a C99 program (gcc, no torch, no Python in the process) drives seam 1 (qp_prune_tail: kept indices and
+    compacted rows exact) and seam 3 (qp_prefill_attn with one visible key: output == value row) through include/quickprefill.h."""
+    import subprocess
+    from tests.test_abi import build_c_caller
+    exe = str(tmp_path / "abi_c")
+    build_c_caller(exe)
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0, (p.stdout, p.stderr[-1000:])
+    assert "kept indices and compacted rows exact" in p.stdout and "output row equals the value row" in p.stdout
