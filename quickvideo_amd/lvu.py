@@ -69,7 +69,13 @@ def _load_hf_dir(path: str, device) -> QwenVLNative:
                     sd[k] = sf.get_tensor(k)
     text = {k.split("model.", 1)[-1].replace("language_model.", ""): v for k, v in sd.items() if "visual" not in k}
     vis = {k.split("visual.", 1)[1]: v for k, v in sd.items() if "visual." in k}
-    return QwenVLNative(DecoderWeights.from_named(spec, text, device), VisionWeights.from_named(vspec, vis, device), device, name=path)
+    gen = None
+    gpath = os.path.join(path, "generation_config.json")           # HF `generate` applies it implicitly (Qwen2.5-VL ships do_sample /
+    if os.path.exists(gpath):                                       # temperature 1e-6 / top_k 1 / top_p 0.001 / repetition_penalty 1.05)
+        g = json.load(open(gpath))
+        gen = {k: g[k] for k in ("do_sample", "temperature", "top_k", "top_p", "repetition_penalty") if k in g}
+    return QwenVLNative(DecoderWeights.from_named(spec, text, device), VisionWeights.from_named(vspec, vis, device), device, name=path,
+                        generation_defaults=gen)
 
 
 class LVU:

@@ -25,6 +25,7 @@ from .decode import GraphDecoder
 from .frames import open_video, smart_nframes
 from .native import host_memcpy
 from .lvu_config import LVUConfig, effective_k
+from .sampling import TokenSelector
 from .spec import TextSpec
 from .vit import VisionTower, VisionWeights, patchify_frames
 from .weights import DecoderWeights
@@ -40,6 +41,7 @@ class QwenVLNative:
     rope_deltas: Optional[int] = None
     engine: Optional[QuickPrefillEngine] = None
     config: Optional[LVUConfig] = None
+    generation_defaults: Optional[dict] = None      # the checkpoint's generation_config.json (HF generate applies it implicitly)
 
     @property
     def spec(self) -> TextSpec:
@@ -214,11 +216,17 @@ class PrefillPipeline:
     # ------------------------------------------------------------------ video -> tokens
     @torch.no_grad()
     def generate(self, question: str, video, max_new_tokens: int = 16, overlap: bool = True, eos_token_id: Optional[int] = None,
-                 **unused) -> List[int]:
-        # decoding is greedy (what the reference's Qwen2-VL generation config amounts to: top_k = 1); anything else is refused
-        # rather than silently ignored
-        if (unused.get("do_sample") and unused.get("top_k") != 1) or unused.get("num_beams", 1) != 1:
-            raise NotImplementedError("the native engine decodes greedily: do_sample (other than top_k=1) and beam search are not implemented")
+                 do_sample: Optional[bool] = None, temperature: Optional[float] = None, top_k: Optional[int] = None,
+                 top_p: Optional[float] = None, repetition_penalty: Optional[float] = None, seed: Optional[int] = None,
+                 num_beams: int = 1, **unused) -> List[int]:
+        """generation kwargs as the reference hands them to HF `generate` (qwen25_lvu.py:744-761); unset ones fall back to the
+        checkpoint's generation_config.json (`model.generation_defaults`), then to greedy.  Beam search is refused, not ignored."""
+        if num_beams != 1:
+            raise NotImplementedError("beam search is not implemented (greedy and sampling with temperature / top-k / top-p / repetition penalty are)")
+        gd = getattr(self.model, "generation_defaults", None) or {}
+        pick = lambda v, k: gd.get(k) if v is None else v
+        selector = TokenSelector(pick(do_sample, "do_sample") or False, pick(temperature, "temperature"), pick(top_k, "top_k"),
+                                 pick(top_p, "top_p"), pick(repetition_penalty, "repetition_penalty"), seed, device=self.model.device)
         tm = Timings()
         dev = self.model.device
         t_e2e = time.perf_counter()
@@ -294,19 +302,28 @@ class PrefillPipeline:
         tm.tokens, tm.groups = start, len(plan.tokens)
         t_dec = time.perf_counter()
         logits = eng.prefill_tail(eng.embed_tokens(tail), pos[:, start:])     # pruning off for the tail (qwen25_lvu.py:737-742)
-        tok = int(torch.argmax(logits).item())                                # first token on the host = TTFT point
+        if not selector.trivial:                                               # HF processors see the whole prompt (video pads included)
+            selector.observe(list(P["prompt"].prefix_ids) + [self.model.spec.video_token_id] + list(P["prompt"].tail_ids),
+                             logits.shape[-1], dev)
+        tok = selector.select(logits) if not selector.trivial else int(torch.argmax(logits).item())   # first token on the host = TTFT point
         tm.ttft = time.perf_counter() - t_e2e
         out = [tok]
-        if GraphDecoder.supported(eng):                                       # one hipGraph replay per token (decode.py)
-            if getattr(eng, "_graph_decoder", None) is None:
-                eng._graph_decoder = GraphDecoder(eng)
+        graph = GraphDecoder.supported(eng)                                   # one hipGraph replay per token (decode.py)
+        if graph and getattr(eng, "_graph_decoder", None) is None:
+            eng._graph_decoder = GraphDecoder(eng)
+        if graph and selector.trivial:                                        # argmax stays on the device inside the graph
             out += eng._graph_decoder.generate(tok, max_new_tokens - 1, P["delta"], eos_token_id)
-        else:                                                                 # per-op path (CPU test doubles, parallel engines)
+        else:                                                                 # logits come back per step: processors / sampling, or the
+            if graph and max_new_tokens > 1:                                  # per-op path (CPU test doubles, parallel engines)
+                eng._graph_decoder.begin(P["delta"])
             for _ in range(max_new_tokens - 1):
                 if eos_token_id is not None and tok == eos_token_id:
                     break
-                logits = eng.decode_step(eng.embed_tokens(torch.tensor([tok], device=dev)), P["delta"])
-                tok = int(torch.argmax(logits).item())
+                if graph:
+                    logits = eng._graph_decoder.step(tok)
+                else:
+                    logits = eng.decode_step(eng.embed_tokens(torch.tensor([tok], device=dev)), P["delta"])
+                tok = selector.select(logits)
                 out.append(tok)
         sync()
         tm.decode = time.perf_counter() - t_dec

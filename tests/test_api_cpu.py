@@ -545,3 +545,49 @@ def test_producer_ring_fill_is_native_and_gil_free():
     alone = rate(None)
     native = rate(lambda: host_memcpy(b, a, 2))
     assert native > 0.3 * alone, (native, alone)        # a GIL-holding 10 ms copy loop would leave ~1/3 or less (5 ms switch interval)
+
+
+def test_generation_kwargs_like_hf_generate():
+    """The reference hands **generation_kwargs to HF `generate` (qwen25_lvu.py:744-761).  TokenSelector restates its logits processing:
+    (a) processed scores equal the installed transformers processors / warpers on random logits, (b) through LVU.generate: sampling
+    is reproducible under a seed, top_k=1 sampling equals greedy, a large repetition penalty changes the greedy continuation,
+    beam search is refused, generation_config.json defaults are honoured."""
+    import lvu
+    from transformers.generation.logits_process import (RepetitionPenaltyLogitsProcessor, TemperatureLogitsWarper, TopKLogitsWarper,
+                                                        TopPLogitsWarper)
+    from quickvideo_amd.lvu import load_native_model
+    from quickvideo_amd.sampling import TokenSelector
+    g = torch.Generator().manual_seed(0)
+    V = 5000
+    for trial, (T, k, p, rp) in enumerate([(0.7, 50, 0.9, 1.05), (1.0, 0, 0.5, 1.3), (1e-6, 1, 0.001, 1.05), (2.0, 7, 1.0, 1.0), (0.3, 0, 0.05, 1.0)] * 3):
+        logits = torch.randn(V, generator=g) * 3
+        ids = torch.randint(0, V, (1, 50), generator=g)
+        ref = logits[None].clone()
+        if rp != 1.0: ref = RepetitionPenaltyLogitsProcessor(rp)(ids, ref)
+        if T != 1.0: ref = TemperatureLogitsWarper(T)(ids, ref)
+        if k > 0: ref = TopKLogitsWarper(k)(ids, ref)
+        if p < 1.0: ref = TopPLogitsWarper(p)(ids, ref)
+        ts = TokenSelector(True, T, k, p, rp, seed=1)
+        ts.observe(ids[0].tolist(), V, "cpu")
+        got = ts.process(logits)
+        assert torch.equal(torch.isinf(got), torch.isinf(ref[0])) and torch.allclose(got[~torch.isinf(got)], ref[0][~torch.isinf(ref[0])])
+    with pytest.raises(ValueError):
+        TokenSelector(True, temperature=0.0)
+    m = load_native_model("synthetic:tiny", device="cpu")
+    obj = lvu.LVU(lvu.LVUConfig("synthetic:tiny", top_p=0.5, video_group_size=4, num_frames=8), model=m)
+    obj._ops = OracleOps()
+    video = "synthetic://?frames=16&h=56&w=84&fps=2&seed=3"
+    run = lambda **kw: obj.generate("What happens?", video, max_new_tokens=6, eos_token_id=None, **kw)[0]
+    greedy = run()
+    assert run(do_sample=True, top_k=1) == greedy                                        # Qwen2-VL's shipped config without the penalty
+    a, b = run(do_sample=True, temperature=5.0, seed=11), run(do_sample=True, temperature=5.0, seed=11)
+    assert a == b and a.count("<tok_") == 6
+    assert len({run(do_sample=True, temperature=5.0, seed=s) for s in range(4)}) > 1      # it does sample
+    # a huge penalty forbids (positive-logit) repeats of prompt or generated ids: the continuation has no duplicate and differs from greedy if greedy repeats
+    pen = run(repetition_penalty=1e6)
+    toks = pen.split()
+    assert len(set(toks)) == len(toks)
+    with pytest.raises(NotImplementedError):
+        run(num_beams=4)
+    m.generation_defaults = {"do_sample": True, "temperature": 5.0}                      # generation_config.json of a checkpoint
+    assert len({run(seed=s) for s in range(4)}) > 1 and run(do_sample=False) == greedy   # explicit kwargs win

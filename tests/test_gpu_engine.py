@@ -276,6 +276,25 @@ def test_lvu_generate_on_gpu(capsys):
     assert "total time spent on prefill was" in capsys.readouterr().out
 
 
+def test_generation_kwargs_on_gpu(monkeypatch):
+    """HF-style generation kwargs on the GPU: the hipGraph decoder fed token by token (logits back to the selector each step) gives the
+    same continuation as the per-op decode path; seeded sampling is reproducible; top_k=1 sampling is greedy."""
+    import lvu
+    from quickvideo_amd.decode import GraphDecoder
+    from quickvideo_amd.lvu import load_native_model
+    m = load_native_model("synthetic:tiny", device="cuda:0", seed=3)
+    video = "synthetic://?frames=48&h=112&w=168&seed=2&pattern=gradient"
+    obj = lvu.LVU(lvu.LVUConfig("synthetic:tiny", top_p=0.5, video_group_size=4, num_frames=16), model=m)
+    run = lambda **kw: obj.generate("What is shown?", video, max_new_tokens=8, eos_token_id=None, **kw)[0]
+    greedy = run()
+    assert run(do_sample=True, top_k=1) == greedy
+    pen_graph = run(repetition_penalty=1.3)
+    samp_graph = run(do_sample=True, temperature=3.0, top_p=0.9, seed=5)
+    assert samp_graph == run(do_sample=True, temperature=3.0, top_p=0.9, seed=5) and samp_graph.count("<tok_") == 8
+    monkeypatch.setattr(GraphDecoder, "supported", staticmethod(lambda eng: False))
+    assert run(repetition_penalty=1.3) == pen_graph and run() == greedy
+
+
 @pytest.mark.parametrize("mode", ["key_norms", "vector_norms", "vector_norms_small"])
 def test_engine_other_norm_modes_vs_oracle(mode):
     """qp_set_prune_mode through the engine: the other norm-based predict types against the composite oracle."""
