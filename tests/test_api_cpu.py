@@ -240,8 +240,10 @@ def test_load_hf_checkpoint_directory(tmp_path):
     obj = lvu.LVU(lvu.LVUConfig(str(tmp_path), top_p=0.5, video_group_size=4, num_frames=8), model=m)
     obj._ops = OracleOps()
     out = obj.generate("hi", "synthetic://?frames=16&h=56&w=84&seed=1", max_new_tokens=2)
-    with pytest.raises(NotImplementedError):                       # sampling / beams are refused, not ignored
-        obj.generate("hi", "synthetic://?frames=16&h=56&w=84&seed=1", max_new_tokens=2, do_sample=True, temperature=0.7)
+    with pytest.raises(NotImplementedError):                       # beam search is refused, not ignored
+        obj.generate("hi", "synthetic://?frames=16&h=56&w=84&seed=1", max_new_tokens=2, num_beams=2)
+    assert obj.generate("hi", "synthetic://?frames=16&h=56&w=84&seed=1", max_new_tokens=2, do_sample=True, temperature=0.7,
+                        seed=1)[0].count("<tok_") == 2
     assert obj.generate("hi", "synthetic://?frames=16&h=56&w=84&seed=1", max_new_tokens=2, do_sample=True, top_k=1) == out
     assert out[0].count("<tok_") == 2
 
