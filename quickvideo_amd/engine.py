@@ -104,6 +104,7 @@ class QuickPrefillEngine:
         self.b_ss = e(self.hkv, n, dtype=torch.float32)
         self.b_ss_all = e(self.tp_size, self.hkv, n, dtype=torch.float32) if self.tp_size > 1 else None
         self.b_idx = e(n, dtype=torch.int32)
+        self.b_idx_pp = e(n, dtype=torch.int32) if self.pp_size > 1 else None   # original rows of a hidden-pruned hand-off
         # prune through 16-bit norm keys (qp_prune_keys): the keys of the group's tokens, written by the RoPE kernel
         self._keys_path = hasattr(self.ops, "prune_keys") and self.device.type == "cuda"
         if self._keys_path:
@@ -307,19 +308,24 @@ class QuickPrefillEngine:
         return allb[::rep].contiguous(), total
 
     # ------------------------------------------------------------------ one segment through all layers
-    def forward_segment(self, embeds: torch.Tensor, pos: torch.Tensor, prune: bool, video_group: bool = False) -> torch.Tensor:
+    def forward_segment(self, embeds: torch.Tensor, pos: torch.Tensor, prune: bool, video_group: bool = False,
+                        row_idx: Optional[torch.Tensor] = None) -> torch.Tensor:
         """embeds [n, d] (device, engine dtype), pos int64 [3, n].  Returns the final hidden rows [n', d] (pre-norm)
-        (group-token parallel segments: this rank's rows only)."""
+        (group-token parallel segments: this rank's rows only).  row_idx (layer-pipeline stages behind a stage that pruned the hidden
+        rows, prefill_prune_starting_layer): embeds holds rows `row_idx` of the n-token segment, ascending.  self._seg_rows is left
+        as the original row indices of the returned rows (None = all n)."""
         s, ops, cfg, D = self.spec, self.ops, self.cfg, self.D
         n = pos.shape[1]                             # embeds may hold only this rank's rows (sp stage behind another stage)
         assert n <= self.n_max, f"group of {n} tokens exceeds max_group_tokens={self.n_max}"
+        self._seg_rows = row_idx
         if self._sp_active(n):
             return self._forward_segment_sp(embeds, pos, prune, video_group)
+        if row_idx is not None:                      # positions of the surviving rows only (utils.py:344-372 gathers them the same way)
+            pos = pos.index_select(1, row_idx.long())
+            n = pos.shape[1]
         assert embeds.shape[0] == n
         L = self.n_layers_total                      # effective_k's decay uses the GLOBAL layer index / count
         cos, sin = ops.mrope_table(pos.contiguous(), s.mrope_section, s.rope_theta, D)
-        if self.pp_size > 1 and prune and cfg.enable and isinstance(cfg.prefill_prune_starting_layer, int) and cfg.prefill_prune_starting_layer >= 0:
-            raise NotImplementedError("hidden-state pruning (prefill_prune_starting_layer) is not combined with the layer pipeline")
         hbufs, hsel = (self.b_h, self.b_h2), 0
         h = hbufs[0][:n]
         h.copy_(embeds)
@@ -366,7 +372,7 @@ class QuickPrefillEngine:
             self._linear("o", att.view(n, self.hq * D), lw.w_o, o)           # o_proj                        (:114-115)
             self._all_reduce(o)
             prune_hidden = (k_keep is not None and cfg.enable and isinstance(cfg.prefill_prune_starting_layer, int)
-                            and cfg.prefill_prune_starting_layer >= 0 and l >= cfg.prefill_prune_starting_layer)
+                            and cfg.prefill_prune_starting_layer >= 0 and self.l0 + l >= cfg.prefill_prune_starting_layer)   # GLOBAL layer index
             if k_keep is not None:                                           # post_process_kv_cache         (:183-192)
                 idx = self.b_idx[:k_keep]
                 if fuse:
@@ -390,6 +396,8 @@ class QuickPrefillEngine:
                 ops.gather_rows(cos, idx, k_keep, cos.shape[1] * cos.element_size(), c2)
                 ops.gather_rows(sin, idx, k_keep, sin.shape[1] * sin.element_size(), s2)
                 h, cos, sin, n = hk, c2, s2, k_keep
+                if self.pp_size > 1:                                         # the next stage needs the survivors' ORIGINAL rows
+                    self._seg_rows = idx.clone() if self._seg_rows is None else self._seg_rows.index_select(0, idx.long())
                 x2 = self.b_x[:n]
                 ops.add_rmsnorm(h, None, lw.ln2, x2, s.rms_eps)
             else:
@@ -597,21 +605,55 @@ class QuickPrefillEngine:
         # several ranks on one GPU; RCCL point-to-point is stream-ordered and takes the device buffer directly)
         return t.is_cuda and torch.distributed.get_backend(self._pp_p2p_group()) == "gloo"
 
-    def _pp_in(self, embeds: torch.Tensor) -> torch.Tensor:
-        if self.pp_size == 1 or self.pp_rank == 0:
-            return embeds
-        buf = self.b_h2[: self._pp_rows(embeds.shape[0])]
+    def _hidden_prune_on(self, prune: bool) -> bool:
+        p = self.cfg.prefill_prune_starting_layer
+        return bool(prune and self.cfg.enable and isinstance(p, int) and p >= 0)
+
+    def _rows_entering_stage(self, n: int, prune: bool):
+        """Hidden rows of an n-token segment that reach this stage's first layer: the earlier stages' hidden-state prunes
+        (prefill_prune_starting_layer, utils.py:292-331) are a function of (n, config, layer index) alone, so both ends of a
+        hand-off agree on the row count without a message.  -> (rows, whether any earlier layer pruned the hidden rows)."""
+        if not self._hidden_prune_on(prune):
+            return n, False
+        cur, pruned, L, pps = n, False, self.n_layers_total, self.cfg.prefill_prune_starting_layer
+        for l in range(self.l0):
+            k = effective_k(cur, self.cfg, l, L)
+            if k is not None and l >= pps:
+                cur, pruned = k, True
+        return cur, pruned
+
+    def _pp_recv(self, buf: torch.Tensor):
+        src, grp = self._pp_peer(self.pp_rank - 1), self._pp_p2p_group()
         if self._pp_host_staged(buf):
             host = torch.empty(buf.shape, dtype=buf.dtype)
-            torch.distributed.recv(host, src=self._pp_peer(self.pp_rank - 1), group=self._pp_p2p_group())
+            torch.distributed.recv(host, src=src, group=grp)
             buf.copy_(host)
         else:
-            torch.distributed.recv(buf, src=self._pp_peer(self.pp_rank - 1), group=self._pp_p2p_group())
-        return buf
+            torch.distributed.recv(buf, src=src, group=grp)
+
+    def _pp_in(self, embeds: torch.Tensor, n: Optional[int] = None, prune: bool = False):
+        """-> (hidden rows entering this stage, their original row indices or None)."""
+        if self.pp_size == 1 or self.pp_rank == 0:
+            return embeds, None
+        n = embeds.shape[0] if n is None else n
+        rows, pruned = self._rows_entering_stage(n, prune)
+        if not pruned:
+            buf = self.b_h2[: self._pp_rows(n)]
+            self._pp_recv(buf)
+            return buf, None
+        buf, idx = self.b_h2[:rows], self.b_idx_pp[:rows]           # a stage before this one pruned the hidden rows
+        self._pp_recv(buf)
+        self._pp_recv(idx)
+        return buf, idx
 
     def _pp_out(self, h: torch.Tensor):
         if self.pp_size > 1 and self.pp_rank < self.pp_size - 1:
-            torch.distributed.send(h.cpu() if self._pp_host_staged(h) else h, dst=self._pp_peer(self.pp_rank + 1), group=self._pp_p2p_group())
+            dst, grp = self._pp_peer(self.pp_rank + 1), self._pp_p2p_group()
+            torch.distributed.send(h.cpu() if self._pp_host_staged(h) else h, dst=dst, group=grp)
+            rows = getattr(self, "_seg_rows", None)
+            if rows is not None:
+                rows = rows.to(torch.int32).contiguous()
+                torch.distributed.send(rows.cpu() if self._pp_host_staged(rows) else rows, dst=dst, group=grp)
 
     @property
     def is_last_stage(self) -> bool:
@@ -630,7 +672,8 @@ class QuickPrefillEngine:
             self._forward_segment_query(torch.cat([embeds, prompt_embeds], 0), pos, m)
             self.seq_pos += embeds.shape[0]
             return
-        h = self.forward_segment(self._pp_in(embeds), pos, prune=True, video_group=True)
+        x, rows = self._pp_in(embeds, pos.shape[1], prune=True)
+        h = self.forward_segment(x, pos, prune=True, video_group=True, row_idx=rows)
         self._pp_out(h)
         self.seq_pos += embeds.shape[0]
 
@@ -638,7 +681,9 @@ class QuickPrefillEngine:
         """Prompt tail over the pruned cache, no pruning (qwen25_lvu.py:724-742, enable = do_top_k_for_query).
         Returns fp32 logits [V] of the last position = distribution of the first generated token (TTFT point); None on
         layer-pipeline stages other than the last."""
-        h = self.forward_segment(self._pp_in(embeds), pos, prune=bool(self.cfg.do_top_k_for_query))
+        pr = bool(self.cfg.do_top_k_for_query)
+        x, rows = self._pp_in(embeds, pos.shape[1], prune=pr)
+        h = self.forward_segment(x, pos, prune=pr, row_idx=rows)
         self._pp_out(h)
         self.seq_pos += embeds.shape[0]
         return self.logits_last(h) if self.is_last_stage else None
@@ -658,7 +703,8 @@ class QuickPrefillEngine:
         (HF generate with the caller-supplied cache_position, qwen25_lvu.py:445-464, 740)."""
         p = self.seq_pos + rope_delta
         pos = torch.full((3, 1), p, dtype=torch.int64, device=self.device)
-        h = self.forward_segment(self._pp_in(token_embed.view(1, -1)), pos, prune=bool(self.cfg.do_top_k_for_query))
+        x, rows = self._pp_in(token_embed.view(1, -1), 1, prune=bool(self.cfg.do_top_k_for_query))
+        h = self.forward_segment(x, pos, prune=bool(self.cfg.do_top_k_for_query), row_idx=rows)
         self._pp_out(h)
         self.seq_pos += 1
         return self.logits_last(h) if self.is_last_stage else None

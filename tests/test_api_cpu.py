@@ -306,7 +306,7 @@ def test_group_token_parallel_gloo(world):
 
 
 # ---------------------------------------------------------------- layer pipeline over gloo (world_size 2 and 3)
-def _pp_worker(rank, world, port, ret):
+def _pp_worker(rank, world, port, ret, pps=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
@@ -323,7 +323,8 @@ def _pp_worker(rank, world, port, ret):
     T = sum(groups) + 7
     embeds = torch.from_numpy(rs.standard_normal((T, 256)).astype(np.float32) * 0.5).to(torch.bfloat16)
     pos = torch.from_numpy(np.tile(np.arange(T, dtype=np.int64), (3, 1)))
-    cfg = LVUConfig("x", top_p=0.5, video_group_size=4, top_k_decay_type="linear", top_k_decay_factor=0.5)   # decay: global layer index matters
+    cfg = LVUConfig("x", top_p=0.5, video_group_size=4, top_k_decay_type="linear", top_k_decay_factor=0.5,   # decay: global layer index matters
+                    prefill_prune_starting_layer=pps)                   # pps: the hidden rows shrink from that layer on, across stages
 
     def run(eng):
         eng.kept_trace = []
@@ -355,12 +356,13 @@ def _pp_worker(rank, world, port, ret):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_layer_pipeline_gloo(world):
-    """Layer-pipeline stages reproduce the single-process engine exactly (same ops in the same order; the hand-off is a copy)."""
-    port = 35500 + os.getpid() % 2000 + world
+@pytest.mark.parametrize("world,pps", [(2, None), (3, None), (2, 1), (3, 0), (4, 2)])
+def test_layer_pipeline_gloo(world, pps):
+    """Layer-pipeline stages reproduce the single-process engine exactly (same ops in the same order; the hand-off is a copy) — also
+    with hidden-state pruning (prefill_prune_starting_layer): the hand-off then carries the surviving rows and their original indices."""
+    port = 35500 + os.getpid() % 2000 + world * 7 + (0 if pps is None else pps + 1)
     ret = mp.Manager().dict()
-    mp.spawn(_pp_worker, args=(world, port, ret), nprocs=world, join=True)
+    mp.spawn(_pp_worker, args=(world, port, ret, pps), nprocs=world, join=True)
     from quickvideo_amd.weights import pp_layer_split
     assert np.array_equal(ret["logits"], ret["ref_logits"]) and np.array_equal(ret["logits2"], ret["ref_logits2"])
     lens = []
