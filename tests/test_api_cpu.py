@@ -515,6 +515,83 @@ def test_load_qwen25_vl_checkpoint_directory(tmp_path):
     assert int(t_ids[per_grid] - t_ids[0]) == 10
 
 
+@pytest.mark.parametrize("family", ["qwen2.5-vl", "qwen2-vl"])
+def test_qwen_vl_end_to_end_equals_hf_forward(tmp_path, family):
+    """The reference's model family end to end (lvu.py:60; and Qwen2-VL, BASELINE.json's model): a tiny checkpoint through LVU's pipeline — frames -> patchify
+    -> windowed ViT + merger -> group-chunked prefill (2 groups, rho = 1: no pruning) -> prompt tail — against ONE forward of the
+    installed transformers Qwen2_5_VLForConditionalGeneration over the whole prompt (it derives its own M-RoPE index from
+    video_grid_thw and second_per_grid_ts).  Same bf16-representable weights; engine in bf16, HF in fp32: stated tolerance
+    |dlogit| <= 5e-2 (|logit| <= 1), cosine >= 0.999, same first token."""
+    import json
+    from safetensors.torch import save_file
+    from transformers.models.qwen2_5_vl.configuration_qwen2_5_vl import Qwen2_5_VLConfig
+    from transformers.models.qwen2_5_vl.modeling_qwen2_5_vl import Qwen2_5_VLForConditionalGeneration
+    from quickvideo_amd.engine import QuickPrefillEngine
+    from quickvideo_amd.frames import open_video
+    from quickvideo_amd.lvu import load_native_model
+    from quickvideo_amd.pipeline import PrefillPipeline
+    from quickvideo_amd.processor import SyntheticProcessor
+    from quickvideo_amd.vit import patchify_frames
+    import lvu
+    text = dict(hidden_size=256, num_attention_heads=2, num_key_value_heads=1, intermediate_size=512, num_hidden_layers=2,
+                vocab_size=320, rms_norm_eps=1e-6, tie_word_embeddings=False,
+                rope_parameters=dict(rope_type="default", mrope_section=[16, 24, 24], rope_theta=1_000_000.0))
+    ids_kw = dict(video_token_id=300, vision_start_token_id=301, vision_end_token_id=302)
+    if family == "qwen2.5-vl":
+        cfg = Qwen2_5_VLConfig(text_config=text, **ids_kw,
+                               vision_config=dict(depth=2, hidden_size=64, intermediate_size=80, num_heads=4, out_hidden_size=256, window_size=112,
+                                                  fullatt_block_indexes=[1], patch_size=14, spatial_merge_size=2, temporal_patch_size=2,
+                                                  tokens_per_second=2))
+        cls = Qwen2_5_VLForConditionalGeneration
+    else:
+        from transformers import Qwen2VLConfig, Qwen2VLForConditionalGeneration
+        cfg = Qwen2VLConfig(text_config=text, **ids_kw,
+                            vision_config=dict(depth=2, embed_dim=64, hidden_size=256, num_heads=4, mlp_ratio=2, patch_size=14,
+                                               spatial_merge_size=2, temporal_patch_size=2))
+        cls = Qwen2VLForConditionalGeneration
+    cfg._attn_implementation = "eager"
+    torch.manual_seed(0)
+    hf = cls(cfg).eval()
+    with torch.no_grad():
+        for p in hf.parameters():
+            p.copy_(p.to(torch.bfloat16).float())
+    save_file({k: v.contiguous() for k, v in hf.state_dict().items()}, str(tmp_path / "model.safetensors"))
+    d = cfg.to_dict()
+    d["text_config"]["rope_scaling"] = {"mrope_section": [16, 24, 24]}
+    d["text_config"]["rope_theta"] = 1_000_000.0
+    json.dump(d, open(tmp_path / "config.json", "w"), default=str)
+    m = load_native_model(str(tmp_path), device="cpu")
+    frames = torch.from_numpy(np.random.RandomState(5).randint(0, 256, (8, 3, 112, 168), dtype=np.uint8))
+    video = str(tmp_path / "v.npy")
+    np.save(video, frames.numpy())
+    pipe = PrefillPipeline(m, lvu.LVUConfig("x", top_p=1.0, video_group_size=4, num_frames=8), SyntheticProcessor(m.spec), ops=OracleOps())
+    cap, orig = {}, QuickPrefillEngine.prefill_tail
+
+    def tail(self, e, p):
+        cap["logits"] = orig(self, e, p)
+        return cap["logits"]
+    QuickPrefillEngine.prefill_tail = tail
+    try:
+        toks = pipe.generate("what is this", video, max_new_tokens=1, overlap=False)
+    finally:
+        QuickPrefillEngine.prefill_tail = orig
+    rd = open_video(video)
+    P = pipe.plan(rd, "what is this")
+    assert len(P["plan"].tokens) == 2                                    # group-chunked: the second group attends over the first
+    n_video = (P["nframes"] // 2) * (P["gh"] // 2) * (P["gw"] // 2)
+    ids = torch.tensor([list(P["prompt"].prefix_ids) + [300] * n_video + list(P["prompt"].tail_ids)])
+    rows, grid = patchify_frames(frames[torch.from_numpy(P["idx"])], m.vision.spec, torch.float32)
+    sample_fps = P["nframes"] / (len(rd) / rd.get_fps())
+    extra = (dict(second_per_grid_ts=torch.tensor([2.0 / sample_fps])) if family == "qwen2.5-vl"
+             else dict(mm_token_type_ids=(ids == 300).long() * 2))          # transformers 5.x Qwen2-VL: text 0 / image 1 / video 2
+    with torch.no_grad():
+        out = hf(input_ids=ids, pixel_values_videos=rows, video_grid_thw=torch.tensor([list(grid)]), attention_mask=torch.ones_like(ids), **extra)
+    ref, got = out.logits[0, -1].float(), cap["logits"].float()
+    assert (ref - got).abs().max().item() <= 5e-2, (ref - got).abs().max().item()
+    assert torch.nn.functional.cosine_similarity(ref, got, 0).item() >= 0.999
+    assert int(ref.argmax()) == int(got.argmax()) == toks[0]
+
+
 def test_producer_ring_fill_is_native_and_gil_free():
     """SURVEY 8b threading row: the producer's copy into the pinned ring must not starve the thread that launches the kernels.
     qp_host_memcpy through ctypes (the GIL is dropped around the foreign call): correct for odd sizes, and the main thread keeps
