@@ -702,11 +702,33 @@ def attach_traffic(roofline, name, world):
             roofline["traffic_over_algorithmic"] = round(roofline["traffic"] / d["algorithmic_bytes_per_launch"], 3)
 
 
+def attach_hbm_kernels(res, name, world):
+    """roofline_prune.traffic and the PMC table of the path's other HBM-bound kernels (key-norm reduction inside the RoPE/append kernel,
+    RMSNorm, SwiGLU) from the committed rocprofv3 passes (tools/pmc_hbm_kernels.sh), labelled with their source."""
+    if world != 1:
+        return
+    path = os.path.join(ROOT, "profiles", f"hbm_kernels_pmc_{'cfg4' if name in ('cfg4', 'cfg4s', 'cfg4x2') else name}.json")
+    if not os.path.exists(path):
+        return
+    d = json.load(open(path))
+    src = f"committed rocprofv3 kernel trace + --pmc FETCH_SIZE / WRITE_SIZE passes ({os.path.relpath(path, ROOT)}: {d.get('workload')}), not collected in this run"
+    pk = d["kernels"].get("prune_keys_kernel")
+    if pk and res.get("roofline_prune"):
+        res["roofline_prune"]["traffic"] = pk.get("traffic_bytes")
+        res["roofline_prune"]["traffic_over_algorithmic"] = pk.get("traffic_over_algorithmic")
+        res["roofline_prune"]["kernel_us_rocprof"] = pk.get("median_us")
+        res["roofline_prune"]["traffic_source"] = src
+    res["hbm_kernels"] = {"source": src, "peak_gb_s": PEAK_HBM_GBS,
+                          "kernels": {k: {f: v.get(f) for f in ("what", "median_us", "algorithmic_bytes", "algorithmic_gb_s", "frac_of_peak_algorithmic",
+                                                                 "traffic_bytes", "traffic_over_algorithmic")} for k, v in d["kernels"].items()}}
+
+
 def secondary_cfg2(args, device, weights):
     """Round 1's headline (BASELINE.json configs[1]) kept as a secondary block: 5 full passes + the front-end TTFT."""
     a = argparse.Namespace(**vars(args)); a.steps, a.warmup, a.window = 5, 2, None
     res, eng, ctx = measure(a, "cfg2", device, 0, 1, "single", (1, 1), None, weights=weights, timing="extra")
     attach_traffic(res.get("roofline"), "cfg2", 1)
+    attach_hbm_kernels(res, "cfg2", 1)
     out = {"workload": describe("cfg2"), "prefill_tokens": ctx["tokens"], "steps": 5, "step": "one full pass over the video", **res}
     if not args.no_pipeline:
         out["video_to_first_token"] = pipeline_leg("cfg2", eng, device)
@@ -810,6 +832,7 @@ def main():
             torch.distributed.destroy_process_group()
         return
     attach_traffic(res.get("roofline"), name, world)
+    attach_hbm_kernels(res, name, world)
 
     legs = {"decode": None, "video_to_first_token": None, "cfg2": None, "cpu_baseline": None}
     emitted = threading.Lock()
@@ -837,7 +860,7 @@ def main():
             "algorithmic_tflop_per_pass": res["algorithmic_tflop_per_pass"], "mfma_frac_whole_pass": res["mfma_frac_whole_pass"],
             "roofline": res.get("roofline"),
         }
-        for k in ("roofline_prune", "kernel_ms_per_pass", "telemetry"):
+        for k in ("roofline_prune", "hbm_kernels", "kernel_ms_per_pass", "telemetry"):
             if k in res:
                 out[k] = res[k]
         if world > 1:
