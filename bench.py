@@ -715,7 +715,11 @@ def attach_hbm_kernels(res, name, world):
     pk = d["kernels"].get("prune_keys_kernel")
     if pk and res.get("roofline_prune"):
         res["roofline_prune"]["traffic"] = pk.get("traffic_bytes")
-        res["roofline_prune"]["traffic_over_algorithmic"] = pk.get("traffic_over_algorithmic")
+        res["roofline_prune"]["bytes_this_launch_moves"] = pk.get("algorithmic_bytes")
+        res["roofline_prune"]["traffic_over_bytes_this_launch_moves"] = pk.get("traffic_over_algorithmic")
+        res["roofline_prune"]["traffic_note"] = ("algorithmic_bytes_per_launch above follows SURVEY 8d's unfused convention (it also charges the "
+                                                 "n*Hkv*D*2 B key-row read that now happens inside the RoPE/append kernel); the counters are compared "
+                                                 "with what this launch moves by construction: 2-byte keys + kept K/V rows in and out + indices")
         res["roofline_prune"]["kernel_us_rocprof"] = pk.get("median_us")
         res["roofline_prune"]["traffic_source"] = src
     res["hbm_kernels"] = {"source": src, "peak_gb_s": PEAK_HBM_GBS,
