@@ -83,5 +83,19 @@ for c in ("SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_I
     v, nv = steady_mean(c, "attn_fwd_kernel_s6")
     if v is not None:
         summary.setdefault("attn_sq_counters_per_launch", {})[c] = v
+sq = summary.get("attn_sq_counters_per_launch", {})
+if "SQ_VALU_MFMA_BUSY_CYCLES" in sq and "GRBM_GUI_ACTIVE" in sq and steady:
+    cyc = sq["GRBM_GUI_ACTIVE"] / 8.0                              # the counter is summed over the 8 XCDs
+    n_mfma, alg_mfma = sq["SQ_VALU_MFMA_BUSY_CYCLES"] / 32.0, alg_flops / 32768.0
+    d = {"note": "GRBM_GUI_ACTIVE is summed over the 8 XCDs; SQ_VALU_MFMA_BUSY_CYCLES counts MFMA-pipe cycles summed over the 1024 SIMDs (= 32 x "
+                 "N_mfma for 32x32x16 bf16); SQ_INSTS_* count wave instructions",
+         "shader_clock_ghz_during_profiled_launch": round(cyc / (sum(steady) / len(steady)), 3),
+         "mfma_busy_fraction_of_cycles": round(sq["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 1024), 4),
+         "mfma_instructions": n_mfma, "algorithmic_mfma_instructions": alg_mfma, "mfma_over_algorithmic": round(n_mfma / alg_mfma, 4)}
+    if "SQ_INSTS_VALU" in sq:
+        d["valu_instructions_per_mfma"] = round((sq["SQ_INSTS_VALU"] - n_mfma) / n_mfma, 3)
+    if "SQ_INSTS_LDS" in sq:
+        d["lds_instructions_per_mfma"] = round(sq["SQ_INSTS_LDS"] / n_mfma, 3)
+    summary["derived"] = d
 json.dump(summary, open(os.path.join(dst, f"{tag}_cfg4_window_pmc.json"), "w"), indent=1)
 print(json.dumps(summary, indent=1))
