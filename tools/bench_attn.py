@@ -32,6 +32,8 @@ for (n, P, hq, hkv) in shapes:
     q = torch.randn(n, hq, D, generator=g, device="cuda").to(torch.bfloat16)
     k = torch.randn(hkv, P + n, D, generator=g, device="cuda").to(torch.bfloat16)
     v = torch.randn(hkv, P + n, D, generator=g, device="cuda").to(torch.bfloat16)
+    if os.environ.get("QP_QSCALE"):               # peakedness of the softmax: scores ~ N(0, QSCALE^2); 1 = this tool's default, the
+        q = (q.float() * float(os.environ["QP_QSCALE"])).to(torch.bfloat16)   # random-weight engine runs sit near 0.05, trained models well above 1
     if os.environ.get("QP_ZERO") == "1":          # power probe: all-zero operands toggle far fewer bits (clock limited by power, not by the schedule)
         q.zero_(); k.zero_(); v.zero_()
     out = torch.empty(n, hq, D, dtype=torch.bfloat16, device="cuda")
