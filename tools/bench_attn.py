@@ -19,6 +19,9 @@ if os.environ.get("QP_SHAPES") == "cfg4":           # steady state of the 1-hour
 if os.environ.get("QP_SHAPES") == "sweep":          # 4- vs 8-wave workgroup crossover
     shapes = [(n, P, 28, 4) for n in (2240, 5760) for P in (16000, 32000, 64000)]
 
+if os.environ.get("QP_SHAPE"):                      # custom list: "n,P,hq,hkv;n,P,hq,hkv"
+    shapes = [tuple(int(v) for v in sh.split(",")) for sh in os.environ["QP_SHAPE"].split(";")]
+
 def bench(f, it=10):
     for _ in range(2): f()
     torch.cuda.synchronize(); s = torch.cuda.Event(True); e = torch.cuda.Event(True)
