@@ -30,7 +30,7 @@ import torch
 
 REF = "/root/reference"
 HERE = os.path.dirname(os.path.abspath(__file__))
-OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+OUT = os.environ.get("QP_GOLDEN_OUT") or os.path.join(os.path.dirname(HERE), "tests", "golden")   # QP_GOLDEN_OUT: regenerate elsewhere and diff
 sys.path.insert(0, os.path.dirname(HERE))
 
 from oracle import qp_oracle as O  # noqa: E402
