@@ -73,14 +73,26 @@ int qp_rope_append(qp_ctx* ctx, const void* qkv, const void* cos, const void* si
                    int n_kv_heads, int head_dim, void* q_out, void* k_dst, void* v_dst, int64_t dst_head_stride,
                    int64_t dst_row0, float* head_sumsq, void* stream);
 
+/* Which rows the prune step (seam 1) keeps — the reference's norm-based `top_k_predict_type`s (utils.py:117-136).  A per-call
+ * argument of every entry point whose result depends on it (no hidden context state): bit 0 = keep the k LARGEST norms (argsort
+ * descending) instead of the k smallest, bit 1 = score the VALUE rows instead of the key rows.  Ties always resolve to the lowest
+ * index.  Only qp_prune_tail reads bit 1 (it fetches the rows itself); the other entry points take sums the caller computed over
+ * the rows of its choice (qp_key_sumsq) and use bit 0 alone. */
+typedef enum qp_prune_mode {
+  QP_PRUNE_KEY_NORMS_SMALL = 0,    /* "key_norms_small" (the reference's default)  */
+  QP_PRUNE_KEY_NORMS = 1,          /* "key_norms"                                  */
+  QP_PRUNE_VECTOR_NORMS_SMALL = 2, /* "vector_norms_small"                         */
+  QP_PRUNE_VECTOR_NORMS = 3        /* "vector_norms"                               */
+} qp_prune_mode;
+
 /* qp_rope_append that also prepares the layer's prune (seam 1) while it holds the key rows: the 16-bit norm key of every token
- * (bf16 pattern of the cross-head key norm bf16(sqrt(((s0+s1)+s2)+...)), complemented when the ctx's prune order is "k largest")
- * goes to norm_keys[t] (uint16 [n]) for qp_prune_keys.  Needs all KV heads of the layer in this call (no tensor-parallel head
+ * (bf16 pattern of the cross-head key norm bf16(sqrt(((s0+s1)+s2)+...)), complemented when prune_mode says "k largest";
+ * prune_mode must be one of the two KEY-row modes) goes to norm_keys[t] (uint16 [n]) for qp_prune_keys.  Needs all KV heads of the layer in this call (no tensor-parallel head
  * sharding) and n_kv_heads in {1, 2, 4} with n_q_heads a multiple of it; returns QP_ERR_UNSUPPORTED otherwise — callers then
  * use qp_rope_append + qp_norm_keys.  head_sumsq may be NULL. */
 int qp_rope_append_keys(qp_ctx* ctx, const void* qkv, const void* cos, const void* sin, int64_t n, int n_q_heads,
                         int n_kv_heads, int head_dim, void* q_out, void* k_dst, void* v_dst, int64_t dst_head_stride,
-                        int64_t dst_row0, float* head_sumsq, uint16_t* norm_keys, void* stream);
+                        int64_t dst_row0, float* head_sumsq, uint16_t* norm_keys, int prune_mode, void* stream);
 
 /* ---- seam 3: prefill attention over (pruned prefix, new group)  (qwen25_lvu.py:61-62,102-112) - */
 /* q bf16 [n][n_q][128]; prefix K/V rows [0,prefix_len) with head stride prefix_head_stride; new K/V rows
@@ -110,24 +122,17 @@ size_t qp_attn_workspace_bytes(const qp_ctx* ctx, int64_t n, int64_t prefix_len,
 int qp_key_sumsq(qp_ctx* ctx, const void* k, int64_t head_stride, int64_t row0, int64_t n, int n_kv_heads,
                  int head_dim, float* head_sumsq, void* stream);
 
-/* Which rows the select keeps — the reference's norm-based `top_k_predict_type`s (utils.py:117-136):
- *   "key_norms_small" (default) = source 0, order 0;  "key_norms" = 0, 1;  "vector_norms_small" = 1, 0;  "vector_norms" = 1, 1.
- * norm_source: 0 = key rows, 1 = value rows (only qp_prune_tail reads it: the other entry points take the sums from the
- * caller, who computes them over the rows of its choice with qp_key_sumsq).  order: 0 = k smallest norms (argsort ascending),
- * 1 = k largest (argsort descending); ties always resolve to the lowest index.  Applies to subsequent calls on this ctx. */
-int qp_set_prune_mode(qp_ctx* ctx, int norm_source, int order);
-
 size_t qp_select_workspace_bytes(int64_t n);
 
 /* head_sumsq fp32 [n_heads_total][n] (all KV heads of the layer, ascending head order; under tensor
  * parallelism the all-gathered per-rank partials).  norm[t] = bf16(sqrt(((s0+s1)+s2)+...)).
- * kept_idx_out int32 [k]: the k smallest norms, ties -> lowest index, listed in ascending index order
- * (utils.py:136,191-194,284).  norm_bits_out (uint16 [n], may be NULL) receives the bf16 norms.
+ * kept_idx_out int32 [k]: the k smallest norms (k largest when bit 0 of prune_mode is set), ties -> lowest index, listed in
+ * ascending index order (utils.py:136,191-194,284).  norm_bits_out (uint16 [n], may be NULL) receives the bf16 norms.
  * Requires 0 < k <= n.  n <= 65536: norms stay in LDS, workspace may be NULL; larger n (single-group baseline mode on
  * long videos): pass a workspace of qp_select_workspace_bytes(n). */
 int qp_select_k_smallest(qp_ctx* ctx, const float* head_sumsq, int n_heads_total, int64_t n, int64_t k,
-                         int32_t* kept_idx_out, uint16_t* norm_bits_out, void* workspace, size_t workspace_bytes,
-                         void* stream);
+                         int32_t* kept_idx_out, uint16_t* norm_bits_out, int prune_mode, void* workspace,
+                         size_t workspace_bytes, void* stream);
 
 /* dst[h*dst_head_stride + (dst_row0+j)*head_dim ...] = src[h*src_head_stride + idx[j]*head_dim ...]
  * for j<k, for K and V (utils.py:287-288, 333-336).  src and dst must not overlap. */
@@ -139,7 +144,8 @@ int qp_gather_kv(qp_ctx* ctx, const void* k_src, const void* v_src, int64_t src_
  * select on head_sumsq and moves its slice of the kept rows src -> dst; kept_idx_out / norm_bits_out as above. */
 int qp_prune_staged(qp_ctx* ctx, const float* head_sumsq, int n_heads_total, int64_t n, int64_t k, const void* k_src,
                     const void* v_src, int64_t src_head_stride, int n_kv_heads, int head_dim, void* k_dst, void* v_dst,
-                    int64_t dst_head_stride, int64_t dst_row0, int32_t* kept_idx_out, uint16_t* norm_bits_out, void* stream);
+                    int64_t dst_head_stride, int64_t dst_row0, int32_t* kept_idx_out, uint16_t* norm_bits_out, int prune_mode,
+                    void* stream);
 
 /* The engine's prune step since round 2 (one launch; replaces qp_prune_staged, which recomputed every norm with an fp64
  * square root in each of up to 256 workgroups and needed up to 150 KB of LDS):
@@ -150,7 +156,8 @@ int qp_prune_staged(qp_ctx* ctx, const float* head_sumsq, int n_heads_total, int
  *                  src -> dst rows [dst_row0, dst_row0+k); kept_idx_out int32 [k] ascending; same tie rule as
  *                  qp_select_k_smallest (keys below the threshold, then ties by lowest index).  Requires 0 < k <= n <= 8192,
  *                  n_kv_heads <= 8 (larger n: qp_select_k_smallest + qp_gather_kv). */
-int qp_norm_keys(qp_ctx* ctx, const float* head_sumsq, int n_heads_total, int64_t n, uint16_t* norm_keys, void* stream);
+int qp_norm_keys(qp_ctx* ctx, const float* head_sumsq, int n_heads_total, int64_t n, uint16_t* norm_keys, int prune_mode,
+                 void* stream);
 int qp_prune_keys(qp_ctx* ctx, const uint16_t* norm_keys, int64_t n, int64_t k, const void* k_src, const void* v_src,
                   int64_t src_head_stride, int n_kv_heads, int head_dim, void* k_dst, void* v_dst, int64_t dst_head_stride,
                   int64_t dst_row0, int32_t* kept_idx_out, void* stream);
@@ -168,10 +175,17 @@ int qp_query_scores(qp_ctx* ctx, const void* q_prompt, const void* k_group, int6
 
 /* In-place drop-in for post_process_kv_cache's KV part on the arena (utils.py:266-342):
  * rows [past_len, past_len+n) are the group's new tokens; on return rows [past_len, past_len+k) hold the
- * kept ones in original order and kept_idx_out[k] lists them.  workspace >= qp_prune_workspace_bytes(). */
+ * kept ones in original order and kept_idx_out[k] lists them.  workspace >= qp_prune_workspace_bytes().
+ * Two launches for n <= 8192 and n_kv_heads <= 8 (round 3): (1) the 16-bit norm key of every tail token; (2) one workgroup per
+ * 16-token slice finds the threshold by a radix select in LDS, STAGES the K/V rows of its kept tokens in registers (<= 256 B per
+ * lane, <= 64 KB per workgroup), signals "rows loaded", waits for the (at most two, always LOWER) slices whose source rows its
+ * destination rows overlap, and stores to [past_len, past_len+k) — the compaction never bounces through HBM scratch.  The wait is
+ * deadlock-free because it only points downwards and the whole grid (<= 512 workgroups) fits on the device at once, which the
+ * library checks with the occupancy API.  The workspace then only holds the keys and the flags (2.25 bytes per token).  Larger
+ * groups use the round-1 form (sums -> select -> gather into the workspace -> copy back). */
 size_t qp_prune_workspace_bytes(int64_t n, int64_t k, int n_kv_heads, int head_dim);
 int qp_prune_tail(qp_ctx* ctx, void* k_cache, void* v_cache, int64_t head_stride, int64_t past_len, int64_t n,
-                  int64_t k, int n_kv_heads, int head_dim, int32_t* kept_idx_out, void* workspace,
+                  int64_t k, int n_kv_heads, int head_dim, int32_t* kept_idx_out, int prune_mode, void* workspace,
                   size_t workspace_bytes, void* stream);
 
 /* Row gather for the hidden-state pruning hand-off (prune_for_next_layer; utils.py:292-331):

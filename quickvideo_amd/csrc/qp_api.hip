@@ -3,6 +3,7 @@
 #include "qp_common.h"
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <thread>
@@ -48,12 +49,18 @@ int qp_create(qp_ctx** out, int device) {
   c->device = device;
   c->cus = prop.multiProcessorCount;
   c->lds_per_cu = (int)prop.sharedMemPerBlock;
-  c->norm_source = 0; c->order = 0;            // key_norms_small
+  c->lt = nullptr;
   *out = c;
   return QP_OK;
 }
 
-void qp_destroy(qp_ctx* ctx) { delete ctx; }
+void qp_destroy(qp_ctx* ctx) {
+  if (!ctx) return;
+  qp_lt_destroy(ctx->lt);                      // hipBLASLt handles / plans of this context
+  delete ctx;
+}
+
+static inline bool valid_mode(int m) { return m >= 0 && m <= 3; }
 
 // Host-side, GIL-free ring fill of the overlap producer (qwen25_lvu_interleaved.py:303-340 runs `.float()` + the HF processor under
 // the GIL): a plain memcpy into the pinned slot, split over a few std::threads for large groups.  Called through ctypes, which
@@ -111,8 +118,10 @@ int qp_rope_append(qp_ctx* ctx, const void* qkv, const void* cos, const void* si
 
 int qp_rope_append_keys(qp_ctx* ctx, const void* qkv, const void* cos, const void* sin, int64_t n, int n_q_heads, int n_kv_heads,
                         int head_dim, void* q_out, void* k_dst, void* v_dst, int64_t dst_head_stride, int64_t dst_row0,
-                        float* head_sumsq, uint16_t* norm_keys, void* stream) {
+                        float* head_sumsq, uint16_t* norm_keys, int prune_mode, void* stream) {
   QP_REQUIRE(ctx && qkv && cos && sin && q_out && k_dst && v_dst && norm_keys, QP_ERR_INVALID, "qp_rope_append_keys: NULL argument");
+  QP_REQUIRE(prune_mode == QP_PRUNE_KEY_NORMS_SMALL || prune_mode == QP_PRUNE_KEY_NORMS, QP_ERR_INVALID,
+             "qp_rope_append_keys: prune_mode=%d (this entry point scores the KEY rows: QP_PRUNE_KEY_NORMS_SMALL or QP_PRUNE_KEY_NORMS)", prune_mode);
   QP_REQUIRE(head_dim == 128, QP_ERR_UNSUPPORTED, "qp_rope_append_keys: head_dim=%d (only 128)", head_dim);
   QP_REQUIRE(n >= 0 && n_q_heads > 0 && n_kv_heads > 0 && dst_row0 >= 0, QP_ERR_INVALID, "qp_rope_append_keys: bad sizes");
   QP_REQUIRE(qp_rope_can_fuse_keys(n_q_heads, n_kv_heads), QP_ERR_UNSUPPORTED,
@@ -125,7 +134,7 @@ int qp_rope_append_keys(qp_ctx* ctx, const void* qkv, const void* cos, const voi
              QP_ERR_INVALID, "qp_rope_append_keys: pointers must be 16-byte aligned");
   if (n == 0) return QP_OK;
   return qp_launch_rope_append(qkv, cos, sin, n, n_q_heads, n_kv_heads, q_out, k_dst, v_dst, dst_head_stride, dst_row0,
-                               head_sumsq, norm_keys, ctx->order, (hipStream_t)stream);
+                               head_sumsq, norm_keys, qp_mode_largest(prune_mode), (hipStream_t)stream);
 }
 
 size_t qp_query_scores_workspace_bytes(int64_t n, int64_t m, int n_q_heads) {
@@ -149,10 +158,11 @@ int qp_query_scores(qp_ctx* ctx, const void* q_prompt, const void* k_group, int6
                                 workspace, (hipStream_t)stream);
 }
 
-int qp_norm_keys(qp_ctx* ctx, const float* head_sumsq, int n_heads_total, int64_t n, uint16_t* norm_keys, void* stream) {
+int qp_norm_keys(qp_ctx* ctx, const float* head_sumsq, int n_heads_total, int64_t n, uint16_t* norm_keys, int prune_mode, void* stream) {
   QP_REQUIRE(ctx && head_sumsq && norm_keys, QP_ERR_INVALID, "qp_norm_keys: NULL argument");
+  QP_REQUIRE(valid_mode(prune_mode), QP_ERR_INVALID, "qp_norm_keys: prune_mode=%d (0..3, enum qp_prune_mode)", prune_mode);
   QP_REQUIRE(n_heads_total > 0 && n > 0 && n < (1ll << 31), QP_ERR_INVALID, "qp_norm_keys: need n_heads_total > 0 and n > 0 (n=%lld)", (long long)n);
-  return qp_launch_norm_keys(head_sumsq, n_heads_total, n, norm_keys, ctx->order, (hipStream_t)stream);
+  return qp_launch_norm_keys(head_sumsq, n_heads_total, n, norm_keys, qp_mode_largest(prune_mode), (hipStream_t)stream);
 }
 
 int qp_prune_keys(qp_ctx* ctx, const uint16_t* norm_keys, int64_t n, int64_t k, const void* k_src, const void* v_src,
@@ -220,27 +230,21 @@ int qp_key_sumsq(qp_ctx* ctx, const void* k, int64_t head_stride, int64_t row0, 
   return qp_launch_key_sumsq(k, head_stride, row0, n, n_kv_heads, head_sumsq, (hipStream_t)stream);
 }
 
-int qp_set_prune_mode(qp_ctx* ctx, int norm_source, int order) {
-  QP_REQUIRE(ctx, QP_ERR_INVALID, "qp_set_prune_mode: NULL ctx");
-  QP_REQUIRE((norm_source == 0 || norm_source == 1) && (order == 0 || order == 1), QP_ERR_INVALID,
-             "qp_set_prune_mode: norm_source=%d order=%d (each 0 or 1)", norm_source, order);
-  ctx->norm_source = norm_source; ctx->order = order;
-  return QP_OK;
-}
-
 size_t qp_select_workspace_bytes(int64_t n) { return n > 65536 ? (size_t)n * 2 + 256 : 256; }
 
 int qp_select_k_smallest(qp_ctx* ctx, const float* head_sumsq, int n_heads_total, int64_t n, int64_t k,
-                         int32_t* kept_idx_out, uint16_t* norm_bits_out, void* workspace, size_t workspace_bytes,
+                         int32_t* kept_idx_out, uint16_t* norm_bits_out, int prune_mode, void* workspace, size_t workspace_bytes,
                          void* stream) {
   QP_REQUIRE(ctx && head_sumsq && kept_idx_out, QP_ERR_INVALID, "qp_select_k_smallest: NULL argument");
+  QP_REQUIRE(valid_mode(prune_mode), QP_ERR_INVALID, "qp_select_k_smallest: prune_mode=%d (0..3, enum qp_prune_mode)", prune_mode);
   QP_REQUIRE(n_heads_total > 0, QP_ERR_INVALID, "qp_select_k_smallest: n_heads_total=%d", n_heads_total);
   QP_REQUIRE(k > 0 && k <= n, QP_ERR_INVALID, "qp_select_k_smallest: need 0 < k <= n, got k=%lld n=%lld", (long long)k,
              (long long)n);
   QP_REQUIRE(n < (1ll << 31), QP_ERR_UNSUPPORTED, "qp_select_k_smallest: n=%lld too large", (long long)n);
   QP_REQUIRE(n <= 65536 || (workspace != nullptr && workspace_bytes >= qp_select_workspace_bytes(n)), QP_ERR_WORKSPACE,
              "qp_select_k_smallest: n=%lld > 65536 needs a workspace of %zu bytes", (long long)n, qp_select_workspace_bytes(n));
-  return qp_launch_select(head_sumsq, n_heads_total, n, k, kept_idx_out, norm_bits_out, workspace, ctx->order, (hipStream_t)stream);
+  return qp_launch_select(head_sumsq, n_heads_total, n, k, kept_idx_out, norm_bits_out, workspace, qp_mode_largest(prune_mode),
+                          (hipStream_t)stream);
 }
 
 int qp_gather_kv(qp_ctx* ctx, const void* k_src, const void* v_src, int64_t src_head_stride, const int32_t* idx, int64_t k,
@@ -260,8 +264,11 @@ int qp_gather_kv(qp_ctx* ctx, const void* k_src, const void* v_src, int64_t src_
 
 int qp_prune_staged(qp_ctx* ctx, const float* head_sumsq, int n_heads_total, int64_t n, int64_t k, const void* k_src,
                     const void* v_src, int64_t src_head_stride, int n_kv_heads, int head_dim, void* k_dst, void* v_dst,
-                    int64_t dst_head_stride, int64_t dst_row0, int32_t* kept_idx_out, uint16_t* norm_bits_out, void* stream) {
+                    int64_t dst_head_stride, int64_t dst_row0, int32_t* kept_idx_out, uint16_t* norm_bits_out, int prune_mode,
+                    void* stream) {
   QP_REQUIRE(ctx && head_sumsq && k_src && v_src && k_dst && v_dst && kept_idx_out, QP_ERR_INVALID, "qp_prune_staged: NULL argument");
+  QP_REQUIRE(valid_mode(prune_mode), QP_ERR_INVALID, "qp_prune_staged: prune_mode=%d (0..3, enum qp_prune_mode)", prune_mode);
+  const int largest = qp_mode_largest(prune_mode);
   QP_REQUIRE(head_dim == 128, QP_ERR_UNSUPPORTED, "qp_prune_staged: head_dim=%d (only 128)", head_dim);
   QP_REQUIRE(n_heads_total > 0 && n_kv_heads > 0 && k > 0 && k <= n, QP_ERR_INVALID,
              "qp_prune_staged: need 0 < k <= n, got k=%lld n=%lld", (long long)k, (long long)n);
@@ -271,39 +278,70 @@ int qp_prune_staged(qp_ctx* ctx, const float* head_sumsq, int n_heads_total, int
   QP_REQUIRE(aligned16(k_src) && aligned16(v_src) && aligned16(k_dst) && aligned16(v_dst), QP_ERR_INVALID, "qp_prune_staged: alignment");
   hipStream_t s = (hipStream_t)stream;
   int rc = qp_launch_prune_fused(head_sumsq, n_heads_total, n, k, k_src, v_src, src_head_stride, n_kv_heads, k_dst, v_dst,
-                                 dst_head_stride, dst_row0, kept_idx_out, norm_bits_out, ctx->cus, ctx->order, s);
+                                 dst_head_stride, dst_row0, kept_idx_out, norm_bits_out, ctx->cus, largest, s);
   if (rc != 1) return rc;
-  rc = qp_launch_select(head_sumsq, n_heads_total, n, k, kept_idx_out, norm_bits_out, nullptr, ctx->order, s);     // large n: two launches
+  rc = qp_launch_select(head_sumsq, n_heads_total, n, k, kept_idx_out, norm_bits_out, nullptr, largest, s);       // large n: two launches
   if (rc) return rc;
   return qp_launch_gather_kv(k_src, v_src, src_head_stride, kept_idx_out, k, n_kv_heads, k_dst, v_dst, dst_head_stride, dst_row0, s);
 }
 
-// workspace layout of qp_prune_tail: [head_sumsq fp32 Hkv*n][pad to 256][K rows Hkv*k*D bf16][V rows Hkv*k*D bf16]
+// qp_prune_tail.  n <= 8192 and n_kv_heads <= 8 (every group size the reference is run at): TWO launches, no HBM bounce —
+//   workspace = [norm keys uint16 n | pad to 256][one int32 "rows loaded" flag per 16-token slice]
+// Larger groups (the single-group baseline mode of long videos) keep the round-1 form: sums -> one-workgroup select -> gather into
+// the workspace -> copy back;  workspace = [head_sumsq fp32 Hkv*n | pad][K rows Hkv*k*D bf16 | pad][V rows | pad].
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+static inline bool tail_inplace_ok(int64_t n, int n_kv_heads) {
+  static const bool staged = getenv("QP_PRUNE_TAIL_STAGED") != nullptr;    // developer A/B switch (tools/bench_prune_tail.py): round-1 form
+  return !staged && n <= 8192 && n_kv_heads <= 8;
+}
+static inline int64_t tail_slices(int64_t n) { return (n + 15) / 16; }
 
-size_t qp_prune_workspace_bytes(int64_t n, int64_t k, int n_kv_heads, int head_dim) {
+static size_t staged_tail_bytes(int64_t n, int64_t k, int n_kv_heads, int head_dim) {
   return align256((size_t)n_kv_heads * n * 4) + 2 * align256((size_t)n_kv_heads * k * head_dim * 2) + 256;
 }
 
+size_t qp_prune_workspace_bytes(int64_t n, int64_t k, int n_kv_heads, int head_dim) {
+  if (n <= 0 || k <= 0 || n_kv_heads <= 0 || head_dim <= 0) return 256;
+  if (tail_inplace_ok(n, n_kv_heads)) return align256((size_t)n * 2) + align256((size_t)tail_slices(n) * 4);
+  return staged_tail_bytes(n, k, n_kv_heads, head_dim);
+}
+
 int qp_prune_tail(qp_ctx* ctx, void* k_cache, void* v_cache, int64_t head_stride, int64_t past_len, int64_t n, int64_t k,
-                  int n_kv_heads, int head_dim, int32_t* kept_idx_out, void* workspace, size_t workspace_bytes, void* stream) {
+                  int n_kv_heads, int head_dim, int32_t* kept_idx_out, int prune_mode, void* workspace, size_t workspace_bytes,
+                  void* stream) {
   QP_REQUIRE(ctx && k_cache && v_cache && kept_idx_out && workspace, QP_ERR_INVALID, "qp_prune_tail: NULL argument");
   QP_REQUIRE(head_dim == 128, QP_ERR_UNSUPPORTED, "qp_prune_tail: head_dim=%d (only 128)", head_dim);
+  QP_REQUIRE(valid_mode(prune_mode), QP_ERR_INVALID, "qp_prune_tail: prune_mode=%d (0..3, enum qp_prune_mode)", prune_mode);
   QP_REQUIRE(past_len >= 0 && k > 0 && k <= n && n_kv_heads > 0, QP_ERR_INVALID,
              "qp_prune_tail: need past_len >= 0 and 0 < k <= n (k=%lld n=%lld)", (long long)k, (long long)n);
   QP_REQUIRE(n <= 65536, QP_ERR_UNSUPPORTED, "qp_prune_tail: n=%lld > 65536", (long long)n);
   QP_REQUIRE(head_stride % 8 == 0 && head_stride >= (past_len + n) * head_dim, QP_ERR_INVALID, "qp_prune_tail: head stride too small");
-  QP_REQUIRE(workspace_bytes >= qp_prune_workspace_bytes(n, k, n_kv_heads, head_dim), QP_ERR_WORKSPACE,
-             "qp_prune_tail: workspace %zu < %zu bytes", workspace_bytes, qp_prune_workspace_bytes(n, k, n_kv_heads, head_dim));
+  // in place only when the whole grid of the second launch is resident at once (see qp_prune.hip: that is what makes its
+  // slice-ordered wait deadlock-free); 512 workgroups at most, an MI355X holds 1024
+  const bool inplace = tail_inplace_ok(n, n_kv_heads) && tail_slices(n) <= qp_prune_tail_inplace_capacity(ctx->cus);
+  const size_t need = inplace ? qp_prune_workspace_bytes(n, k, n_kv_heads, head_dim) : staged_tail_bytes(n, k, n_kv_heads, head_dim);
+  QP_REQUIRE(workspace_bytes >= need, QP_ERR_WORKSPACE, "qp_prune_tail: workspace %zu < %zu bytes%s", workspace_bytes, need,
+             (!inplace && tail_inplace_ok(n, n_kv_heads)) ? " (this device cannot hold the in-place grid at once: the staged form needs the larger scratch)" : "");
   QP_REQUIRE(aligned16(k_cache) && aligned16(v_cache) && aligned16(workspace), QP_ERR_INVALID, "qp_prune_tail: alignment");
   hipStream_t s = (hipStream_t)stream;
   unsigned char* ws = (unsigned char*)workspace;
+  const int largest = qp_mode_largest(prune_mode);
+  const void* scored = qp_mode_values(prune_mode) ? v_cache : k_cache;
+  if (inplace) {
+    uint16_t* keys = (uint16_t*)ws;
+    int* sync_words = (int*)(ws + align256((size_t)n * 2));
+    // launch 1: 16-bit norm key of every tail token (all KV heads of a token in one 16-lane group) + clears the sync words
+    int rc = qp_launch_tail_keys(scored, head_stride, past_len, n, n_kv_heads, keys, largest, sync_words, (int)tail_slices(n), s);
+    if (rc) return rc;
+    // launch 2: radix select per 16-token slice, kept rows staged in registers, slice-ordered hand-shake, stores to [past, past+k)
+    return qp_launch_prune_tail_inplace(keys, n, k, k_cache, v_cache, head_stride, past_len, n_kv_heads, kept_idx_out, sync_words, s);
+  }
   float* sumsq = (float*)ws;
   unsigned char* kt = ws + align256((size_t)n_kv_heads * n * 4);
   unsigned char* vt = kt + align256((size_t)n_kv_heads * k * head_dim * 2);
-  int rc = qp_launch_key_sumsq(ctx->norm_source ? v_cache : k_cache, head_stride, past_len, n, n_kv_heads, sumsq, s);
+  int rc = qp_launch_key_sumsq(scored, head_stride, past_len, n, n_kv_heads, sumsq, s);
   if (rc) return rc;
-  rc = qp_launch_select(sumsq, n_kv_heads, n, k, kept_idx_out, nullptr, nullptr, ctx->order, s);
+  rc = qp_launch_select(sumsq, n_kv_heads, n, k, kept_idx_out, nullptr, nullptr, largest, s);
   if (rc) return rc;
   // gather the kept tail rows into the workspace, then copy them back contiguously (dst <= src row-wise, but
   // workgroups run in no defined order, so the in-place move goes through the scratch block)
@@ -424,7 +462,7 @@ int qp_linear_act(qp_ctx* ctx, const void* x, const void* w, const void* bias, i
   QP_REQUIRE(act >= 0 && act <= 1, QP_ERR_INVALID, "qp_linear_act: act=%d (0 none, 1 Swish z*sigmoid(z))", act);
   QP_REQUIRE(aligned16(x) && aligned16(w) && aligned16(out) && (!bias || aligned16(bias)) && (!workspace || aligned16(workspace)),
              QP_ERR_INVALID, "qp_linear_act: alignment");
-  return qp_launch_linear_act(x, w, bias, bias_f32, alpha, out, m, n, k, act, workspace, workspace_bytes, (hipStream_t)stream);
+  return qp_launch_linear_act(ctx, x, w, bias, bias_f32, alpha, out, m, n, k, act, workspace, workspace_bytes, (hipStream_t)stream);
 }
 
 int qp_linear_tune(qp_ctx* ctx, const void* x, const void* const* weights, int n_weights, const void* bias, int bias_f32, float alpha,
@@ -434,7 +472,7 @@ int qp_linear_tune(qp_ctx* ctx, const void* x, const void* const* weights, int n
              (long long)n, (long long)k);
   QP_REQUIRE(act >= 0 && act <= 1, QP_ERR_INVALID, "qp_linear_tune: act=%d", act);
   for (int i = 0; i < n_weights; ++i) QP_REQUIRE(weights[i] && aligned16(weights[i]), QP_ERR_INVALID, "qp_linear_tune: weight %d", i);
-  return qp_launch_linear_tune(x, weights, n_weights, bias, bias_f32, alpha, out, m, n, k, act, workspace, workspace_bytes,
+  return qp_launch_linear_tune(ctx, x, weights, n_weights, bias, bias_f32, alpha, out, m, n, k, act, workspace, workspace_bytes,
                                (hipStream_t)stream, nullptr);
 }
 

@@ -604,9 +604,15 @@ int qp_launch_prefill_attn(const qp_ctx* ctx, const void* q, const void* k_prefi
   }
   const int per_kvh = a.n_whole + (a.items - a.n_whole) * a.nsplit;
   const bool xcd = (hkv <= 8 && 8 % hkv == 0 && variant != 3);
+#ifdef QP_EXPERIMENTS                                    // `make EXPERIMENTS=1` (measured slower): not in the product library
   if (variant == 10) {                                   // experiment: one wave per SIMD, 64 rows per wave (qp_attn_s7.hip)
     qp_launch_attn_s7(p, xcd, (unsigned)per_kvh, s);
-  } else if (variant != 4) {                             // production: software-pipelined kernel (qp_attn_s6.hip); 4: s4
+  } else
+#else
+  if (variant == 9 || variant == 10)
+    return qp_fail(QP_ERR_UNSUPPORTED, "qp_prefill_attn: QP_ATTN_VARIANT=%d is an experiment; rebuild with `make EXPERIMENTS=1`", variant);
+#endif
+  if (variant != 4) {                             // production: software-pipelined kernel (qp_attn_s6.hip); 4: s4
     qp_launch_attn_s6(p, xcd, (unsigned)per_kvh, s);
   } else if (xcd) {
     const int G = 8 / hkv;

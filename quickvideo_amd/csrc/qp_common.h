@@ -9,9 +9,14 @@ struct qp_ctx {
   int device;
   int cus;
   int lds_per_cu;
-  int norm_source;   // qp_set_prune_mode: 0 = key rows, 1 = value rows (qp_prune_tail)
-  int order;         // 0 = k smallest norms, 1 = k largest
+  void* lt;          // hipBLASLt handles (one per stream) and GEMM plans of THIS context/device (qp_linear.hip); freed by qp_destroy
 };
+void qp_lt_destroy(void* lt_state);
+
+// prune_mode argument of the seam-1 entry points (include/quickprefill.h: enum qp_prune_mode): bit 0 = keep the k LARGEST norms,
+// bit 1 = score the VALUE rows
+static inline int qp_mode_largest(int prune_mode) { return prune_mode & 1; }
+static inline int qp_mode_values(int prune_mode) { return (prune_mode >> 1) & 1; }
 
 // thread-local error message (qp_api.cpp)
 int qp_fail(int status, const char* fmt, ...);
@@ -107,7 +112,12 @@ int qp_launch_decode_attn_fused(const qp_ctx* ctx, const void* qkv, const void* 
                                 int64_t head_stride, const int64_t* state, int hq, int hkv, float scale, void* out, void* workspace,
                                 hipStream_t s);
 int qp_launch_decode_advance(int64_t* state, int n, hipStream_t s);
-int qp_launch_linear_tune(const void* x, const void* const* ws_list, int n_ws, const void* bias, int bias_f32, float alpha, void* out,
+int qp_launch_tail_keys(const void* rows, int64_t head_stride, int64_t row0, int64_t n, int hkv, uint16_t* norm_keys, int largest,
+                        int* sync_words, int n_sync_words, hipStream_t s);
+int qp_prune_tail_inplace_capacity(int cus);
+int qp_launch_prune_tail_inplace(const uint16_t* norm_keys, int64_t n, int64_t k, void* k_cache, void* v_cache, int64_t head_stride,
+                                 int64_t past_len, int hkv, int32_t* kept, int* sync_words, hipStream_t s);
+int qp_launch_linear_tune(qp_ctx* ctx, const void* x, const void* const* ws_list, int n_ws, const void* bias, int bias_f32, float alpha, void* out,
                           int64_t m, int64_t n, int64_t k, int act, void* workspace, size_t workspace_bytes, hipStream_t s, int* chosen);
-int qp_launch_linear_act(const void* x, const void* w, const void* bias, int bias_f32, float alpha, void* out, int64_t m, int64_t n,
+int qp_launch_linear_act(qp_ctx* ctx, const void* x, const void* w, const void* bias, int bias_f32, float alpha, void* out, int64_t m, int64_t n,
                          int64_t k, int act, void* workspace, size_t workspace_bytes, hipStream_t s);

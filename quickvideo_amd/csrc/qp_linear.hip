@@ -29,14 +29,19 @@ struct LtState {
   // One hipBLASLt handle PER STREAM: the library keeps device-side state per handle (the flag / partial-tile buffer of its stream-K
   // kernels), so GEMMs of two streams that run concurrently (ViT stream and prefill stream, pipeline.py) must not go through the
   // same handle — with one shared handle the device stalls for good in the video -> first-token leg (tools/repro_pipeline.py).
+  // The state lives in the qp_ctx, i.e. per DEVICE: stream 0 exists on every device, and a handle (or a plan tuned on one device's
+  // handle) must not be reused on another.  qp_destroy frees handles, descriptors and layouts.
   std::map<hipStream_t, hipblasLtHandle_t> handles;
   std::map<std::tuple<int64_t, int64_t, int64_t, int, int>, Plan> plans;   // (m, n, k, act, bias kind: 0 none, 1 bf16, 2 fp32)
   std::mutex mu;
 };
 
-LtState& lt() {
-  static LtState s;
-  return s;
+std::mutex g_create_mu;
+
+LtState& lt(qp_ctx* ctx) {
+  std::lock_guard<std::mutex> g(g_create_mu);
+  if (!ctx->lt) ctx->lt = new LtState;
+  return *static_cast<LtState*>(ctx->lt);
 }
 
 #define LT_CHECK(call)                                                                                     \
@@ -98,9 +103,23 @@ int make_plan(hipblasLtHandle_t handle, Plan& p, int64_t m, int64_t n, int64_t k
 
 }  // namespace
 
-int qp_launch_linear_act(const void* x, const void* w, const void* bias, int bias_f32, float alpha, void* out, int64_t m, int64_t n,
+void qp_lt_destroy(void* lt_state) {
+  LtState* st = static_cast<LtState*>(lt_state);
+  if (!st) return;
+  for (auto& kv : st->plans) {
+    Plan& p = kv.second;
+    if (p.desc) (void)hipblasLtMatmulDescDestroy(p.desc);
+    if (p.a) (void)hipblasLtMatrixLayoutDestroy(p.a);
+    if (p.b) (void)hipblasLtMatrixLayoutDestroy(p.b);
+    if (p.d) (void)hipblasLtMatrixLayoutDestroy(p.d);
+  }
+  for (auto& kv : st->handles) (void)hipblasLtDestroy(kv.second);
+  delete st;
+}
+
+int qp_launch_linear_act(qp_ctx* ctx, const void* x, const void* w, const void* bias, int bias_f32, float alpha, void* out, int64_t m, int64_t n,
                          int64_t k, int act, void* workspace, size_t workspace_bytes, hipStream_t s) {
-  LtState& st = lt();
+  LtState& st = lt(ctx);
   std::lock_guard<std::mutex> g(st.mu);
   hipblasLtHandle_t handle = nullptr;
   if (int rc = handle_for(st, s, &handle)) return rc;
@@ -125,9 +144,9 @@ int qp_launch_linear_act(const void* x, const void* w, const void* bias, int bia
 // visited round-robin, because a skinny GEMM re-reading one hot weight matrix is served by the Infinity Cache and ranks the
 // candidates differently (prompt tail, M = 30, 7B dims: down projection 110 us with the default pick, 47 us with the best) —
 // and keeps the fastest for later qp_linear_act calls of the same (m, n, k, act, bias kind).  Synchronises the stream.
-int qp_launch_linear_tune(const void* x, const void* const* ws_list, int n_ws, const void* bias, int bias_f32, float alpha, void* out,
+int qp_launch_linear_tune(qp_ctx* ctx, const void* x, const void* const* ws_list, int n_ws, const void* bias, int bias_f32, float alpha, void* out,
                           int64_t m, int64_t n, int64_t k, int act, void* workspace, size_t workspace_bytes, hipStream_t s, int* chosen) {
-  LtState& st = lt();
+  LtState& st = lt(ctx);
   std::lock_guard<std::mutex> g(st.mu);
   hipblasLtHandle_t handle = nullptr;
   if (int rc = handle_for(st, s, &handle)) return rc;

@@ -2,6 +2,7 @@
 // Reference semantics: lvu/utils.py:133-136 (key_norms_small), :190-194 (mask), :266-342 (gather + cat).
 // All HBM-bound byte/integer work: coalesced 16-B accesses, 16 lanes per 256-B head row.
 #include "qp_common.h"
+#include <cstdlib>
 
 // ------------------------------------------------------------------------------------------------
 // K4: per-head sum of squares in the canonical order (oracle: key_sumsq_heads).
@@ -389,6 +390,170 @@ int qp_launch_prune_keys(const uint16_t* norm_keys, int64_t n, int64_t k, const 
   prune_keys_kernel<<<grid, 256, 0, s>>>(norm_keys, (int)n, (int)k, (const uint4*)k_src, (const uint4*)v_src, src_head_stride / 8, hkv,
                                          (uint4*)k_dst, (uint4*)v_dst, dst_head_stride / 8, dst_row0, kept);
   return qp_check_launch("prune_keys");
+}
+
+// ------------------------------------------------------------------------------------------------
+// qp_prune_tail, round 3: the in-place seam (utils.py:266-342 on the arena itself) in TWO launches, no HBM bounce.
+//   tail_keys_kernel          one 16-lane group per tail token: the hkv key (or value) rows of the token -> canonical per-head sums
+//                             (same order as key_sumsq_kernel) -> heads added in ascending order -> 16-bit norm key; also clears
+//                             the hand-shake flags of the second launch.
+//   prune_tail_inplace_kernel prune_keys_kernel's select, then the compaction staged through registers: rows [past, past+n) shrink
+//                             to [past, past+k) IN PLACE.  Kept token t moves to position pos(t) <= t, so the <= 16 destination
+//                             rows of a 16-token slice are source rows of at most two slices, both at or before its own.  Every
+//                             workgroup (1) loads the K/V rows of its kept tokens into registers (<= 2*hkv*16 B per lane),
+//                             (2) publishes flag[slice] = 1 ("my loads have retired"), (3) waits for the flags of the (<= 2)
+//                             LOWER slices whose rows it is about to overwrite, (4) stores.
+//   Why the wait cannot deadlock: a slice waits only for lower slices and never the other way round (no cycle), and the launcher
+//   only uses this kernel when the WHOLE grid fits on the device at once (grid <= CUs x workgroups per CU from the occupancy
+//   API; n <= 8192 needs <= 512 workgroups, an MI355X holds 1024) — so waiting workgroups can never occupy every slot a not yet
+//   dispatched lower slice needs; workgroups of OTHER kernels in those slots finish on their own.  (The same argument a
+//   cooperative launch makes; verified with a second stream keeping all CUs busy, tests/test_gpu_ops.py.)  An atomic ticket
+//   (slice = start order) would drop even that condition, but 360 same-address device atomics serialise at ~25 ns each: +3-4 us per
+//   launch (measured, profiles/r3_prune_tail_old_vs_new.json), on a 10 us kernel.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tail_keys_kernel(const uint4* __restrict__ rows, int64_t hs16, int64_t row0, int n, int hkv,
+                                                        uint16_t* __restrict__ norm_keys, int largest, int* __restrict__ sync_words,
+                                                        int n_sync_words) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < n_sync_words; i += gridDim.x * 256) sync_words[i] = 0;
+  const int c = threadIdx.x & 15;
+  const int t = blockIdx.x * 16 + (threadIdx.x >> 4);
+  if (t >= n) return;                                   // whole 16-lane groups leave together
+  const uint4* p = rows + (row0 + t) * 16 + c;
+  uint4 v[8];
+#pragma unroll
+  for (int h = 0; h < 8; ++h) if (h < hkv) v[h] = p[h * hs16];
+  float tot = 0.f;
+#pragma unroll
+  for (int h = 0; h < 8; ++h) {
+    if (h < hkv) {
+      const float s = row16_butterfly(chunk_sumsq(v[h]));
+      tot = h == 0 ? s : tot + s;
+    }
+  }
+  if (c == 0) {
+    const uint16_t b = f32_to_bf16_bits(sqrt_rn_f32(tot));
+    norm_keys[t] = largest ? (uint16_t)~b : b;
+  }
+}
+
+int qp_launch_tail_keys(const void* rows, int64_t head_stride, int64_t row0, int64_t n, int hkv, uint16_t* norm_keys, int largest,
+                        int* sync_words, int n_sync_words, hipStream_t s) {
+  tail_keys_kernel<<<(unsigned)((n + 15) / 16), 256, 0, s>>>((const uint4*)rows, head_stride / 8, row0, (int)n, hkv, norm_keys, largest,
+                                                            sync_words, n_sync_words);
+  return qp_check_launch("tail_keys");
+}
+
+// kThreads / 16 tokens per workgroup (one 16-lane group per token)
+template <int kThreads>
+__global__ __launch_bounds__(kThreads) void prune_tail_inplace_kernel(const uint16_t* __restrict__ keys_g, int n, int k, uint4* k_cache,
+                                                                      uint4* v_cache, int64_t hs16, int64_t past, int hkv,
+                                                                      int32_t* __restrict__ kept, int* sync_words, int dbg) {
+  constexpr int QP_TAIL_TS = kThreads / 16;
+  constexpr int kWaves = kThreads / 64;
+  __shared__ __attribute__((aligned(16))) uint16_t keys[QP_PRUNE_MAX_N];
+  __shared__ unsigned hist[2][QP_HIST_COPIES * QP_HIST_STRIDE];
+  __shared__ unsigned res[8];                  // pass 1: bucket, count before it; pass 2 (res + 4): low byte, count before tau inside the bucket
+  __shared__ unsigned red[2][kWaves];
+  __shared__ int s_tok[QP_TAIL_TS], s_pos[QP_TAIL_TS];
+  __shared__ int s_nk, s_base;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int* flags = sync_words;
+  const int n8 = n >> 3;
+  for (int i = tid; i < n8; i += kThreads) ((uint4*)keys)[i] = ((const uint4*)keys_g)[i];
+  if (tid < (n & 7)) keys[n8 * 8 + tid] = keys_g[n8 * 8 + tid];
+  for (int i = tid; i < 2 * QP_HIST_COPIES * QP_HIST_STRIDE; i += kThreads) (&hist[0][0])[i] = 0u;
+  __syncthreads();
+  unsigned* h1c = &hist[0][(lane & (QP_HIST_COPIES - 1)) * QP_HIST_STRIDE];
+  unsigned* h2c = &hist[1][(lane & (QP_HIST_COPIES - 1)) * QP_HIST_STRIDE];
+
+  // two-pass 256-bin radix select of the threshold key tau (same tie rule as select_kernel / prune_keys_kernel)
+  for (int t = tid; t < n; t += kThreads) atomicAdd(&h1c[keys[t] >> 8], 1u);
+  __syncthreads();
+  find_bucket_256(&hist[0][0], QP_HIST_COPIES, QP_HIST_STRIDE, (unsigned)k, res);
+  const unsigned b1 = res[0], c1 = res[1];
+  for (int t = tid; t < n; t += kThreads) { const unsigned key = keys[t]; if ((key >> 8) == b1) atomicAdd(&h2c[key & 255u], 1u); }
+  __syncthreads();
+  find_bucket_256(&hist[1][0], QP_HIST_COPIES, QP_HIST_STRIDE, (unsigned)k - c1, res + 4);      // (ends with a barrier)
+  const unsigned tau = (b1 << 8) | res[4];
+  const unsigned r_ties = (unsigned)k - (c1 + res[5]);   // >= 1 ties (key == tau) to take, lowest index first
+  const int slice = (int)blockIdx.x;
+  const int t0 = slice * QP_TAIL_TS;
+
+  // kept tokens in front of this slice
+  unsigned lt = 0, eq = 0;
+  for (int t = tid; t < t0; t += kThreads) { const unsigned key = keys[t]; lt += key < tau; eq += key == tau; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { lt += __shfl_xor(lt, o, 64); eq += __shfl_xor(eq, o, 64); }
+  if (lane == 0) { red[0][wave] = lt; red[1][wave] = eq; }
+  __syncthreads();
+  if (wave == 0) {
+    unsigned lt_b = 0, eq_b = 0;
+#pragma unroll
+    for (int w = 0; w < kWaves; ++w) { lt_b += red[0][w]; eq_b += red[1][w]; }
+    const bool mine = lane < QP_TAIL_TS && t0 + lane < n;                     // lane j owns token t0 + j
+    const unsigned mykey = mine ? (unsigned)keys[t0 + lane] : 0xffffffffu;
+    const bool is_lt = mykey < tau, is_eq = mykey == tau;
+    const unsigned long long m_eq = __ballot(is_eq);
+    const unsigned eq_rank = eq_b + (unsigned)__popcll(m_eq & ((1ull << lane) - 1ull));
+    const bool keep = is_lt || (is_eq && eq_rank < r_ties);
+    const unsigned long long m_keep = __ballot(keep);
+    const unsigned rank = (unsigned)__popcll(m_keep & ((1ull << lane) - 1ull));
+    const unsigned base = lt_b + min(eq_b, r_ties);
+    if (keep) { s_tok[rank] = t0 + lane; s_pos[rank] = (int)(base + rank); kept[base + rank] = t0 + lane; }
+    if (lane == 0) { s_nk = (int)__popcll(m_keep); s_base = (int)base; }
+  }
+  __syncthreads();
+  // (2) stage: 16-lane group g holds the K and V rows (all heads) of kept slot g in registers
+  const int c = tid & 15, grp = tid >> 4;
+  const int nk = s_nk, base = s_base;
+  const bool have = grp < nk;
+  uint4 rk[8], rv[8];
+  if (have) {
+    const uint4* ks = k_cache + (past + s_tok[grp]) * 16 + c;
+    const uint4* vs = v_cache + (past + s_tok[grp]) * 16 + c;
+#pragma unroll
+    for (int h = 0; h < 8; ++h) if (h < hkv) { rk[h] = ks[h * hs16]; rv[h] = vs[h * hs16]; }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the rows are IN the registers before anyone may overwrite them
+  __syncthreads();
+  // (3) publish, (4) wait for the lower slices whose source rows [base, base+nk) covers.  RELAXED device-scope atomics: the flag
+  // carries no data (it says "my loads have retired", which the s_waitcnt above established locally), so neither side needs the L2
+  // write-back / invalidate of a release / acquire pair (measured: 35 us per call with them at n = 5760).
+  if (tid == 0) __hip_atomic_store(&flags[slice], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (nk > 0 && tid < 2) {
+    const int dep = tid == 0 ? base / QP_TAIL_TS : (base + nk - 1) / QP_TAIL_TS;
+    if (dep < slice && !(dbg & 2))                       // (dbg: developer probe of the wait's cost, results then UNSAFE)
+      while (__hip_atomic_load(&flags[dep], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {}
+  }
+  asm volatile("" ::: "memory");
+  __syncthreads();
+  // (5) store
+  if (have) {
+    uint4* kd = k_cache + (past + s_pos[grp]) * 16 + c;
+    uint4* vd = v_cache + (past + s_pos[grp]) * 16 + c;
+#pragma unroll
+    for (int h = 0; h < 8; ++h) if (h < hkv) { kd[h * hs16] = rk[h]; vd[h * hs16] = rv[h]; }
+  }
+}
+
+// workgroups of prune_tail_inplace_kernel<256> the device holds at once (0 = unknown: the caller uses the staged form)
+int qp_prune_tail_inplace_capacity(int cus) {
+  static std::atomic<int> per_cu{-1};
+  int v = per_cu.load(std::memory_order_relaxed);
+  if (v < 0) {
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)prune_tail_inplace_kernel<256>, 256, 0) != hipSuccess) nb = 0;
+    per_cu.store(v = nb, std::memory_order_relaxed);
+  }
+  return v * cus;
+}
+
+int qp_launch_prune_tail_inplace(const uint16_t* norm_keys, int64_t n, int64_t k, void* k_cache, void* v_cache, int64_t head_stride,
+                                 int64_t past_len, int hkv, int32_t* kept, int* sync_words, hipStream_t s) {
+  static const int dbg = getenv("QP_TAIL_DBG") ? atoi(getenv("QP_TAIL_DBG")) : 0;          // developer probe (UNSAFE results): 2 = no wait
+  prune_tail_inplace_kernel<256><<<(unsigned)((n + 15) / 16), 256, 0, s>>>(norm_keys, (int)n, (int)k, (uint4*)k_cache, (uint4*)v_cache,
+                                                                         head_stride / 8, past_len, hkv, kept, sync_words, dbg);
+  return qp_check_launch("prune_tail_inplace");
 }
 
 static size_t prune_fused_smem(int64_t n, int64_t k) { return (16 * 257 + 256 + 16 + 4 + 4) * 4 + (size_t)((n + 7) & ~7) * 2 + (size_t)k * 2 + 16; }

@@ -72,7 +72,13 @@ class QuickPrefillEngine:
         # contiguous slice of each group's tokens through all layers and the ranks exchange only the group's new K/V rows
         # (+ key sums) once per layer — ~14x fewer bytes on xGMI than the two [n, d] all-reduces of tensor parallelism.
         self.sp_group, self.sp_rank, self.sp_size = sp_group, sp_rank, sp_size
-        assert not (self.sp_size > 1 and self.tp_size > 1), "choose tensor parallel OR group-token parallel"
+        # A process group handed in explicitly is USED even when it has one member: every collective of the layer loop is then
+        # issued on it (all-reduce of [n, d], all-gather of the key sums / of the K|V|sums exchange block).  That is how a 1-GPU
+        # box pre-flights the RCCL path (backend "nccl", world_size 1: dtype / shape / device-binding errors surface without a
+        # second GPU — tests/test_gpu_engine.py, bench.py --nccl-preflight); with no group a single rank issues no collective.
+        self.tp_on = self.tp_size > 1 or tp_group is not None
+        self.sp_on = self.sp_size > 1 or sp_group is not None
+        assert not (self.sp_on and self.tp_on), "choose tensor parallel OR group-token parallel"
         # layer-pipeline parallelism ("pp"): rank r holds a contiguous slice of the layers (weights AND their KV), receives a group's
         # hidden rows from rank r-1, runs its layers and hands the rows to rank r+1.  No collective: one [n, d] point-to-point
         # hand-off per group and stage.  Groups flow through the stages back to back, so a video of G groups keeps
@@ -96,13 +102,13 @@ class QuickPrefillEngine:
         self.b_q, self.b_att = e(n, self.hq, self.D), e(n, self.hq, self.D)
         self.b_gu, self.b_act = e(n, 2 * self.li), e(n, self.li)
         self.b_stage = e(2, self.hkv, n + 2 * self.sp_size, self.D)
-        if self.sp_size > 1:
+        if self.sp_on:
             m = 2 * -(-n // (2 * self.sp_size))                                           # two chunks of ceil(n / 2N) rows
             self.sp_chunk = 2 * self.hkv * m * self.D * 2 + self.hkv * m * 4              # bytes: K | V | key sums of one rank
             self.b_xsend = e(self.sp_chunk, dtype=torch.uint8)
             self.b_xall = e(self.sp_size * self.sp_chunk, dtype=torch.uint8)
         self.b_ss = e(self.hkv, n, dtype=torch.float32)
-        self.b_ss_all = e(self.tp_size, self.hkv, n, dtype=torch.float32) if self.tp_size > 1 else None
+        self.b_ss_all = e(self.tp_size, self.hkv, n, dtype=torch.float32) if self.tp_on else None
         self.b_idx = e(n, dtype=torch.int32)
         self.b_idx_pp = e(n, dtype=torch.int32) if self.pp_size > 1 else None   # original rows of a hidden-pruned hand-off
         # prune through 16-bit norm keys (qp_prune_keys): the keys of the group's tokens, written by the RoPE kernel
@@ -121,13 +127,16 @@ class QuickPrefillEngine:
         self.norm_source, self.norm_order = NORM_PRUNE_MODES.get(cfg.top_k_predict_type, (0, 1))
         if self.query_mode and not hasattr(self, "b_keys"):
             self.b_keys = e(n, dtype=torch.int16)
-        self.ops.set_prune_mode(self.norm_source, self.norm_order)
+        # per-call argument of every mode-dependent operator (no state on the shared ops object: two engines of different
+        # top_k_predict_type may share one QuickPrefillOps)
+        self.prune_mode = (self.norm_source << 1) | self.norm_order
         env = os.environ.get("QP_SPLIT_GATE_UP_ROWS")                                  # developer override, see _gate_up_swiglu
         self.split_gate_up_rows = tuple(int(v) for v in env.split(",")) if env else None
         self._tune_gemms = self.device.type == "cuda" and os.environ.get("QP_TUNE_GEMMS", "1") == "1"
         # decisions are per (projection shape, rows, device) and shared by every engine of the process
         self._gemm_plans, self._gu_split, self._lt_tuned = (QuickPrefillEngine._SHARED.setdefault((str(self.device), self._tune_gemms, i), {}) for i in range(3))
         self.kept_trace: Optional[list] = None      # tests: set to [] to record kept indices per (group, layer)
+        self.hidden_trace: Optional[list] = None    # tests: set to [] to record the residual stream after every layer (fp32 copy)
         self.seq_pos = 0                            # tokens of the original sequence consumed so far
 
     # ------------------------------------------------------------------ helpers
@@ -140,10 +149,10 @@ class QuickPrefillEngine:
         ops, D = self.ops, self.D
         if not (self._keys_path and n <= ops.PRUNE_KEYS_MAX_N):
             ops.prune_staged(ss_all, heads_total, n, k_keep, kn, vn, new_stride, self.hkv, D, self.arena.k(l), self.arena.v(l),
-                             self.arena.head_stride, past, idx)
+                             self.arena.head_stride, past, idx, mode=self.prune_mode)
             return
         if not keys_ready:                                   # sums crossed ranks / came from the value rows: keys now
-            ops.norm_keys(ss_all, heads_total, n, self.b_keys)
+            ops.norm_keys(ss_all, heads_total, n, self.b_keys, mode=self.prune_mode)
         elif self._prune_probe:                              # developer probe: an (almost) empty launch in the prune's position
             ops.norm_keys(self.b_ss, 1, 1, self._probe_key)
         ops.prune_keys(self.b_keys, n, k_keep, kn, vn, new_stride, self.hkv, D, self.arena.k(l), self.arena.v(l), self.arena.head_stride,
@@ -290,13 +299,13 @@ class QuickPrefillEngine:
             self.ops.swiglu(gu, act)
 
     def _all_reduce(self, t: torch.Tensor):
-        if self.tp_size > 1:
+        if self.tp_on:
             torch.distributed.all_reduce(t, group=self.tp_group)
 
     def _global_sumsq(self, n: int) -> (torch.Tensor, int):
         """[Hkv_total, n] per-head sums in ascending head order, identical on every rank (partials are
         all-gathered and added in fixed head order so the norm is bit-stable across TP degrees)."""
-        if self.tp_size == 1:
+        if not self.tp_on:
             return self.b_ss.view(-1)[: self.hkv * n].view(self.hkv, n), self.hkv
         local = self.b_ss.view(-1)[: self.hkv * n].view(self.hkv, n)
         allb = self.b_ss_all.view(-1)[: self.tp_size * self.hkv * n].view(self.tp_size * self.hkv, n)
@@ -348,10 +357,10 @@ class QuickPrefillEngine:
             if k_keep is not None:                                           # prune layer: new K/V go to staging
                 kn = self.b_stage[0].view(-1)[: self.hkv * n * D].view(self.hkv, n, D)
                 vn = self.b_stage[1].view(-1)[: self.hkv * n * D].view(self.hkv, n, D)
-                fuse = (self._keys_path and n <= ops.PRUNE_KEYS_MAX_N and self.tp_size == 1 and self.norm_source == 0
+                fuse = (self._keys_path and n <= ops.PRUNE_KEYS_MAX_N and not self.tp_on and self.norm_source == 0
                         and ops.can_fuse_keys(self.hq, self.hkv))
                 if fuse:                                                     # 16-bit norm keys while the key rows are in registers
-                    ops.rope_append_keys(qkv, cos, sin, self.hq, self.hkv, D, q, kn, vn, n * D, 0, None, self.b_keys)
+                    ops.rope_append_keys(qkv, cos, sin, self.hq, self.hkv, D, q, kn, vn, n * D, 0, None, self.b_keys, mode=self.prune_mode)
                 else:
                     ops.rope_append(qkv, cos, sin, self.hq, self.hkv, D, q, kn, vn, n * D, 0, self.b_ss)
                 new_stride = n * D
@@ -409,6 +418,8 @@ class QuickPrefillEngine:
             self._linear("down", act, lw.w_down, dn)
             self._all_reduce(dn)
             delta = dn
+            if self.hidden_trace is not None:                                # the layer's output = h + MLP (the add itself is deferred)
+                self.hidden_trace.append((l, h.float() + dn.float()))
         ops.add_inplace(h, delta)                                            # last residual                  (:198)
         return h
 
@@ -424,7 +435,7 @@ class QuickPrefillEngine:
         nt = pos.shape[1]
         n = nt - m
         assert embeds.shape[0] == nt and n > 0 and nt <= self.n_max, f"group of {n}+{m} tokens exceeds max_group_tokens={self.n_max}"
-        if self.tp_size > 1 or self.sp_size > 1 or self.pp_size > 1:
+        if self.tp_on or self.sp_on or self.pp_size > 1:
             raise NotImplementedError("query-attention-score pruning runs on one GPU (no tensor / group-token / layer-pipeline parallel form)")
         if cfg.enable and isinstance(cfg.prefill_prune_starting_layer, int) and cfg.prefill_prune_starting_layer >= 0:
             raise NotImplementedError("query-attention-score pruning + hidden-state pruning: the reference drops the prompt rows there")
@@ -583,7 +594,7 @@ class QuickPrefillEngine:
     # ------------------------------------------------------------------ public steps of the group loop
     # layer-pipeline hand-off: stage r > 0 receives the segment's hidden rows from stage r-1, the last stage keeps its output
     def _sp_active(self, n: int) -> bool:
-        return self.sp_size > 1 and n >= 64 * self.sp_size
+        return self.sp_on and n >= 64 * self.sp_size
 
     def _pp_rows(self, n: int) -> int:
         """Rows of an n-token segment that travel between this rank and its pipeline counterparts."""
@@ -689,7 +700,7 @@ class QuickPrefillEngine:
         return self.logits_last(h) if self.is_last_stage else None
 
     def logits_last(self, h: torch.Tensor) -> torch.Tensor:
-        if self.device.type == "cuda" and hasattr(self.ops, "gemv") and self.tp_size == 1 and self.spec.hidden <= 32256:
+        if self.device.type == "cuda" and hasattr(self.ops, "gemv") and self.tp_size == 1 and self.spec.hidden <= 32256:   # (lm_head is not sharded by a 1-rank group)
             # final RMSNorm + lm_head of ONE row: the weight-streaming kernel of the decode step (1.09 GB at 6.5 TB/s)
             logits = torch.empty(self.w.lm_head.shape[0], dtype=self.dtype, device=self.device)
             self.ops.gemv(self.w.lm_head, h[-1].contiguous(), logits, self.ops.GEMV_BIAS, norm_w=self.w.norm, eps=self.spec.rms_eps)

@@ -41,22 +41,21 @@ SIGNATURES = {
     "qp_host_memcpy": (_i32, [_vp, _vp, _sz, _i32]),
     "qp_mrope_table": (_i32, [_vp, _vp, _i64, _c.POINTER(_c.c_int32), _f32, _i32, _vp, _vp, _vp]),
     "qp_rope_append": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _vp, _vp]),
-    "qp_rope_append_keys": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
+    "qp_rope_append_keys": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i32, _vp]),
     "qp_query_scores_workspace_bytes": (_sz, [_i64, _i64, _i32]),
     "qp_query_scores": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "qp_norm_keys": (_i32, [_vp, _vp, _i32, _i64, _vp, _vp]),
+    "qp_norm_keys": (_i32, [_vp, _vp, _i32, _i64, _vp, _i32, _vp]),
     "qp_prune_keys": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _i64, _vp, _vp]),
     "qp_prefill_attn": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _i32, _i32, _i32, _f32, _vp, _vp, _sz, _vp]),
     "qp_prefill_attn_rows": (_i32, [_vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _f32, _vp, _vp, _sz, _vp]),
     "qp_attn_workspace_bytes": (_sz, [_vp, _i64, _i64, _i32, _i32]),
     "qp_key_sumsq": (_i32, [_vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _vp]),
-    "qp_set_prune_mode": (_i32, [_vp, _i32, _i32]),
     "qp_select_workspace_bytes": (_sz, [_i64]),
-    "qp_select_k_smallest": (_i32, [_vp, _vp, _i32, _i64, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "qp_select_k_smallest": (_i32, [_vp, _vp, _i32, _i64, _i64, _vp, _vp, _i32, _vp, _sz, _vp]),
     "qp_gather_kv": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _i64, _vp]),
-    "qp_prune_staged": (_i32, [_vp, _vp, _i32, _i64, _i64, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _i64, _vp, _vp, _vp]),
+    "qp_prune_staged": (_i32, [_vp, _vp, _i32, _i64, _i64, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _i64, _vp, _vp, _i32, _vp]),
     "qp_prune_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32]),
-    "qp_prune_tail": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _vp, _vp, _sz, _vp]),
+    "qp_prune_tail": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _vp, _i32, _vp, _sz, _vp]),
     "qp_gather_rows": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _vp]),
     "qp_sp_unpack": (_i32, [_vp, _vp, _i32, _i32, _i64, _i32, _i64, _vp, _vp, _i64, _vp, _vp]),
     "qp_add_rmsnorm": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
@@ -169,13 +168,22 @@ class QuickPrefillOps:
                                             q_out.data_ptr(), k_dst.data_ptr(), v_dst.data_ptr(), dst_head_stride, dst_row0,
                                             _ptr(head_sumsq), self._stream()))
 
-    def rope_append_keys(self, qkv, cos, sin, n_q, n_kv, head_dim, q_out, k_dst, v_dst, dst_head_stride, dst_row0, head_sumsq, norm_keys):
+    # prune_mode argument of the seam-1 entry points (enum qp_prune_mode): bit 0 = keep the k LARGEST norms, bit 1 = score the VALUE rows
+    PRUNE_KEY_NORMS_SMALL, PRUNE_KEY_NORMS, PRUNE_VECTOR_NORMS_SMALL, PRUNE_VECTOR_NORMS = 0, 1, 2, 3
+
+    @staticmethod
+    def prune_mode(norm_source: int, order: int) -> int:
+        """(norm_source, order) of lvu_config.NORM_PRUNE_MODES -> the C ABI's prune_mode (utils.py:117-136)."""
+        return (int(norm_source) << 1) | int(order)
+
+    def rope_append_keys(self, qkv, cos, sin, n_q, n_kv, head_dim, q_out, k_dst, v_dst, dst_head_stride, dst_row0, head_sumsq, norm_keys,
+                         mode: int = 0):
         """rope_append that also emits the layer's 16-bit norm keys (raises QuickPrefillError, status QP_ERR_UNSUPPORTED, when the
-        head layout cannot be fused: see can_fuse_keys)."""
+        head layout cannot be fused: see can_fuse_keys).  mode: one of the two key-row prune modes."""
         n = qkv.shape[0]
         self._check(self.lib.qp_rope_append_keys(self.ctx, qkv.data_ptr(), cos.data_ptr(), sin.data_ptr(), n, n_q, n_kv, head_dim,
                                                  q_out.data_ptr(), k_dst.data_ptr(), v_dst.data_ptr(), dst_head_stride, dst_row0,
-                                                 _ptr(head_sumsq), norm_keys.data_ptr(), self._stream()))
+                                                 _ptr(head_sumsq), norm_keys.data_ptr(), int(mode), self._stream()))
 
     @staticmethod
     def can_fuse_keys(n_q, n_kv) -> bool:
@@ -194,8 +202,8 @@ class QuickPrefillOps:
                                              _ptr(value_sumsq), norm_keys.data_ptr(), _ptr(scores), self._qs_ws.data_ptr(), self._qs_ws.numel(),
                                              self._stream()))
 
-    def norm_keys(self, head_sumsq, n_heads_total, n, norm_keys):
-        self._check(self.lib.qp_norm_keys(self.ctx, head_sumsq.data_ptr(), n_heads_total, n, norm_keys.data_ptr(), self._stream()))
+    def norm_keys(self, head_sumsq, n_heads_total, n, norm_keys, mode: int = 0):
+        self._check(self.lib.qp_norm_keys(self.ctx, head_sumsq.data_ptr(), n_heads_total, n, norm_keys.data_ptr(), int(mode), self._stream()))
 
     def prune_keys(self, norm_keys, n, k, k_src, v_src, src_head_stride, n_kv, head_dim, k_dst, v_dst, dst_head_stride, dst_row0, kept_idx):
         self._check(self.lib.qp_prune_keys(self.ctx, norm_keys.data_ptr(), n, k, k_src.data_ptr(), v_src.data_ptr(), src_head_stride, n_kv,
@@ -220,12 +228,12 @@ class QuickPrefillOps:
         self._check(self.lib.qp_key_sumsq(self.ctx, k.data_ptr(), head_stride, row0, n, n_kv, head_dim, head_sumsq.data_ptr(),
                                           self._stream()))
 
-    def select_k_smallest(self, head_sumsq, n_heads_total, n, k, kept_idx, norm_bits=None):
+    def select_k_smallest(self, head_sumsq, n_heads_total, n, k, kept_idx, norm_bits=None, mode: int = 0):
         need = int(self.lib.qp_select_workspace_bytes(n))
         if self._select_ws.numel() < need:
             self._select_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         self._check(self.lib.qp_select_k_smallest(self.ctx, head_sumsq.data_ptr(), n_heads_total, n, k, kept_idx.data_ptr(),
-                                                  _ptr(norm_bits), self._select_ws.data_ptr(), self._select_ws.numel(),
+                                                  _ptr(norm_bits), int(mode), self._select_ws.data_ptr(), self._select_ws.numel(),
                                                   self._stream()))
 
     def gather_kv(self, k_src, v_src, src_head_stride, idx, k, n_kv, head_dim, k_dst, v_dst, dst_head_stride, dst_row0):
@@ -234,22 +242,18 @@ class QuickPrefillOps:
                                           self._stream()))
 
     def prune_staged(self, head_sumsq, n_heads_total, n, k, k_src, v_src, src_head_stride, n_kv, head_dim, k_dst, v_dst,
-                     dst_head_stride, dst_row0, kept_idx, norm_bits=None):
+                     dst_head_stride, dst_row0, kept_idx, norm_bits=None, mode: int = 0):
         self._check(self.lib.qp_prune_staged(self.ctx, head_sumsq.data_ptr(), n_heads_total, n, k, k_src.data_ptr(), v_src.data_ptr(),
                                              src_head_stride, n_kv, head_dim, k_dst.data_ptr(), v_dst.data_ptr(), dst_head_stride,
-                                             dst_row0, kept_idx.data_ptr(), _ptr(norm_bits), self._stream()))
+                                             dst_row0, kept_idx.data_ptr(), _ptr(norm_bits), int(mode), self._stream()))
 
     def prune_workspace_bytes(self, n, k, n_kv, head_dim) -> int:
         return int(self.lib.qp_prune_workspace_bytes(n, k, n_kv, head_dim))
 
-    def prune_tail(self, k_cache, v_cache, head_stride, past_len, n, k, n_kv, head_dim, kept_idx, workspace):
+    def prune_tail(self, k_cache, v_cache, head_stride, past_len, n, k, n_kv, head_dim, kept_idx, workspace, mode: int = 0):
         self._check(self.lib.qp_prune_tail(self.ctx, k_cache.data_ptr(), v_cache.data_ptr(), head_stride, past_len, n, k, n_kv,
-                                           head_dim, kept_idx.data_ptr(), workspace.data_ptr(), workspace.numel() * workspace.element_size(),
-                                           self._stream()))
-
-    def set_prune_mode(self, norm_source: int, order: int):
-        """0/0 = key_norms_small (default), 0/1 = key_norms, 1/0 = vector_norms_small, 1/1 = vector_norms (utils.py:117-136)."""
-        self._check(self.lib.qp_set_prune_mode(self.ctx, int(norm_source), int(order)))
+                                           head_dim, kept_idx.data_ptr(), int(mode), workspace.data_ptr(),
+                                           workspace.numel() * workspace.element_size(), self._stream()))
 
     def sp_unpack(self, gathered, world, n_kv, m2, head_dim, n, k_stage, v_stage, stage_head_stride, sumsq_out):
         self._check(self.lib.qp_sp_unpack(self.ctx, gathered.data_ptr(), world, n_kv, m2, head_dim, n, k_stage.data_ptr(), v_stage.data_ptr(),

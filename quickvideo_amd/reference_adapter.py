@@ -86,12 +86,12 @@ def post_process_kv_cache(hidden_states: torch.Tensor, attention_mask: torch.Ten
         return unchanged
     assert hidden_states.shape[0] == 1, f"Only support batch size 1 for now, but got {hidden_states.shape[0]}"    # utils.py:264
     ops = present_key_value.ops
-    ops.set_prune_mode(*NORM_PRUNE_MODES[cfg.top_k_predict_type])
+    src, order = NORM_PRUNE_MODES[cfg.top_k_predict_type]
     kc, vc, total = present_key_value.layer(layer)
     past = total - q_len                                                               # utils.py:266-271: only the new rows are scored
     idx = torch.empty(k, dtype=torch.int32, device=kc.device)
     ws = present_key_value.workspace(ops.prune_workspace_bytes(q_len, k, kc.shape[0], kc.shape[2]))
-    ops.prune_tail(kc, vc, kc.stride(0), past, q_len, k, kc.shape[0], kc.shape[2], idx, ws)
+    ops.prune_tail(kc, vc, kc.stride(0), past, q_len, k, kc.shape[0], kc.shape[2], idx, ws, mode=(src << 1) | order)
     present_key_value.set_len(layer, past + k)                                         # replaces key_cache[layer] = cat(...) (utils.py:333-340)
     if lvu_layer_config.prune_for_next_layer:                                          # utils.py:292-331, 344-372
         def rows(t2d):                                                                  # [q_len, C] -> [k, C] on the device

@@ -49,7 +49,7 @@ int main(void) {
   CHECK_HIP(hipMalloc(&dk, elems * 2)); CHECK_HIP(hipMalloc(&dv, elems * 2));
   CHECK_HIP(hipMalloc(&dws, ws_bytes ? ws_bytes : 16)); CHECK_HIP(hipMalloc((void**)&didx, K * 4));
   CHECK_HIP(hipMemcpy(dk, hk, elems * 2, hipMemcpyHostToDevice)); CHECK_HIP(hipMemcpy(dv, hv, elems * 2, hipMemcpyHostToDevice));
-  CHECK_QP(qp_prune_tail(ctx, dk, dv, (int64_t)CAP * D, PAST, N, K, HKV, D, didx, dws, ws_bytes, NULL));
+  CHECK_QP(qp_prune_tail(ctx, dk, dv, (int64_t)CAP * D, PAST, N, K, HKV, D, didx, QP_PRUNE_KEY_NORMS_SMALL, dws, ws_bytes, NULL));
   CHECK_HIP(hipDeviceSynchronize());
   int32_t idx[K];
   CHECK_HIP(hipMemcpy(idx, didx, K * 4, hipMemcpyDeviceToHost));
@@ -68,7 +68,7 @@ int main(void) {
   printf("seam 1 (qp_prune_tail): %s\n", bad ? "MISMATCH" : "kept indices and compacted rows exact");
 
   /* error behaviour: batch-style misuse is rejected before any launch, with a message */
-  int rc = qp_prune_tail(ctx, dk, dv, (int64_t)CAP * D, PAST, N, N + 1, HKV, D, didx, dws, ws_bytes, NULL);
+  int rc = qp_prune_tail(ctx, dk, dv, (int64_t)CAP * D, PAST, N, N + 1, HKV, D, didx, QP_PRUNE_KEY_NORMS_SMALL, dws, ws_bytes, NULL);
   if (rc == QP_OK || !qp_last_error()[0]) { printf("k > n was accepted\n"); ++bad; }
 
   /* seam 3: one query, one key */

@@ -58,20 +58,16 @@ class OracleOps:
             ks.append(torch.cat(parts_k)); vs.append(torch.cat(parts_v))
         out[:n].copy_(O.attention_bottom_right(q[:n].transpose(0, 1), torch.stack(ks), torch.stack(vs), scale))
 
-    order = 0            # qp_set_prune_mode: 0 = k smallest norms, 1 = k largest
-
-    def set_prune_mode(self, norm_source, order):
-        self.order = int(order)
-
     def key_sumsq(self, k, head_stride, row0, n, n_kv, head_dim, head_sumsq):
         rows = torch.stack([self._rows(k, h, head_stride, row0, n, head_dim) for h in range(n_kv)])
         ss = O.key_sumsq_heads(O.torch_bf16_to_bits(rows.contiguous()))
         head_sumsq.view(-1)[: n_kv * n].copy_(torch.from_numpy(ss).view(-1))
 
-    def select_k_smallest(self, head_sumsq, n_heads_total, n, k, kept_idx, norm_bits=None):
+    def select_k_smallest(self, head_sumsq, n_heads_total, n, k, kept_idx, norm_bits=None, mode=0):
+        """mode = the C ABI's prune_mode: bit 0 = keep the k largest norms"""
         ss = head_sumsq.reshape(-1)[: n_heads_total * n].view(n_heads_total, n).numpy()
         nb = O.key_norms_bf16(ss)
-        kept_idx[:k].copy_(torch.from_numpy(O.select_k_largest(nb, k) if self.order else O.select_k_smallest(nb, k)))
+        kept_idx[:k].copy_(torch.from_numpy(O.select_k_largest(nb, k) if (mode & 1) else O.select_k_smallest(nb, k)))
 
     def gather_kv(self, k_src, v_src, src_head_stride, idx, k, n_kv, D, k_dst, v_dst, dst_head_stride, dst_row0):
         ii = idx[:k].long()
@@ -81,8 +77,8 @@ class OracleOps:
             self._rows(v_dst, h, dst_head_stride, dst_row0, k, D).copy_(self._rows(v_src, h, src_head_stride, 0, n_src, D)[ii])
 
     def prune_staged(self, head_sumsq, n_heads_total, n, k, k_src, v_src, src_head_stride, n_kv, D, k_dst, v_dst, dst_head_stride,
-                     dst_row0, kept_idx, norm_bits=None):
-        self.select_k_smallest(head_sumsq, n_heads_total, n, k, kept_idx)
+                     dst_row0, kept_idx, norm_bits=None, mode=0):
+        self.select_k_smallest(head_sumsq, n_heads_total, n, k, kept_idx, mode=mode)
         self.gather_kv(k_src, v_src, src_head_stride, kept_idx, k, n_kv, D, k_dst, v_dst, dst_head_stride, dst_row0)
 
     PRUNE_KEYS_MAX_N = 8192

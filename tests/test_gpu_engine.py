@@ -168,6 +168,93 @@ def test_engine_72b_tp8_rank_slice_vs_oracle():
     check_logits(logits.numpy(), ref["logits"].numpy())
 
 
+def _oracle_trace(w, spec_o, embeds, pos, group_tokens, top_p):
+    """oracle.group_prefill's loop with the residual stream recorded after every layer: -> (hidden[(segment, layer)] fp32, kept, cache_len)."""
+    cache = O.OracleCache(spec_o.n_layers)
+    post, start, hid, kept = torch.from_numpy(pos), 0, {}, {}
+    segs = list(group_tokens) + [embeds.shape[0] - sum(group_tokens)]
+    for gi, n in enumerate(segs):
+        tail = gi == len(segs) - 1
+        h = embeds[start:start + n]
+        cos, sin = O.mrope_cos_sin(post[:, start:start + n], spec_o, embeds.dtype)
+        for l in range(spec_o.n_layers):
+            kk = None if tail else O.effective_k(n, None, top_p, None, None, l, spec_o.n_layers)
+            h, kp, cos, sin = O.decoder_layer(h, w, l, spec_o, cache, cos, sin, kk)
+            hid[(gi, l)], kept[(gi, l)] = h.float(), kp
+        start += n
+    return hid, kept, [cache.length(l) for l in range(spec_o.n_layers)]
+
+
+def _row_cosine_min_mean(a, b):
+    c = torch.nn.functional.cosine_similarity(a.float(), b.float(), dim=-1)
+    return float(c.min()), float(c.mean())
+
+
+def test_engine_cfg5_rank_shape_vs_oracle(monkeypatch):
+    """BASELINE.json configs[4] (Qwen2-VL-72B, TP=8, 512 frames of 224x420, group_size 16, rho 0.5) at its OWN per-rank shape:
+    d = 8192, 8 q heads + 1 kv head, I/8 = 3696 MLP columns, groups of n = 960 tokens (8 frame pairs x 120), k = 480, 4 layers,
+    DEFAULT-std (0.02) hash-generated weights; 3 groups + prompt tail through forward_segment on the GPU vs the CPU oracle.
+
+    At this width attention is peaky (q.k/sqrt(D) has std ~3) and final logits amplify a handful of near-tie flips in the kept
+    sets (two implementations that are both right differ by 0.6 in a logit: tools/probe/dbg_engine_slice.py), so the logit check
+    lives in test_engine_72b_tp8_rank_slice_vs_oracle with damped weights.  Here the ROBUST quantities are pinned, and the bar is
+    not "what the GPU produced" but the distance between TWO CPU evaluations of the same model that differ only in GEMM
+    accumulation (torch's bf16 linear vs fp32-accumulated matmul rounded once): the GPU may be at most twice as far from the
+    oracle as that second CPU implementation is, plus a stated absolute slack —
+        cache lengths: exact;
+        kept-set overlap per (group, layer): 1 - ov_gpu <= 2 * (1 - ov_cpu2) + 0.02;
+        residual-stream rows after every layer, mean row cosine: 1 - cos_gpu <= 2 * (1 - cos_cpu2) + 2e-3; worst row >= 0.90."""
+    dims = dict(hidden=8192, n_heads=8, n_kv_heads=1, head_dim=128, intermediate=3696, n_layers=4, vocab=1024)
+    spec, spec_o = TextSpec(**dims), O.TextSpec(**dims)
+    w = O.hashed_text_weights(spec_o, seed=31, device="cuda", norm_jitter=0.05)            # std = 0.02, the synthetic default
+    frames, gh, gw, gs, prefix, tail = 48, 16, 30, 16, 15, 24                            # 224x420 frames -> 16x30 patches; 3 groups x 960
+    T = prefix + (frames // 2) * (gh // 2) * (gw // 2) + tail
+    plan = planner.plan_groups(frames, gs, gh, gw, prefix, T)
+    assert plan.tokens == [975, 960, 960]
+    pos, _ = planner.mrope_positions(prefix, (frames // 2, gh, gw), tail)
+    embeds = O.hashed_normal((T, spec.hidden), 32, 0.5)
+    cfg = LVUConfig("x", top_p=0.5, video_group_size=gs)
+    dw = DecoderWeights.from_named(spec, w, "cuda:0")
+    eng = QuickPrefillEngine(dw, cfg, capacity=T + 8, max_group_tokens=max(plan.tokens + [plan.tail_len]), device="cuda:0")
+    eng.kept_trace, eng.hidden_trace = [], []
+    post, e, start = torch.from_numpy(pos).cuda(), embeds.cuda(), 0
+    for n in plan.tokens:
+        eng.prefill_group(e[start:start + n], post[:, start:start + n]); start += n
+    eng.prefill_tail(e[start:], post[:, start:])
+    torch.cuda.synchronize()
+    wc = {k: v.cpu() for k, v in w.items()}
+    hid, kept, clen = _oracle_trace(wc, spec_o, embeds, pos, plan.tokens, 0.5)
+    # second CPU implementation: same oracle code, every linear accumulated in fp32 and rounded once
+    lin = lambda x, ww, b=None: ((x.float() @ ww.float().t()) + (0 if b is None else b.float())).to(x.dtype)    # noqa: E731
+    monkeypatch.setattr(torch.nn.functional, "linear", lin)
+    hid2, kept2, clen2 = _oracle_trace(wc, spec_o, embeds, pos, plan.tokens, 0.5)
+    monkeypatch.undo()
+    assert eng.arena.len == clen == clen2
+    L, S = spec.n_layers, len(plan.tokens) + 1
+    assert len(eng.hidden_trace) == S * L and len(eng.kept_trace) == S * L
+    rows = []
+    for si in range(S):
+        for l in range(L):
+            (lg, got), (lh, hg) = eng.kept_trace[si * L + l], eng.hidden_trace[si * L + l]
+            assert lg == l and lh == l
+            cmin, cmean = _row_cosine_min_mean(hg.cpu(), hid[(si, l)])
+            _, cmean2 = _row_cosine_min_mean(hid2[(si, l)], hid[(si, l)])
+            ov = ov2 = 1.0
+            if kept[(si, l)] is not None:
+                g, want, w2 = got.cpu().numpy(), kept[(si, l)], kept2[(si, l)]
+                assert len(g) == len(want) and np.all(np.diff(g) > 0)
+                ov = len(set(g.tolist()) & set(want.tolist())) / len(want)
+                ov2 = len(set(w2.tolist()) & set(want.tolist())) / len(want)
+            rows.append((si, l, ov, ov2, cmean, cmean2, cmin))
+    print("segment layer  overlap(gpu) overlap(cpu2)  mean-row-cos(gpu) (cpu2)  min-row-cos(gpu)")
+    for r in rows:
+        print("   %d      %d      %.4f       %.4f          %.5f      %.5f     %.4f" % r)
+    for si, l, ov, ov2, cmean, cmean2, cmin in rows:
+        assert 1 - ov <= 2 * (1 - ov2) + 0.02, (si, l, ov, ov2)
+        assert 1 - cmean <= 2 * (1 - cmean2) + 2e-3, (si, l, cmean, cmean2)
+        assert cmin >= 0.90, (si, l, cmin)
+
+
 @pytest.mark.parametrize("pt", ["query_attention_weights", "query_attention_weights_by_value_norm"])
 def test_engine_query_based_vs_oracle(pt):
     """SURVEY 8 f4 on the GPU: prompt-appended groups, qp_query_scores + qp_prune_keys, the shifted causal alignment as two attention
@@ -297,7 +384,7 @@ def test_generation_kwargs_on_gpu(monkeypatch):
 
 @pytest.mark.parametrize("mode", ["key_norms", "vector_norms", "vector_norms_small"])
 def test_engine_other_norm_modes_vs_oracle(mode):
-    """qp_set_prune_mode through the engine: the other norm-based predict types against the composite oracle."""
+    """prune_mode through the engine: the other norm-based predict types against the composite oracle."""
     spec_o, w, plan, pos, delta, embeds = make_case(24, 12, 16, 8, 15, 20)
     cfg = LVUConfig("x", top_p=0.5, video_group_size=8, top_k_predict_type=mode)
     eng, logits = run_gpu(TINY, w, plan, pos, embeds, cfg)
@@ -312,7 +399,6 @@ def test_engine_other_norm_modes_vs_oracle(mode):
             assert len(g) == len(want) and np.all(np.diff(g) > 0)
             tot += len(want); same += len(set(g.tolist()) & set(want.tolist()))
     assert same / tot >= 0.90, same / tot
-    eng.ops.set_prune_mode(0, 0)
 
 
 def test_gemm_tuning_does_not_change_results(monkeypatch):
