@@ -10,7 +10,15 @@ the keys of layer l depend on 28 bf16 GEMM chains whose fp32 accumulation order 
 and a group's bf16 norms fall on a few dozen values — so a rounding flip in one key norm can move a token across the threshold.
 The test therefore pins (1) every cache length exactly, (2) the first generated token exactly (reference top-2 margin 0.9),
 (3) the first-token logits within DEEP_ATOL / cosine, and (4) the per-layer kept-set overlap with the reference, which must
-stay above a bound that is allowed to fall with depth (reported in the assertion message and printed)."""
+stay above a bound that is allowed to fall with depth (reported in the assertion message and printed).
+
+Where the bars come from (round 3): NOT from the GPU's own output.  tests/golden/gv8_deep_oracle_calibration.json is the record of
+the independent CPU restatement (oracle/qp_oracle.py, torch-CPU bf16) run against the same fixture by oracle/calibrate_deep.py
+(13 min of CPU): max|d logit| 0.2129, cosine 0.998940, same argmax, per-layer kept-set overlap 1.000 ... 0.969.  The GPU path
+may be at most 1.25x as far from the reference composite as that CPU implementation is:
+    max|d| <= 1.25 * 0.2129 = 0.266;   1 - cosine <= 1.25 * (1 - 0.998940);
+    overlap(layer l) >= 1 - 1.25 * (1 - e(l)) - 0.005,  e(l) = min over layers <= l of the oracle's overlap (its monotone
+    envelope: single layers of either implementation wobble by a few tokens of 640)."""
 import json
 import os
 
@@ -27,8 +35,17 @@ from quickvideo_amd.weights import DecoderWeights
 
 pytestmark = pytest.mark.gpu
 
-DEEP_ATOL, DEEP_COS = 3.0e-1, 0.997          # |logit| up to 5.6 after 28 layers; measured on MI355X: max|d| 0.232, cosine 0.99897
-OVERLAP_FLOOR = lambda layer: 0.96 - 0.0015 * layer     # noqa: E731  bound as a function of depth; measured: 1.000 at layer 0, 0.970-0.992 below
+SLACK = 1.25                                   # the GPU may be this much farther from the reference than the CPU oracle is
+
+
+def bars_from_oracle_calibration(golden_dir):
+    cal = json.load(open(os.path.join(golden_dir, "gv8_deep_oracle_calibration.json")))
+    assert cal["cache_len_equal"] and cal["argmax"] == cal["reference_argmax"]
+    atol = SLACK * cal["logits_max_abs_diff"]
+    cos = 1.0 - SLACK * (1.0 - cal["logits_cosine"])
+    env = np.minimum.accumulate(np.asarray(cal["overlap_min_over_groups_by_layer"]))
+    floor = 1.0 - SLACK * (1.0 - env) - 0.005
+    return atol, cos, floor, cal
 
 
 def test_full_depth_7b_dims_vs_reference_composite(golden_dir):
@@ -56,6 +73,10 @@ def test_full_depth_7b_dims_vs_reference_composite(golden_dir):
     logits = eng.prefill_tail(embeds[start:], post[:, start:]).cpu().numpy()
     torch.cuda.synchronize()
     L, G = spec.n_layers, len(plan.tokens)
+    DEEP_ATOL, DEEP_COS, floor, cal = bars_from_oracle_calibration(golden_dir)
+    OVERLAP_FLOOR = lambda layer: floor[layer]                   # noqa: E731
+    print(f"bars from the CPU oracle's own distance to the fixture (x{SLACK}): max|d| <= {DEEP_ATOL:.4f}, cosine >= {DEEP_COS:.6f}, "
+          f"overlap floor by layer: " + " ".join(f"{x:.3f}" for x in floor))
     # (1) cache lengths: exact
     assert eng.arena.len == list(gold["cache_len"])
     # (4) kept sets per (group, layer)
@@ -77,7 +98,7 @@ def test_full_depth_7b_dims_vs_reference_composite(golden_dir):
     cos = float(np.dot(logits, ref) / (np.linalg.norm(logits) * np.linalg.norm(ref)))
     print(f"first-token logits after 28 layers: max|d| = {err:.4f} (|logit| max {np.abs(ref).max():.2f}), cosine = {cos:.5f}, "
           f"argmax {int(np.argmax(logits))} vs reference {meta['argmax']} (reference top-2 margin {meta['top2_margin']:.3f})")
-    assert overlap[:, 0].min() >= 0.97, overlap[:, 0]            # layer 0 sees identical inputs: only GEMM rounding in K
+    assert overlap[:, 0].min() >= 0.99, overlap[:, 0]            # layer 0 sees identical inputs: only GEMM rounding in K
     for l in range(L):
         assert per_layer[l] >= OVERLAP_FLOOR(l), (l, per_layer[l], per_layer)
     assert int(np.argmax(logits)) == meta["argmax"]
