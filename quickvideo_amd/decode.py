@@ -114,8 +114,13 @@ class GraphDecoder:
         eng.seq_pos += 1
         return self.logits
 
-    def generate(self, first_token: int, max_new_tokens: int, rope_delta: int, eos_token_id: Optional[int] = None) -> List[int]:
-        """Greedy continuation after `first_token` (the TTFT token): up to max_new_tokens further tokens."""
+    def generate(self, first_token: int, max_new_tokens: int, rope_delta: int, eos_token_id=None) -> List[int]:
+        """Greedy continuation after `first_token` (the TTFT token): up to max_new_tokens further tokens.  eos_token_id: an id or a
+        collection of ids — HF generate stops on ANY id of generation_config.eos_token_id ([151645, 151643] for Qwen2/2.5-VL)."""
+        if eos_token_id is not None and not isinstance(eos_token_id, (set, frozenset)):
+            eos_token_id = frozenset(int(e) for e in (eos_token_id if isinstance(eos_token_id, (list, tuple)) else [eos_token_id]))
+        if not eos_token_id:
+            eos_token_id = None
         if max_new_tokens <= 0:
             return []
         self.begin(rope_delta)
@@ -130,7 +135,7 @@ class GraphDecoder:
                 toks[i:i + 1].copy_(self.tok)
             return [int(t) for t in toks.tolist()]
         for _ in range(max_new_tokens):
-            if tok == eos_token_id:
+            if tok in eos_token_id:
                 break
             self.step()
             tok = int(self.tok.item())

@@ -76,8 +76,7 @@ class QuickPrefillEngine:
         # issued on it (all-reduce of [n, d], all-gather of the key sums / of the K|V|sums exchange block).  That is how a 1-GPU
         # box pre-flights the RCCL path (backend "nccl", world_size 1: dtype / shape / device-binding errors surface without a
         # second GPU — tests/test_gpu_engine.py, bench.py --nccl-preflight); with no group a single rank issues no collective.
-        self.tp_on = self.tp_size > 1 or tp_group is not None
-        self.sp_on = self.sp_size > 1 or sp_group is not None
+        # (tp_on / sp_on are properties: bench.py attaches the groups after construction)
         assert not (self.sp_on and self.tp_on), "choose tensor parallel OR group-token parallel"
         # layer-pipeline parallelism ("pp"): rank r holds a contiguous slice of the layers (weights AND their KV), receives a group's
         # hidden rows from rank r-1, runs its layers and hands the rows to rank r+1.  No collective: one [n, d] point-to-point
@@ -102,13 +101,9 @@ class QuickPrefillEngine:
         self.b_q, self.b_att = e(n, self.hq, self.D), e(n, self.hq, self.D)
         self.b_gu, self.b_act = e(n, 2 * self.li), e(n, self.li)
         self.b_stage = e(2, self.hkv, n + 2 * self.sp_size, self.D)
-        if self.sp_on:
-            m = 2 * -(-n // (2 * self.sp_size))                                           # two chunks of ceil(n / 2N) rows
-            self.sp_chunk = 2 * self.hkv * m * self.D * 2 + self.hkv * m * 4              # bytes: K | V | key sums of one rank
-            self.b_xsend = e(self.sp_chunk, dtype=torch.uint8)
-            self.b_xall = e(self.sp_size * self.sp_chunk, dtype=torch.uint8)
+        self.b_xsend = self.b_xall = self.b_ss_all = None                                 # exchange buffers: _parallel_buffers()
         self.b_ss = e(self.hkv, n, dtype=torch.float32)
-        self.b_ss_all = e(self.tp_size, self.hkv, n, dtype=torch.float32) if self.tp_on else None
+        self._parallel_buffers()
         self.b_idx = e(n, dtype=torch.int32)
         self.b_idx_pp = e(n, dtype=torch.int32) if self.pp_size > 1 else None   # original rows of a hidden-pruned hand-off
         # prune through 16-bit norm keys (qp_prune_keys): the keys of the group's tokens, written by the RoPE kernel
@@ -140,6 +135,25 @@ class QuickPrefillEngine:
         self.seq_pos = 0                            # tokens of the original sequence consumed so far
 
     # ------------------------------------------------------------------ helpers
+    @property
+    def tp_on(self) -> bool:
+        return self.tp_size > 1 or self.tp_group is not None
+
+    @property
+    def sp_on(self) -> bool:
+        return self.sp_size > 1 or self.sp_group is not None
+
+    def _parallel_buffers(self):
+        """Exchange buffers of the parallel layouts, allocated when the layout is (or becomes) active."""
+        n, dev = self.n_max, self.device
+        if self.sp_on and self.b_xsend is None:
+            m = 2 * -(-n // (2 * self.sp_size))                                           # two chunks of ceil(n / 2N) rows
+            self.sp_chunk = 2 * self.hkv * m * self.D * 2 + self.hkv * m * 4              # bytes: K | V | key sums of one rank
+            self.b_xsend = torch.empty(self.sp_chunk, dtype=torch.uint8, device=dev)
+            self.b_xall = torch.empty(self.sp_size * self.sp_chunk, dtype=torch.uint8, device=dev)
+        if self.tp_on and self.b_ss_all is None:
+            self.b_ss_all = torch.empty(self.tp_size, self.hkv, n, dtype=torch.float32, device=dev)
+
     def reset(self):
         self.arena.reset()
         self.seq_pos = 0
@@ -327,6 +341,7 @@ class QuickPrefillEngine:
         n = pos.shape[1]                             # embeds may hold only this rank's rows (sp stage behind another stage)
         assert n <= self.n_max, f"group of {n} tokens exceeds max_group_tokens={self.n_max}"
         self._seg_rows = row_idx
+        self._parallel_buffers()
         if self._sp_active(n):
             return self._forward_segment_sp(embeds, pos, prune, video_group)
         if row_idx is not None:                      # positions of the surviving rows only (utils.py:344-372 gathers them the same way)

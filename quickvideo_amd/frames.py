@@ -9,6 +9,12 @@ InterleavedVideoReader [3P] as used in qwen25_lvu_interleaved.py:385-410, 438-44
 
 There is no FFmpeg / codec in this image, so real containers cannot be decoded; the sources here are
   * synthetic://?frames=F&h=H&w=W&fps=R&seed=S[&pattern=noise|gradient]   seeded frames generated on the fly
+    [&decode_h=1080&decode_w=1920[&decode_s=21.3]]   a source that COSTS something, like a decoder: every frame is produced at the
+    decode size on one of the reader's `num_threads` workers (QUICKCODEC_CORES) and resized to the requested height x width with
+    PIL's LANCZOS filter — the interpolation the reference asks its decoder for (interleaved:438-442).  decode_s = wall seconds
+    the whole sampled frame set should cost at this thread count (the reference's figure: 21.3 s of QuickCodec time for a 60-minute
+    video on 16 threads, assets/imgs/video_processing_times.png): each worker pads its frame to decode_s * threads / n_frames with a
+    sleep when the real work was cheaper (a codec's latency without burning the host); never shortens real work
   * *.npy / *.pt files holding uint8 [F, 3, H, W] (pre-decoded video)
 A real decoder plugs in by implementing the same five members.  Environment knobs QUICKCODEC_CORES /
 QUICKCODEC_INTERVALS are read like the reference does (interleaved:391-392) and passed to the reader."""
@@ -63,12 +69,42 @@ class SyntheticVideoReader(VideoReaderBase):
         self.total = int(q.get("frames", 64))
         self.src_h, self.src_w = int(q.get("h", 1080)), int(q.get("w", 1920))
         self.fps, self.seed, self.pattern = float(q.get("fps", 2.0)), int(q.get("seed", 1)), q.get("pattern", "noise")
+        self.decode_h, self.decode_w = int(q.get("decode_h", 0)), int(q.get("decode_w", 0))
+        self.decode_s = float(q.get("decode_s", 0.0))
+        self._frame_budget = 0.0          # seconds one worker spends per frame (set in process(): decode_s * threads / n_frames)
+        self.work_seconds = 0.0           # thread-seconds of real work (generate + resize), for the report
+        self._texture = None
         self._pool = None
+
+    def process(self, idx):
+        super().process(idx)
+        self.work_seconds = 0.0
+        self._frame_budget = self.decode_s * max(self.num_threads, 1) / max(len(self._idx), 1) if self.decode_s > 0 else 0.0
 
     def __len__(self): return self.total
     def get_fps(self): return self.fps
 
+    def _decoded_frame(self, out, j, i, H, W):
+        """Frame i at the decode size -> LANCZOS resize to H x W (PIL releases the GIL; the workers run in parallel)."""
+        import time
+        from PIL import Image
+        t0 = time.perf_counter()
+        # "decoded" picture = one seeded noise texture, rolled by the frame index and XORed with a per-frame byte: a pure function of
+        # (seed, i) made of large-array numpy ops, which release the GIL (RandomState.randint per frame does not: 8 threads ran
+        # no faster than one)
+        if self._texture is None:
+            self._texture = np.random.RandomState(self.seed % (2 ** 31)).randint(0, 256, (self.decode_h, self.decode_w, 3), dtype=np.uint8)
+        src = np.bitwise_xor(np.roll(self._texture, int(i) % self.decode_h, axis=0), np.uint8((int(i) * 37) & 255))
+        img = Image.fromarray(src).resize((W, H), Image.LANCZOS)
+        out[j] = np.asarray(img).transpose(2, 0, 1)
+        dt = time.perf_counter() - t0
+        self.work_seconds += dt            # (approximate under threads: float += is not atomic; a report figure only)
+        if dt < self._frame_budget:
+            time.sleep(self._frame_budget - dt)
+
     def _frame(self, out, j, i, H, W):
+        if self.decode_h and self.decode_w:
+            return self._decoded_frame(out, j, i, H, W)
         if self.pattern == "gradient":
             yy = (np.arange(H, dtype=np.uint32)[:, None] * 255 // max(H - 1, 1))
             xx = (np.arange(W, dtype=np.uint32)[None, :] * 255 // max(W - 1, 1))

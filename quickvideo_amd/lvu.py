@@ -73,7 +73,7 @@ def _load_hf_dir(path: str, device) -> QwenVLNative:
     gpath = os.path.join(path, "generation_config.json")           # HF `generate` applies it implicitly (Qwen2.5-VL ships do_sample /
     if os.path.exists(gpath):                                       # temperature 1e-6 / top_k 1 / top_p 0.001 / repetition_penalty 1.05)
         g = json.load(open(gpath))
-        gen = {k: g[k] for k in ("do_sample", "temperature", "top_k", "top_p", "repetition_penalty") if k in g}
+        gen = {k: g[k] for k in ("do_sample", "temperature", "top_k", "top_p", "repetition_penalty", "eos_token_id") if k in g}
     return QwenVLNative(DecoderWeights.from_named(spec, text, device), VisionWeights.from_named(vspec, vis, device), device, name=path,
                         generation_defaults=gen)
 

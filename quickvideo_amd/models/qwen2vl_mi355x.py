@@ -15,40 +15,42 @@ def init_lvu_model(model: QwenVLNative, config: LVUConfig):
     return model
 
 
-def _content_question(messages):
-    video, question = None, ""
-    for m in messages:
-        for c in (m["content"] if isinstance(m["content"], list) else [{"type": "text", "text": m["content"]}]):
-            if c.get("type") == "video":
-                assert video is None, "Only one video is supported for now."      # qwen25_lvu.py:554
-                video = c["video"]
-            elif c.get("type") == "text":
-                question += c["text"]
-    assert video is not None, "Only one video is supported for now."
-    return video, question
+def _the_video(messages):
+    """The single video entry of the conversation (qwen25_lvu.py:552-554: `extract_vision_info`, one video only)."""
+    videos = [c["video"] for m in messages if not isinstance(m["content"], str) for c in m["content"]
+              if c.get("type") == "video" or "video" in c]
+    assert len(videos) == 1, "Only one video is supported for now."
+    return videos[0]
 
 
 def chat_lvu_model(self, messages, _overlap: bool = True, **generation_kwargs):
-    """`_overlap` is how the sequential plugin (qwen2vl_mi355x_sequential) reuses this function: an argument, not a module global,
+    """`messages` goes to the processor's chat template as it is (system / user / assistant turns, several text entries): the
+    reference renders `processor.apply_chat_template(messages, tokenize=False, add_generation_prompt=True)` (qwen25_lvu.py:546-548).
+    `_overlap` is how the sequential plugin (qwen2vl_mi355x_sequential) reuses this function: an argument, not a module global,
     so two LVU objects of different plugins can generate concurrently."""
-    video, question = _content_question(messages)
+    video = _the_video(messages)
     pipe = getattr(self, "_pipeline", None)
-    if pipe is None or pipe.cfg is not self.config or pipe.model is not self.model:
+    if pipe is None or pipe.cfg is not self.config or pipe.model is not self.model or pipe.processor is not self.processor:
         pipe = PrefillPipeline(self.model, self.config, self.processor, ops=getattr(self, "_ops", None))
         self._pipeline = pipe
     mnt = generation_kwargs.pop("max_new_tokens", 16)
-    if "eos_token_id" not in generation_kwargs:              # HF generate stops at the generation config's EOS (qwen25_lvu.py:740)
-        eos = getattr(self.processor, "eos_token_id", None)
+    if "eos_token_id" not in generation_kwargs:
+        # HF generate stops on ANY id of the checkpoint's generation_config.eos_token_id ([<|im_end|>, <|endoftext|>] for
+        # Qwen2/2.5-VL; qwen25_lvu.py:740); without one: the tokenizer's EOS, else <|im_end|> (a chat turn ends with it)
+        eos = (getattr(self.model, "generation_defaults", None) or {}).get("eos_token_id")
         if eos is None:
             eos = getattr(getattr(self.processor, "tokenizer", None), "eos_token_id", None)
         if eos is None:
-            eos = getattr(self.processor, "im_end", None)   # Qwen2-VL chat models end a turn with <|im_end|>
+            eos = getattr(self.processor, "eos_token_id", None)
+        if eos is None:
+            eos = getattr(self.processor, "im_end", None)
         generation_kwargs["eos_token_id"] = eos
-    ids = pipe.generate(question, video, max_new_tokens=mnt, overlap=_overlap, **generation_kwargs)
+    ids = pipe.generate(messages, video, max_new_tokens=mnt, overlap=_overlap, **generation_kwargs)
     t = pipe.last_timings
-    # the reference prints these six lines (qwen25_lvu.py:748-753); ours are device-synchronised
-    print(f"total time spent fetching frames was: {t.fetch}")
-    print(f"total time spent on processor was: {t.vit}")
+    # the reference prints these six lines (qwen25_lvu.py:748-753) from unsynchronised host clocks; here: the producer's time inside
+    # the frame source, the ViT by itself, the device-synchronised group loop, decode, e2e, first token
+    print(f"total time spent fetching frames was: {t.sequential_fetch if not _overlap else t.producer_busy}")
+    print(f"total time spent on processor was: {t.vit_uncontended}")
     print(f"total time spent on prefill was: {t.prefill}")
     print(f"total time spent on decoding was: {t.decode}")
     print(f"total time spent on e2e fetching and decoding was: {t.e2e}")

@@ -25,6 +25,7 @@ from .decode import GraphDecoder
 from .frames import open_video, smart_nframes
 from .native import host_memcpy
 from .lvu_config import LVUConfig, effective_k
+from .processor import as_messages, prompt_from_messages
 from .sampling import TokenSelector
 from .spec import TextSpec
 from .vit import VisionTower, VisionWeights, patchify_frames
@@ -50,14 +51,28 @@ class QwenVLNative:
 
 @dataclass
 class Timings:
-    fetch: float = 0.0          # time the consumer waited for frames (video_processing_time analogue)
-    vit: float = 0.0            # device time of patchify + ViT (events)
-    prefill: float = 0.0        # group loop wall time, device-synchronised at the end (total_prefill)
+    """Seconds.  Host clocks: perf_counter; device intervals: HIP events of the three streams against one origin event.
+    The reference reports `video_processing_time`, `total_prefill` and `e2e_time` from unsynchronised host clocks
+    (qwen25_lvu_interleaved.py:852-905); here every figure says which resource it measures, so a reader can tell a slow
+    producer from a busy GPU."""
+    prefill: float = 0.0               # group loop wall time, device-synchronised at the end (total_prefill)
     decode: float = 0.0
     e2e: float = 0.0
-    ttft: float = 0.0           # first frame requested -> first token id on the host
+    ttft: float = 0.0                  # video opened -> first token id on the host
     tokens: int = 0
     groups: int = 0
+    # host side of the producer (the reference's decode + resize + processor thread)
+    producer_busy: float = 0.0         # inside next(reader): decoding / resizing frames (the cost the overlap is meant to hide)
+    producer_blocked: float = 0.0      # waiting for a free ring slot or for the previous H2D out of it: back-pressure, the GPU is the bottleneck
+    producer_copy: float = 0.0         # filling the pinned slot + enqueueing the H2D copy
+    sequential_fetch: float = 0.0      # overlap=False only: wall time of fetching EVERY group before the GPU starts (video_processing_time)
+    consumer_get_wait: float = 0.0     # host thread blocked in queue.get() (it runs ahead of the GPU, so this is NOT GPU idle time)
+    # device side (event timestamps)
+    gpu_prefill_busy: float = 0.0      # sum over groups of prefill(g) on the main stream
+    gpu_stall_frames: float = 0.0      # main stream idle between groups because group g's frames had not been uploaded yet: TRUE frame wait
+    gpu_stall_vit: float = 0.0         # main stream idle because ViT(g) was not finished although its frames were there (ViT not hidden)
+    vit_span: float = 0.0              # sum of ViT(g) start->end on its own stream WHILE the prefill shares the CUs (contended)
+    vit_uncontended: float = 0.0       # ViT of one group replayed alone after the run, x groups: what the tower costs by itself
 
 
 class _GpuProgress(threading.Thread):
@@ -101,12 +116,18 @@ class _Producer(threading.Thread):
         self.fpg = frames_per_group
         self.h2d_done = [None] * depth      # per slot: event after the last H2D copy out of the pinned buffer (copy stream)
         self.read_done = [None] * depth     # per slot: event after the consumer's last GPU read of the device buffer (ViT stream)
+        self.t_busy = self.t_blocked = self.t_copy = 0.0    # host seconds: in next(reader) / waiting for a slot / filling + enqueueing
 
     def run(self):
         try:
+            pc = time.perf_counter
             for g in range(self.n_groups):
-                frames = next(self.reader)                      # uint8 [g,3,H,W] (CPU work, GIL released inside numpy)
+                t0 = pc()
+                frames = next(self.reader)                      # uint8 [g,3,H,W] (CPU work, GIL released inside numpy / PIL)
+                t1 = pc()
+                self.t_busy += t1 - t0
                 self.slots_free.acquire()
+                self.t_blocked += pc() - t1
                 if self.use_gpu:
                     if self.ring is None:
                         shape = (self.fpg,) + tuple(frames.shape[1:])
@@ -122,8 +143,11 @@ class _Producer(threading.Thread):
                     # previous H2D copy out of it has finished (host-side wait, this thread only); (2) the device buffer may only
                     # be overwritten once the consumer's last GPU read of it (patchify on the ViT stream) has finished — the
                     # consumer hands that event back through release() and the copy stream waits on it.
+                    t2 = pc()
                     if self.h2d_done[slot] is not None:
                         self.h2d_done[slot].synchronize()
+                    t3 = pc()
+                    self.t_blocked += t3 - t2
                     # native, GIL-free fill of the pinned slot (qp_host_memcpy through ctypes; 2-10x faster than Tensor.copy_ here,
                     # whose speed follows torch's process-wide intra-op thread count): the launching thread is never starved
                     host_memcpy(host[: frames.shape[0]], frames.contiguous())
@@ -131,9 +155,10 @@ class _Producer(threading.Thread):
                         if self.read_done[slot] is not None:
                             self.copy_stream.wait_event(self.read_done[slot])
                         dev[: frames.shape[0]].copy_(host[: frames.shape[0]], non_blocking=True)
-                        ev = torch.cuda.Event()
+                        ev = torch.cuda.Event(enable_timing=True)
                         ev.record(self.copy_stream)
                     self.h2d_done[slot] = ev
+                    self.t_copy += pc() - t3
                     self.q.put((g, dev[: frames.shape[0]], ev))
                 else:
                     self.q.put((g, frames.clone(), None))
@@ -172,7 +197,8 @@ class PrefillPipeline:
         return self._tower
 
     # ------------------------------------------------------------------ planning (no pixels needed)
-    def plan(self, reader, question: str):
+    def plan(self, reader, question):
+        """`question`: the user's text or the reference's `messages` list (one video entry; qwen25_lvu.py:546-554)."""
         cfg, spec = self.cfg, self.model.spec
         total, vfps = len(reader), reader.get_fps()
         nframes = smart_nframes(total, vfps, nframes=cfg.num_frames if cfg.fps is None else None, fps=cfg.fps)
@@ -187,16 +213,19 @@ class PrefillPipeline:
         idx = np.linspace(0, total - 1, nframes).round().astype(np.int64)   # interleaved:397-399
         vs = self.model.vision.spec
         gh, gw = H // vs.patch_size, W // vs.patch_size
-        prompt = self.processor.build_prompt(question)
+        # the processor seam (lvu/lvu.py:18-23): the caller's own processor renders the chat template and tokenises it
+        prompt = prompt_from_messages(self.processor, as_messages(question))
         n_video = (nframes // vs.temporal_patch_size) * (gh // 2) * (gw // 2)
         T = len(prompt.prefix_ids) + n_video + len(prompt.tail_ids)
         gs = cfg.video_group_size
         plan = planner.plan_groups(nframes, gs, gh, gw, len(prompt.prefix_ids), T, vs.temporal_patch_size, vs.spatial_merge_size)
         # Qwen2.5-VL: tokens_per_second * second_per_grid_t with second_per_grid_t = temporal_patch / sampled fps
         sample_fps = nframes / max(total / vfps, 1e-9)             # qwen-vl-utils: video_sample_fps = nframes / total_frames * video_fps
-        tscale = spec.resolved_temporal_scale(sample_fps, vs.temporal_patch_size)
+        q25 = spec.temporal_scale < 0                                # Qwen2.5-VL: HF's float32 expression (planner.temporal_ids)
         pos, delta = planner.mrope_positions(len(prompt.prefix_ids), (nframes // vs.temporal_patch_size, gh, gw), len(prompt.tail_ids),
-                                             vs.spatial_merge_size, tscale)
+                                             vs.spatial_merge_size, spec.temporal_scale if not q25 else 1.0,
+                                             second_per_grid_t=vs.temporal_patch_size / sample_fps if q25 else None,
+                                             tokens_per_second=-spec.temporal_scale if q25 else None)
         return dict(nframes=nframes, H=H, W=W, idx=idx, prompt=prompt, plan=plan, pos=pos, delta=delta, T=T, gh=gh, gw=gw)
 
     def _engine(self, plan, T, max_new_tokens: int = 0) -> QuickPrefillEngine:
@@ -215,18 +244,22 @@ class PrefillPipeline:
 
     # ------------------------------------------------------------------ video -> tokens
     @torch.no_grad()
-    def generate(self, question: str, video, max_new_tokens: int = 16, overlap: bool = True, eos_token_id: Optional[int] = None,
+    def generate(self, question, video, max_new_tokens: int = 16, overlap: bool = True, eos_token_id=None,
                  do_sample: Optional[bool] = None, temperature: Optional[float] = None, top_k: Optional[int] = None,
                  top_p: Optional[float] = None, repetition_penalty: Optional[float] = None, seed: Optional[int] = None,
                  num_beams: int = 1, **unused) -> List[int]:
         """generation kwargs as the reference hands them to HF `generate` (qwen25_lvu.py:744-761); unset ones fall back to the
-        checkpoint's generation_config.json (`model.generation_defaults`), then to greedy.  Beam search is refused, not ignored."""
+        checkpoint's generation_config.json (`model.generation_defaults`), then to greedy.  Beam search is refused, not ignored.
+        `question`: the user's text, or the reference's `messages` list (chat(); qwen25_lvu.py:546-548) when the processor can
+        template it.  eos_token_id: an id or a list of ids (HF stops on ANY of generation_config.eos_token_id)."""
         if num_beams != 1:
             raise NotImplementedError("beam search is not implemented (greedy and sampling with temperature / top-k / top-p / repetition penalty are)")
         gd = getattr(self.model, "generation_defaults", None) or {}
         pick = lambda v, k: gd.get(k) if v is None else v
         selector = TokenSelector(pick(do_sample, "do_sample") or False, pick(temperature, "temperature"), pick(top_k, "top_k"),
                                  pick(top_p, "top_p"), pick(repetition_penalty, "repetition_penalty"), seed, device=self.model.device)
+        eos = pick(eos_token_id, "eos_token_id")
+        eos_set = frozenset() if eos is None else frozenset(int(e) for e in (eos if isinstance(eos, (list, tuple, set, frozenset)) else [eos]))
         tm = Timings()
         dev = self.model.device
         t_e2e = time.perf_counter()
@@ -241,22 +274,28 @@ class PrefillPipeline:
         self.model.rope_deltas = P["delta"]                           # qwen25_lvu.py:620
         prefix = torch.tensor(P["prompt"].prefix_ids, dtype=torch.long, device=dev)
         tail = torch.tensor(P["prompt"].tail_ids, dtype=torch.long, device=dev)
-        # overlapped: bounded ring of 3 groups like the reference's Queue(maxsize=3); sequential: everything is fetched first
+        G = len(plan.tokens)
+        if not overlap:
+            # sequential plugin (the reference's non-interleaved path, qwen25_lvu.py:551-575): EVERY frame group is fetched before the
+            # GPU sees the first one; the groups then go through the same 3-slot ring (a memcpy + H2D each), so the GPU side of the two
+            # modes is identical and ttft(sequential) - ttft(overlapped) is what the overlap hides
+            t0 = time.perf_counter()
+            fetched = [next(reader) for _ in range(G)]
+            tm.sequential_fetch = time.perf_counter() - t0
+            reader = iter(fetched)
         if not hasattr(self, "_ring_cache"):
             self._ring_cache = {}
-        prod = _Producer(reader, len(plan.tokens), gs, dev, depth=3 if overlap else len(plan.tokens), ring_cache=self._ring_cache)
-        if overlap:
-            prod.start()
-        else:
-            prod.run()                                                # sequential plugin: fetch everything first
+        prod = _Producer(reader, G, gs, dev, depth=3, ring_cache=self._ring_cache)     # bounded like the reference's Queue(maxsize=3)
+        prod.start()
         sync = (lambda: torch.cuda.synchronize(dev)) if self.use_gpu else (lambda: None)
+        ev_t = (lambda: torch.cuda.Event(enable_timing=True)) if self.use_gpu else (lambda: None)
 
         def vit_group(g):
             t0 = time.perf_counter()
             gi, frames, ev = prod.get()
-            tm.fetch += time.perf_counter() - t0
+            tm.consumer_get_wait += time.perf_counter() - t0
             if self.use_gpu:
-                s_ev, e_ev = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s_ev, e_ev = ev_t(), ev_t()
                 self.vit_stream.wait_event(ev)
                 with torch.cuda.stream(self.vit_stream):
                     s_ev.record(self.vit_stream)
@@ -265,46 +304,55 @@ class PrefillPipeline:
                     read_done.record(self.vit_stream)             # last read of the ring's device slot
                     feats = self.tower.forward(rows, grid)
                     e_ev.record(self.vit_stream)
-                return feats, (s_ev, e_ev), read_done
+                return feats, (s_ev, e_ev, ev), read_done, frames
             rows, grid = patchify_frames(frames, self.model.vision.spec, self.model.text.embed.dtype)
-            return self.tower.forward(rows, grid), None, None
+            return self.tower.forward(rows, grid), None, None, frames
 
         t_pre = time.perf_counter()
-        start, vit_events = 0, []
-        dbg = _GpuProgress(len(plan.tokens)) if (self.use_gpu and os.environ.get("QP_PIPELINE_DEBUG")) else None
+        origin = ev_t()
+        if self.use_gpu:
+            origin.record(torch.cuda.current_stream(dev))
+        start, trace = 0, []                                          # trace[g] = (h2d_done, vit_start, vit_end, prefill_start, prefill_end)
+        dbg = _GpuProgress(G) if (self.use_gpu and os.environ.get("QP_PIPELINE_DEBUG")) else None
         # query-based predict types: the prompt (everything after the last video token) is appended to every group and scores its
         # keys (qwen25_lvu.py:661-664, 684-689); positions are then the group's AND the next tail_len of the sequence
         q_m = plan.tail_len if (self.cfg.query_based and self.cfg.enable) else 0
         tail_emb = eng.embed_tokens(tail) if q_m else None
         nxt = vit_group(0)
+        last_frames = None
         for g, n in enumerate(plan.tokens):
-            feats, evs, read_done = nxt
+            feats, evs, read_done, last_frames = nxt
             if self.use_gpu:
                 main = torch.cuda.current_stream(dev)
                 main.wait_event(evs[1])
                 # feats was allocated on the ViT stream and is read on the main stream (cat / copy into the engine's buffer): tell
                 # the caching allocator, or ViT(g+2) could be handed the same block while prefill(g) is still queued
                 feats.record_stream(main)
-                vit_events.append(evs)
+                p0 = ev_t(); p0.record(main)
             emb = torch.cat([eng.embed_tokens(prefix), feats], 0) if g == 0 else feats
             assert emb.shape[0] == n, (emb.shape, n)
-            if g + 1 < len(plan.tokens):
+            if g + 1 < G:
                 nxt = vit_group(g + 1)                                # ViT of the next group runs ahead on its own stream
             eng.prefill_group(emb, pos[:, start:start + n + q_m], prompt_embeds=tail_emb)
+            if self.use_gpu:
+                p1 = ev_t(); p1.record(torch.cuda.current_stream(dev))
+                trace.append((evs[2], evs[0], evs[1], p0, p1))
             prod.release(g, read_done)
             start += n
             if dbg is not None:
-                dbg.enqueued(evs[1], torch.cuda.current_stream(dev).record_event())
+                dbg.enqueued(evs[1], p1)
         sync()
         if dbg is not None:
             dbg.stop()
         tm.prefill = time.perf_counter() - t_pre
-        tm.tokens, tm.groups = start, len(plan.tokens)
+        tm.tokens, tm.groups = start, G
         t_dec = time.perf_counter()
         logits = eng.prefill_tail(eng.embed_tokens(tail), pos[:, start:])     # pruning off for the tail (qwen25_lvu.py:737-742)
-        if not selector.trivial:                                               # HF processors see the whole prompt (video pads included)
-            selector.observe(list(P["prompt"].prefix_ids) + [self.model.spec.video_token_id] + list(P["prompt"].tail_ids),
-                             logits.shape[-1], dev)
+        if not selector.trivial:
+            # HF's processors see `input_ids` of the generate() call.  The reference calls it with the TAIL only — everything behind
+            # the last video token, `whole_inputs['input_ids'][:, past_len:]` over a pre-filled cache (qwen25_lvu.py:724-740) — so the
+            # repetition penalty touches tail + generated tokens, never the system prompt or the video pads.
+            selector.observe(list(P["prompt"].tail_ids), logits.shape[-1], dev)
         tok = selector.select(logits) if not selector.trivial else int(torch.argmax(logits).item())   # first token on the host = TTFT point
         tm.ttft = time.perf_counter() - t_e2e
         out = [tok]
@@ -312,12 +360,12 @@ class PrefillPipeline:
         if graph and getattr(eng, "_graph_decoder", None) is None:
             eng._graph_decoder = GraphDecoder(eng)
         if graph and selector.trivial:                                        # argmax stays on the device inside the graph
-            out += eng._graph_decoder.generate(tok, max_new_tokens - 1, P["delta"], eos_token_id)
+            out += eng._graph_decoder.generate(tok, max_new_tokens - 1, P["delta"], eos_set or None)
         else:                                                                 # logits come back per step: processors / sampling, or the
             if graph and max_new_tokens > 1:                                  # per-op path (CPU test doubles, parallel engines)
                 eng._graph_decoder.begin(P["delta"])
             for _ in range(max_new_tokens - 1):
-                if eos_token_id is not None and tok == eos_token_id:
+                if tok in eos_set:
                     break
                 if graph:
                     logits = eng._graph_decoder.step(tok)
@@ -328,7 +376,41 @@ class PrefillPipeline:
         sync()
         tm.decode = time.perf_counter() - t_dec
         tm.e2e = time.perf_counter() - t_e2e
-        if self.use_gpu:
-            tm.vit = sum(s.elapsed_time(e) for s, e in vit_events) * 1e-3
+        tm.producer_busy, tm.producer_blocked, tm.producer_copy = prod.t_busy, prod.t_blocked, prod.t_copy
+        if self.use_gpu and trace:
+            self._device_breakdown(tm, origin, trace)
+            if os.environ.get("QP_PIPELINE_VIT_REPLAY", "1") == "1" and last_frames is not None:
+                tm.vit_uncontended = self._vit_alone(last_frames) * G
         self.last_timings = tm
         return out
+
+    @staticmethod
+    def _device_breakdown(tm: Timings, origin, trace):
+        """Event timestamps (ms since `origin`) -> who the main stream waited for between two groups.  The stall in front of group g,
+        [end of prefill(g-1), start of prefill(g)], is split at the moment group g's frames finished uploading: before it the GPU
+        could not have started ViT(g) (frame wait, the producer's fault); after it the ViT simply was not finished (the tower's)."""
+        at = lambda e: origin.elapsed_time(e) * 1e-3
+        prev_end = 0.0
+        for h2d, v0, v1, p0, p1 in trace:
+            t_h2d, t_v0, t_v1, t_p0, t_p1 = at(h2d), at(v0), at(v1), at(p0), at(p1)
+            stall = max(0.0, t_p0 - prev_end)
+            frames_part = min(stall, max(0.0, t_h2d - prev_end))
+            tm.gpu_stall_frames += frames_part
+            tm.gpu_stall_vit += stall - frames_part
+            tm.gpu_prefill_busy += t_p1 - t_p0
+            tm.vit_span += t_v1 - t_v0
+            prev_end = t_p1
+
+    def _vit_alone(self, frames) -> float:
+        """Seconds for patchify + ViT of one frame group with the GPU otherwise idle (the run itself shares the CUs with the prefill)."""
+        torch.cuda.synchronize(self.model.device)
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(self.vit_stream):
+            for i in range(3):
+                if i == 1:
+                    s.record(self.vit_stream)
+                rows, grid = patchify_frames(frames, self.model.vision.spec, self.model.text.embed.dtype)
+                self.tower.forward(rows, grid)
+            e.record(self.vit_stream)
+        e.synchronize()
+        return s.elapsed_time(e) * 1e-3 / 2

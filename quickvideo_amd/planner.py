@@ -46,13 +46,30 @@ def plan_groups(n_frames: int, video_group_size: Optional[int], grid_h: int, gri
     return GroupPlan(tokens, grids, pixel_rows, frames, past, total_len - past)
 
 
+def temporal_ids(t: int, temporal_scale: float = 1.0, second_per_grid_t: Optional[float] = None,
+                 tokens_per_second: Optional[float] = None) -> np.ndarray:
+    """Temporal M-RoPE id of each of the t temporal patches.  Qwen2-VL: 0..t-1.  Qwen2.5-VL (get_rope_index [3P]):
+    `(arange(t) * second_per_grid_t * tokens_per_second).long()` where second_per_grid_t is a FLOAT32 tensor element
+    (`second_per_grid_ts` goes through torch.tensor) — so both products are rounded to fp32 before the truncation.  Evaluating
+    the same expression in float64 differs by one whenever a product lands on an integer in one precision and just below it in
+    the other (about 2 % of (video length, nframes) pairs; e.g. 24 fps, 28416 frames, 768 sampled)."""
+    if second_per_grid_t is not None:
+        spg, tps = np.float32(second_per_grid_t), np.float32(tokens_per_second)
+        return ((np.arange(t, dtype=np.int64).astype(np.float32) * spg) * tps).astype(np.int64)
+    if temporal_scale == 1.0:
+        return np.arange(t, dtype=np.int64)
+    return (np.arange(t, dtype=np.float64) * temporal_scale).astype(np.int64)
+
+
 def mrope_positions(prefix_len: int, grid_thw: Tuple[int, int, int], tail_len: int, merge: int = 2,
-                    temporal_scale: float = 1.0) -> Tuple[np.ndarray, int]:
+                    temporal_scale: float = 1.0, second_per_grid_t: Optional[float] = None,
+                    tokens_per_second: Optional[float] = None) -> Tuple[np.ndarray, int]:
     """int64 [3, T] ids for <prefix text><video><tail text> and rope_delta (transformers 4.50 get_rope_index rule:
-    text after the video resumes at max(position)+1)."""
+    text after the video resumes at max(position)+1).  Qwen2.5-VL: pass second_per_grid_t (= temporal_patch / sampled fps)
+    and tokens_per_second; the temporal stream is then computed with HF's float32 arithmetic (temporal_ids)."""
     t, h, w = grid_thw[0], grid_thw[1] // merge, grid_thw[2] // merge
     pre = np.tile(np.arange(prefix_len, dtype=np.int64), (3, 1))
-    ti = np.arange(t, dtype=np.int64) if temporal_scale == 1.0 else (np.arange(t, dtype=np.float64) * temporal_scale).astype(np.int64)
+    ti = temporal_ids(t, temporal_scale, second_per_grid_t, tokens_per_second)
     vid = np.stack([np.repeat(ti, h * w), np.tile(np.repeat(np.arange(h, dtype=np.int64), w), t),
                     np.tile(np.arange(w, dtype=np.int64), t * h)]) + prefix_len
     st = int(vid.max()) + 1 if vid.size else prefix_len

@@ -470,7 +470,7 @@ def test_duck_typed_reader_and_eos_default():
     assert len(out) == 1 and 1 <= out[0].count("<tok_") <= 3
     # EOS default: make the first generated token the end-of-turn token -> decoding stops after it
     first = int(out[0].split("<tok_")[1].split(">")[0])
-    obj.processor.im_end = first
+    obj.processor.eos_token_id = first            # (processor.tokenizer is the processor itself for the offline stand-in)
     out2 = obj.generate("What happens?", ThirdPartyReader(), max_new_tokens=3)
     assert out2[0].count("<tok_") == 1
     assert obj.generate("What happens?", ThirdPartyReader(), max_new_tokens=3, eos_token_id=None)[0].count("<tok_") == 3
@@ -515,8 +515,8 @@ def test_load_qwen25_vl_checkpoint_directory(tmp_path):
     assert int(t_ids[per_grid] - t_ids[0]) == 10
 
 
-@pytest.mark.parametrize("family", ["qwen2.5-vl", "qwen2-vl"])
-def test_qwen_vl_end_to_end_equals_hf_forward(tmp_path, family):
+@pytest.mark.parametrize("family,proc", [("qwen2.5-vl", "synthetic"), ("qwen2-vl", "synthetic"), ("qwen2-vl", "hf")])
+def test_qwen_vl_end_to_end_equals_hf_forward(tmp_path, family, proc):
     """The reference's model family end to end (lvu.py:60; and Qwen2-VL, BASELINE.json's model): a tiny checkpoint through LVU's pipeline — frames -> patchify
     -> windowed ViT + merger -> group-chunked prefill (2 groups, rho = 1: no pruning) -> prompt tail — against ONE forward of the
     installed transformers Qwen2_5_VLForConditionalGeneration over the whole prompt (it derives its own M-RoPE index from
@@ -564,7 +564,12 @@ def test_qwen_vl_end_to_end_equals_hf_forward(tmp_path, family):
     frames = torch.from_numpy(np.random.RandomState(5).randint(0, 256, (8, 3, 112, 168), dtype=np.uint8))
     video = str(tmp_path / "v.npy")
     np.save(video, frames.numpy())
-    pipe = PrefillPipeline(m, lvu.LVUConfig("x", top_p=1.0, video_group_size=4, num_frames=8), SyntheticProcessor(m.spec), ops=OracleOps())
+    if proc == "hf":            # the processor seam: the INSTALLED transformers Qwen2VLProcessor object (tiny tokenizer, Qwen2-VL chat template)
+        from tests.test_processor_seam import installed_qwen2vl_processor
+        processor = installed_qwen2vl_processor((4, 8, 12))
+    else:
+        processor = SyntheticProcessor(m.spec)
+    pipe = PrefillPipeline(m, lvu.LVUConfig("x", top_p=1.0, video_group_size=4, num_frames=8), processor, ops=OracleOps())
     cap, orig = {}, QuickPrefillEngine.prefill_tail
 
     def tail(self, e, p):
