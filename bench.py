@@ -564,10 +564,14 @@ def pipeline_leg(name, eng, device, modes=("overlapped", "sequential"), warm_vid
     if "overlapped" in res and "sequential" in res:
         cost = res["sequential"]["fetch_all_frames_before_gpu_ms"]
         hidden = res["sequential"]["ttft_ms"] - res["overlapped"]["ttft_ms"]
+        G = res["sequential"]["groups"]
+        hideable = min(cost, res["sequential"]["group_loop_ms"] * (G - 1) / G)     # the last group's GPU work always follows the last frame
         res["overlap"] = {"producer_cost_ms": cost, "ttft_sequential_ms": res["sequential"]["ttft_ms"], "ttft_overlapped_ms": res["overlapped"]["ttft_ms"],
                           "hidden_ms": round(hidden, 2), "hidden_frac_of_producer_cost": round(hidden / cost, 3) if cost > 0 else None,
+                          "hideable_ms": round(hideable, 2), "hidden_frac_of_hideable": round(hidden / hideable, 3) if hideable > 0 else None,
                           "definition": "producer_cost = wall time of fetching every frame group before the GPU starts (sequential plugin); "
-                                        "hidden = ttft(sequential) - ttft(overlapped)"}
+                                        "hidden = ttft(sequential) - ttft(overlapped); hideable = min(producer_cost, GPU time of all groups but "
+                                        "the last): a producer-bound video (GPU time < producer cost, e.g. cfg2) cannot hide more than its GPU time"}
     res["frame_source"] = (f"synthetic, costed: each of the {frames} sampled frames is produced at 1080x1920 and LANCZOS-resized (PIL) to {fh}x{fw} on "
                            f"{threads} threads (QUICKCODEC_CORES), padded to {REFERENCE_DECODE_S_PER_HOUR} s per hour of video at that thread count "
                            f"(the reference's QuickCodec figure; no codec in the image); video length {secs:.0f} s")

@@ -331,13 +331,16 @@ class PrefillPipeline:
                 p0 = ev_t(); p0.record(main)
             emb = torch.cat([eng.embed_tokens(prefix), feats], 0) if g == 0 else feats
             assert emb.shape[0] == n, (emb.shape, n)
-            if g + 1 < G:
-                nxt = vit_group(g + 1)                                # ViT of the next group runs ahead on its own stream
+            # prefill(g) is enqueued BEFORE the host asks for group g+1's frames: with a producer-bound source (short videos)
+            # prod.get() blocks until they exist, and the GPU must not sit idle behind that wait (round 2 had the two the other
+            # way round: cfg2's overlapped TTFT carried ~70 ms of it).  ViT(g+1) still runs ahead on its own stream.
             eng.prefill_group(emb, pos[:, start:start + n + q_m], prompt_embeds=tail_emb)
             if self.use_gpu:
                 p1 = ev_t(); p1.record(torch.cuda.current_stream(dev))
                 trace.append((evs[2], evs[0], evs[1], p0, p1))
             prod.release(g, read_done)
+            if g + 1 < G:
+                nxt = vit_group(g + 1)                                # ViT of the next group: own stream, overlaps prefill(g) on the GPU
             start += n
             if dbg is not None:
                 dbg.enqueued(evs[1], p1)
