@@ -140,15 +140,14 @@ int qp_gather_kv(qp_ctx* ctx, const void* k_src, const void* v_src, int64_t src_
                  int64_t k, int n_kv_heads, int head_dim, void* k_dst, void* v_dst, int64_t dst_head_stride,
                  int64_t dst_row0, void* stream);
 
-/* qp_select_k_smallest + qp_gather_kv in ONE launch (the engine's prune step): every workgroup repeats the LDS-resident
- * select on head_sumsq and moves its slice of the kept rows src -> dst; kept_idx_out / norm_bits_out as above. */
+/* qp_select_k_smallest + qp_gather_kv behind one call (two launches), for groups beyond qp_prune_keys' 8192 tokens (the
+ * single-group baseline mode of long videos); kept_idx_out / norm_bits_out as above. */
 int qp_prune_staged(qp_ctx* ctx, const float* head_sumsq, int n_heads_total, int64_t n, int64_t k, const void* k_src,
                     const void* v_src, int64_t src_head_stride, int n_kv_heads, int head_dim, void* k_dst, void* v_dst,
                     int64_t dst_head_stride, int64_t dst_row0, int32_t* kept_idx_out, uint16_t* norm_bits_out, int prune_mode,
                     void* stream);
 
-/* The engine's prune step since round 2 (one launch; replaces qp_prune_staged, which recomputed every norm with an fp64
- * square root in each of up to 256 workgroups and needed up to 150 KB of LDS):
+/* The engine's prune step since round 2 (one launch):
  *   qp_norm_keys   head_sumsq fp32 [n_heads_total][n] -> norm_keys uint16 [n].  Only needed when qp_rope_append_keys could not
  *                  produce them (tensor-/group-token-parallel gathered sums, value-row norms, 8 KV heads in one process).
  *   qp_prune_keys  one workgroup per 16 tokens: all n keys in registers, threshold key by a two-pass radix select in LDS, kept

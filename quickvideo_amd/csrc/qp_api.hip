@@ -277,10 +277,9 @@ int qp_prune_staged(qp_ctx* ctx, const float* head_sumsq, int n_heads_total, int
              QP_ERR_INVALID, "qp_prune_staged: bad strides");
   QP_REQUIRE(aligned16(k_src) && aligned16(v_src) && aligned16(k_dst) && aligned16(v_dst), QP_ERR_INVALID, "qp_prune_staged: alignment");
   hipStream_t s = (hipStream_t)stream;
-  int rc = qp_launch_prune_fused(head_sumsq, n_heads_total, n, k, k_src, v_src, src_head_stride, n_kv_heads, k_dst, v_dst,
-                                 dst_head_stride, dst_row0, kept_idx_out, norm_bits_out, ctx->cus, largest, s);
-  if (rc != 1) return rc;
-  rc = qp_launch_select(head_sumsq, n_heads_total, n, k, kept_idx_out, norm_bits_out, nullptr, largest, s);       // large n: two launches
+  // two launches (round 1's fused form — every one of up to 256 workgroups repeating the whole select in 150 KB of LDS — is gone: the
+  // engine prunes through qp_prune_keys, and this entry point only serves groups of n > 8192 tokens, where a launch boundary is noise)
+  int rc = qp_launch_select(head_sumsq, n_heads_total, n, k, kept_idx_out, norm_bits_out, nullptr, largest, s);
   if (rc) return rc;
   return qp_launch_gather_kv(k_src, v_src, src_head_stride, kept_idx_out, k, n_kv_heads, k_dst, v_dst, dst_head_stride, dst_row0, s);
 }

@@ -98,9 +98,6 @@ int qp_launch_vit_rope(void* qkv, const float* cos_t, const float* sin_t, int64_
 int qp_launch_quick_gelu(const void* x, void* out, int64_t n_elems, hipStream_t s);
 int qp_launch_add_layernorm(void* x, const void* delta, const void* w, const void* b, void* out, int64_t n, int hidden, float eps,
                             hipStream_t s);
-int qp_launch_prune_fused(const float* head_sumsq, int n_heads, int64_t n, int64_t k, const void* k_src, const void* v_src,
-                          int64_t src_head_stride, int hkv, void* k_dst, void* v_dst, int64_t dst_head_stride, int64_t dst_row0,
-                          int32_t* kept, uint16_t* norm_bits, int cus, int largest, hipStream_t s);
 int qp_launch_gemv(const qp_ctx* ctx, const void* w, const void* x, const void* norm_w, float eps, const void* bias, void* out,
                    int64_t n_out, int64_t k, int mode, hipStream_t s);
 int qp_launch_decode_rope(const void* qkv, const int64_t* state, const void* cos_t, const void* sin_t, float theta, int hq, int hkv,

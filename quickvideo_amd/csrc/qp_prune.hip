@@ -168,78 +168,6 @@ __global__ __launch_bounds__(1024) void select_kernel(const float* __restrict__ 
 
 
 // ------------------------------------------------------------------------------------------------
-// K5+K6 fused: select + gather in ONE launch.  Every workgroup repeats the (LDS-resident, ~10 us) select on the
-// [Hkv][n] fp32 sums — they sit in L2 — and then moves its own slice of the kept K/V rows staging -> arena; workgroup 0
-// also emits the index list.  Saves a kernel boundary and keeps all CUs busy during the copy.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void prune_fused_kernel(const float* __restrict__ head_sumsq, int n_heads, int n, int k,
-                                                           const uint4* __restrict__ k_src, const uint4* __restrict__ v_src,
-                                                           int64_t src_hs16, int hkv, uint4* __restrict__ k_dst,
-                                                           uint4* __restrict__ v_dst, int64_t dst_hs16, int64_t dst_row0,
-                                                           int32_t* __restrict__ kept, uint16_t* __restrict__ norm_bits_out, int largest) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned* hist = (unsigned*)smem;            // 16 per-wave histograms x 257 (odd stride: waves hit different banks)
-  unsigned* scan = hist + 16 * 257;            // 256
-  unsigned* wave_tot = scan + 256;             // 16
-  unsigned* res = wave_tot + 16;               // 4
-  unsigned* tot = res + 4;                     // 4
-  uint16_t* keys = (uint16_t*)(tot + 4);       // n (padded to 8)
-  uint16_t* kidx = keys + ((n + 7) & ~7);      // k
-  const int tid = threadIdx.x, wave = tid >> 6;
-  unsigned* myh = hist + wave * 257;
-
-  for (int t = tid; t < n; t += 1024) {
-    float s = head_sumsq[t];
-    for (int h = 1; h < n_heads; ++h) s = s + head_sumsq[(int64_t)h * n + t];
-    uint16_t b = f32_to_bf16_bits(sqrt_rn_f32(s));
-    keys[t] = largest ? (uint16_t)~b : b;
-    if (blockIdx.x == 0 && norm_bits_out) norm_bits_out[t] = b;
-  }
-  for (int i = tid; i < 16 * 257; i += 1024) hist[i] = 0;
-  __syncthreads();
-  for (int t = tid; t < n; t += 1024) atomicAdd(&myh[keys[t] >> 8], 1u);
-  __syncthreads();
-  find_bucket_256(hist, 16, 257, (unsigned)k, res);
-  const unsigned b1 = res[0], c1 = res[1];
-  __syncthreads();
-  for (int i = tid; i < 16 * 257; i += 1024) hist[i] = 0;
-  __syncthreads();
-  for (int t = tid; t < n; t += 1024) { unsigned key = keys[t]; if ((key >> 8) == b1) atomicAdd(&myh[key & 255u], 1u); }
-  __syncthreads();
-  find_bucket_256(hist, 16, 257, (unsigned)k - c1, res);
-  const unsigned tau = (b1 << 8) | res[0];
-  const unsigned r_ties = (unsigned)k - (c1 + res[1]);
-  __syncthreads();
-
-  const int chunk = (n + 1023) / 1024;
-  const int t0 = tid * chunk, t1 = min(n, t0 + chunk);
-  unsigned lt = 0, eq = 0;
-  for (int t = t0; t < t1; ++t) { unsigned key = keys[t]; lt += key < tau; eq += key == tau; }
-  const unsigned eq_before = block_excl_scan_1024(eq, wave_tot, tot);
-  unsigned take = 0;
-  if (eq_before < r_ties) take = min(eq, r_ties - eq_before);
-  unsigned pos = block_excl_scan_1024(lt + take, wave_tot, tot), taken = 0;
-  for (int t = t0; t < t1; ++t) {
-    unsigned key = keys[t];
-    bool keep = key < tau;
-    if (key == tau && taken < take) { keep = true; ++taken; }
-    if (keep) { kidx[pos] = (uint16_t)t; if (blockIdx.x == 0) kept[pos] = t; ++pos; }
-  }
-  __syncthreads();
-  // gather this workgroup's slice of the 2*hkv*k kept rows (16 lanes x 16 B per 256-B row)
-  const int c = tid & 15;
-  const int64_t rows = 2ll * hkv * k;
-  const int64_t r_lo = rows * blockIdx.x / gridDim.x, r_hi = rows * (blockIdx.x + 1) / gridDim.x;
-  for (int64_t r = r_lo + (tid >> 4); r < r_hi; r += 64) {
-    const int64_t j = r % k, hh = (r / k) % hkv;
-    const bool isv = r >= (int64_t)hkv * k;
-    const uint4 val = (isv ? v_src : k_src)[hh * src_hs16 + (int64_t)kidx[j] * 16 + c];
-    (isv ? v_dst : k_dst)[hh * dst_hs16 + (dst_row0 + j) * 16 + c] = val;
-  }
-}
-
-
-// ------------------------------------------------------------------------------------------------
 // K5+K6, the engine's path since round 2: ONE launch, no 150 KB of LDS, no fp64 square roots per workgroup.
 //   * The 16-bit norm key of every token (bf16 pattern of the cross-head norm; complemented for "k largest") is produced once,
 //     by the RoPE/append kernel that already holds the key rows (qp_rope.hip) — or by norm_keys_kernel below when the per-head
@@ -554,25 +482,6 @@ int qp_launch_prune_tail_inplace(const uint16_t* norm_keys, int64_t n, int64_t k
   prune_tail_inplace_kernel<256><<<(unsigned)((n + 15) / 16), 256, 0, s>>>(norm_keys, (int)n, (int)k, (uint4*)k_cache, (uint4*)v_cache,
                                                                          head_stride / 8, past_len, hkv, kept, sync_words, dbg);
   return qp_check_launch("prune_tail_inplace");
-}
-
-static size_t prune_fused_smem(int64_t n, int64_t k) { return (16 * 257 + 256 + 16 + 4 + 4) * 4 + (size_t)((n + 7) & ~7) * 2 + (size_t)k * 2 + 16; }
-
-int qp_launch_prune_fused(const float* head_sumsq, int n_heads, int64_t n, int64_t k, const void* k_src, const void* v_src,
-                          int64_t src_head_stride, int hkv, void* k_dst, void* v_dst, int64_t dst_head_stride, int64_t dst_row0,
-                          int32_t* kept, uint16_t* norm_bits, int cus, int largest, hipStream_t s) {
-  const size_t smem = prune_fused_smem(n, k);
-  if (smem > 150 * 1024) return 1;             // caller falls back to select + gather
-  static std::atomic<unsigned long long> lds_ok{0};
-  if (int rc = qp_opt_in_lds(lds_ok, (const void*)prune_fused_kernel, 160 * 1024 - 64, "prune_fused")) return rc;
-  int64_t rows = 2 * (int64_t)hkv * k;
-  int grid = (int)((rows + 255) / 256);          // >= 256 rows (64 KB) per workgroup
-  if (grid > cus) grid = cus;
-  if (grid < 1) grid = 1;
-  prune_fused_kernel<<<grid, 1024, smem, s>>>(head_sumsq, n_heads, (int)n, (int)k, (const uint4*)k_src, (const uint4*)v_src,
-                                             src_head_stride / 8, hkv, (uint4*)k_dst, (uint4*)v_dst, dst_head_stride / 8, dst_row0,
-                                             kept, norm_bits, largest);
-  return qp_check_launch("prune_fused");
 }
 
 static size_t select_smem_bytes(int64_t n) { return (256 + 256 + 16 + 4 + 4) * 4 + (size_t)((n + 7) / 8 * 8) * 2; }

@@ -133,7 +133,7 @@ def test_prune_tail_inplace_and_staged(ops, golden_dir, ci):
     torch.cuda.synchronize()
     assert sha(dev_bits(kc2[:, :past + k])) == meta["k_sha"] and sha(dev_bits(vc2[:, :past + k])) == meta["v_sha"]
     assert torch.count_nonzero(kc2[:, past + k:]).item() == 0      # nothing written past the kept rows
-    # (c) the engine's fused single-launch form
+    # (c) qp_prune_staged: select + gather behind one call (groups beyond qp_prune_keys' 8192 tokens)
     kc3 = torch.zeros(hkv, cap, D, dtype=torch.bfloat16, device="cuda"); vc3 = torch.zeros_like(kc3)
     idx3 = torch.empty(k, dtype=torch.int32, device="cuda"); nb3 = torch.zeros(n, dtype=torch.int16, device="cuda")
     ops.prune_staged(ss, hkv, n, k, ks, vs, n * D, hkv, D, kc3, vc3, cap * D, past, idx3, nb3)
@@ -701,10 +701,54 @@ def test_prefill_attn_query_subranges(ops, n, P, hq, hkv, parts):
         ops.prefill_attn(q[:10].contiguous(), k, v, (P + n) * D, P, k[:, P:], v[:, P:], (P + n) * D, n, hq, hkv, D, 1.0, full, q_row0=n - 5, nq=10)
 
 
-@pytest.mark.parametrize("variant", ["4", "7", "8", "2", "3", "9", "10"])
+def test_attention_experiments_are_not_in_the_product_library(ops, monkeypatch):
+    """QP_ATTN_VARIANT 9 (staggered s6) and 10 (s7) measured slower and are compiled only by `make EXPERIMENTS=1`: the
+    product library refuses them loudly instead of carrying dead kernels."""
+    from quickvideo_amd.native import QuickPrefillError
+    q = torch.zeros(64, 2, D, dtype=torch.bfloat16, device="cuda"); k = torch.zeros(1, 64, D, dtype=torch.bfloat16, device="cuda")
+    for variant in ("9", "10"):
+        monkeypatch.setenv("QP_ATTN_VARIANT", variant)
+        with pytest.raises(QuickPrefillError, match="EXPERIMENTS=1"):
+            ops.prefill_attn(q, None, None, 64 * D, 0, k, k, 64 * D, 64, 2, 1, D, 1.0, torch.empty_like(q))
+
+
+@pytest.mark.parametrize("split", [None, "2"])
+def test_prefill_attn_early_out_is_bit_identical(ops, monkeypatch, split):
+    """The per-wave early-out of the production kernel (waves stop computing after their last visible key tile and only keep the tile
+    DMA + step barrier going; QP_S6_EARLY_OUT, default 3) must not change a single bit against the full walk (=0): ragged last
+    blocks in both workgroup forms, query sub-ranges (q_row0 > 0: group-token parallel ranks, the query-score mode's second launch),
+    and with every item forced into two KV ranges (QP_ATTN_FORCE_SPLIT: the partial path, where a range may end before the diagonal)."""
+    if split:
+        monkeypatch.setenv("QP_ATTN_FORCE_SPLIT", split)
+    off = 0 if split is None else 1                      # shapes no other test plans: the forced split is part of the cached plan
+    cases = [(2240 + off, 5003, 28, 4, 0, None, "8"), (2240 + off, 5003, 28, 4, 0, None, "7"), (301 + off, 0, 4, 2, 0, None, None),
+             (1111 + off, 777, 8, 1, 0, None, None), (1500 + off, 2051, 8, 2, 640, 500, None), (903 + off, 4097, 4, 4, 129, 774, "8"),
+             (700 + off, 0, 6, 2, 650, 50, None)]
+    for (n, P, hq, hkv, q0, nq, variant) in cases:
+        if variant:
+            monkeypatch.setenv("QP_ATTN_VARIANT", variant)
+        else:
+            monkeypatch.delenv("QP_ATTN_VARIANT", raising=False)
+        g = torch.Generator(device="cuda"); g.manual_seed(n * 3 + P)
+        nq_ = n if nq is None else nq
+        q = torch.randn(nq_, hq, D, generator=g, device="cuda").to(torch.bfloat16)
+        k = torch.randn(hkv, P + n, D, generator=g, device="cuda").to(torch.bfloat16)
+        v = torch.randn(hkv, P + n, D, generator=g, device="cuda").to(torch.bfloat16)
+        outs = []
+        for eo in ("0", "3"):
+            monkeypatch.setenv("QP_S6_EARLY_OUT", eo)
+            o = torch.full((nq_, hq, D), 7.0, dtype=torch.bfloat16, device="cuda")
+            ops.prefill_attn(q, k, v, (P + n) * D, P, k[:, P:], v[:, P:], (P + n) * D, n, hq, hkv, D, D ** -0.5, o, q_row0=q0, nq=nq_)
+            torch.cuda.synchronize()
+            outs.append(o)
+        assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16)), (n, P, hq, hkv, q0, nq, variant, split)
+        assert torch.isfinite(outs[0].float()).all()
+
+
+@pytest.mark.parametrize("variant", ["4", "7", "8", "2", "3"])
 def test_prefill_attn_every_kernel_form(ops, variant, monkeypatch):
     """The launch picks a kernel form per shape (s6 with 4- or 8-wave workgroups, planner-chosen kv-split); force each form
-    (QP_ATTN_VARIANT: 4 = s4, 7 / 8 = s6 4- / 8-wave, 2 = no kv split, 3 = plain 2-D grid, 9 = staggered 8-wave experiment, 10 = s7: one wave per SIMD with asm-owned AGPR accumulators) over ragged sizes, prefix lengths around the tile size,
+    (QP_ATTN_VARIANT: 4 = s4, 7 / 8 = s6 4- / 8-wave, 2 = no kv split, 3 = plain 2-D grid) over ragged sizes, prefix lengths around the tile size,
     single-tile and sub-range launches, and the rescale branch."""
     monkeypatch.setenv("QP_ATTN_VARIANT", variant)
     for (n, P, hq, hkv, staged) in [(1, 0, 2, 1, True), (31, 1, 2, 1, False), (64, 63, 4, 2, True), (65, 64, 2, 1, False),

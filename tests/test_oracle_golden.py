@@ -306,3 +306,46 @@ def test_query_scores_match_reference(golden_dir):
         assert np.array_equal(O.torch_bf16_to_bits(sc), data[f"c{ci}_score_bits"])
         assert np.array_equal(O.select_k_largest(O.query_score_keys(sc), k), data[f"c{ci}_query_attention_weights"])
         assert np.array_equal(O.select_k_largest(O.query_score_keys(sc, vv[0, :, :n]), k), data[f"c{ci}_query_attention_weights_by_value_norm"])
+
+
+def test_full_depth_calibration_record_is_consistent(golden_dir):
+    """tests/golden/gv8_deep_oracle_calibration.json (oracle/calibrate_deep.py: the CPU oracle's FULL 28-layer run against GV8, 13 min of
+    CPU, not repeated here) is what tests/test_gpu_deep.py derives its bars from.  It must belong to the committed fixture (same argmax,
+    cache lengths equal, one overlap figure per layer, layer 0 exact) and say what DESIGN.md quotes."""
+    import json
+    meta = json.load(open(os.path.join(golden_dir, "gv8_deep.json")))
+    cal = json.load(open(os.path.join(golden_dir, "gv8_deep_oracle_calibration.json")))
+    assert cal["cache_len_equal"] and cal["argmax"] == cal["reference_argmax"] == meta["argmax"]
+    ov = cal["overlap_min_over_groups_by_layer"]
+    assert len(ov) == meta["spec"]["n_layers"] and len(cal["overlap_by_group_layer"]) == len(meta["group_tokens"])
+    assert ov[0] == 1.0 and min(ov) >= 0.96
+    assert abs(cal["logits_max_abs_diff"] - 0.2129) < 1e-3 and abs(cal["logits_cosine"] - 0.99894) < 1e-5
+    assert abs(cal["logit_absmax"] - meta["logit_absmax"]) < 1e-6
+
+
+def test_costed_frame_source_is_deterministic_and_threaded():
+    """synthetic://...&decode_h=&decode_w= (frames.py): a frame source that costs what a decoder costs — every frame produced at the
+    decode size and LANCZOS-resized on the reader's worker threads.  Same pixels whatever the thread count or access order; the
+    calibrated per-frame pad (decode_s) stretches a group to at least its share of the budget."""
+    import time
+    from quickvideo_amd.frames import open_video
+    url = "synthetic://?frames=64&h=112&w=168&fps=2&seed=3&decode_h=270&decode_w=480"
+    got = []
+    for nt in (1, 4):
+        r = open_video(url, num_threads=nt)
+        r.height, r.width, r.frame_iter = 112, 168, 8
+        r.process(np.arange(0, 32, 2))
+        got.append(torch.cat([next(r), next(r)]))
+        assert got[-1].shape == (16, 3, 112, 168) and got[-1].dtype == torch.uint8
+        with pytest.raises(StopIteration):
+            next(r)
+    assert torch.equal(got[0], got[1])
+    r = open_video(url, num_threads=2)
+    r.height, r.width, r.frame_iter = 112, 168, 4
+    r.process(np.array([30, 2]))                         # other order, other grouping: frame 2 is still frame 2
+    assert torch.equal(next(r)[1], got[0][1])
+    r = open_video(url + "&decode_s=0.4", num_threads=4)
+    r.height, r.width, r.frame_iter = 112, 168, 8
+    r.process(np.arange(16))                             # budget: 0.4 s for 16 frames on 4 threads = 0.1 s per frame per thread, 0.2 s per group of 8
+    t0 = time.perf_counter(); next(r); dt = time.perf_counter() - t0
+    assert 0.18 <= dt < 1.0, dt
