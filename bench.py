@@ -71,6 +71,19 @@ def progress(msg):
         print(f"[bench {time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
 
 
+_JSON_FD = None
+
+
+def emit_line(text):
+    """The JSON line -> the process's ORIGINAL stdout (see main(): fd 1 itself is redirected to stderr)."""
+    data = (text + "\n").encode()
+    if _JSON_FD is None:
+        sys.stdout.write(text + "\n"); sys.stdout.flush()
+        return
+    while data:
+        data = data[os.write(_JSON_FD, data):]
+
+
 def describe(name):
     c = CONFIGS[name]
     return f"{name}: {c[0]}, {c[1]} frames {c[2]}x{c[3]}, group_size {c[4]}, key-norm rho={c[5]}"
@@ -875,6 +888,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
+    # stdout carries exactly ONE line (the driver's contract).  Native libraries print there too — RCCL writes a five-line version
+    # banner to C stdout when its first communicator is created (seen under --nccl-preflight) — so file descriptor 1 is pointed at
+    # stderr for the whole run and the JSON line is written to the saved original.
+    global _JSON_FD
+    sys.stdout.flush()
+    _JSON_FD = os.dup(1)
+    os.dup2(2, 1)
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # QP_BENCH_SINGLE_DEVICE=1: developer hook to exercise the multi-process path on a 1-GPU box (all ranks on cuda:0, gloo
@@ -930,7 +950,7 @@ def main():
     progress(f"timed pass done: {res['value']} tok/s, {res['full_prefill_ms']} ms per pass")
     if args.window:
         if rank == 0:
-            print(json.dumps({"config": describe(name), **res}))
+            emit_line(json.dumps({"config": describe(name), **res}))
         if world > 1:
             torch.distributed.destroy_process_group()
         return
@@ -985,7 +1005,7 @@ def main():
                 out[k] = v
         if note:
             out["note"] = note
-        print(json.dumps(out), flush=True)
+        emit_line(json.dumps(out))
 
     if world == 1:
         # The auxiliary legs (decode, video -> first token, cfg2 block, CPU baseline) come after the timed region.  Should one of them

@@ -16,8 +16,8 @@ def run_bench(args, env_extra=None, timeout=600):
     env.update(env_extra or {})
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
-    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1, p.stdout[-2000:]                       # ONE JSON line
+    lines = p.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), p.stdout[-2000:]      # stdout = ONE line, the JSON (native libraries' prints go to stderr)
     return json.loads(lines[0])
 
 
@@ -48,3 +48,14 @@ def test_bench_prints_its_line_when_an_auxiliary_leg_overruns():
     """The decode / video->first-token / cfg2 / CPU-baseline legs run after the timed region; a stuck one must not cost the line."""
     d = run_bench(["--config", "tiny", "--steps", "2", "--warmup", "1"], {"QP_BENCH_AUX_BUDGET_S": "0.001"})
     assert d["value"] > 0 and d["roofline"] is not None and "cut off" in d["note"]
+
+
+def test_bench_nccl_preflight_runs_the_pass_through_rccl_with_the_same_result():
+    """`--nccl-preflight`: the N = 1 pass through an initialised 1-rank RCCL group in the tensor-parallel layout (2 all-reduces + 1 all-gather
+    per layer).  Same first token, a value within a few per cent of the plain run, and stdout still exactly one line although RCCL prints its
+    version banner to C stdout."""
+    one = run_bench(["--config", "cfg4s", "--steps", "5", "--warmup", "1", "--lean"])
+    pre = run_bench(["--config", "cfg4s", "--steps", "5", "--warmup", "1", "--lean", "--nccl-preflight"])
+    assert pre["nccl_preflight"]["backend"] == "nccl" and pre["nccl_preflight"]["world_size"] == 1
+    assert pre["first_token"] == one["first_token"] and pre["first_token_check"]["match"]
+    assert 0.90 <= pre["value"] / one["value"] <= 1.05, (pre["value"], one["value"])
