@@ -155,7 +155,7 @@ def test_engine_72b_tp8_rank_slice_vs_oracle():
     spec, spec_o = TextSpec(**dims), O.TextSpec(**dims)
     # std 0.01: at d = 8192 the usual 0.02 gives q.k/sqrt(D) a std of ~3.3, i.e. attention so peaky that ONE token moving across the
     # prune threshold (2 of 240 kept tokens differ between hipBLASLt's and the CPU's K rounding) moves the logits by 0.6
-    # (tests/dbg_engine_slice.py); with 0.01 the same two differences move them by 0.02
+    # (tools/probe/dbg_engine_slice.py); with 0.01 the same two differences move them by 0.02
     w = O.hashed_text_weights(spec_o, seed=21, device="cuda", norm_jitter=0.05, std=0.01)
     frames, gh, gw, gs, prefix, tail = 16, 16, 30, 8, 15, 24       # 8 frame pairs x 120 tokens -> 2 groups of 480
     T = prefix + (frames // 2) * (gh // 2) * (gw // 2) + tail
