@@ -247,6 +247,13 @@ int qp_select_k_smallest(qp_ctx* ctx, const float* head_sumsq, int n_heads_total
                           (hipStream_t)stream);
 }
 
+int qp_select_keys(qp_ctx* ctx, const uint16_t* norm_keys, int64_t n, int64_t k, int32_t* kept_idx_out, void* stream) {
+  QP_REQUIRE(ctx && norm_keys && kept_idx_out, QP_ERR_INVALID, "qp_select_keys: NULL argument");
+  QP_REQUIRE(k > 0 && k <= n, QP_ERR_INVALID, "qp_select_keys: need 0 < k <= n, got k=%lld n=%lld", (long long)k, (long long)n);
+  QP_REQUIRE(n < (1ll << 31), QP_ERR_UNSUPPORTED, "qp_select_keys: n=%lld too large", (long long)n);
+  return qp_launch_select(nullptr, 0, n, k, kept_idx_out, nullptr, nullptr, 0, (hipStream_t)stream, norm_keys);
+}
+
 int qp_gather_kv(qp_ctx* ctx, const void* k_src, const void* v_src, int64_t src_head_stride, const int32_t* idx, int64_t k,
                  int n_kv_heads, int head_dim, void* k_dst, void* v_dst, int64_t dst_head_stride, int64_t dst_row0,
                  void* stream) {

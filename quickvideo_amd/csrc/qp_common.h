@@ -75,7 +75,7 @@ int qp_launch_prune_keys(const uint16_t* norm_keys, int64_t n, int64_t k, const 
 int qp_launch_key_sumsq(const void* k, int64_t head_stride, int64_t row0, int64_t n, int hkv, float* head_sumsq,
                         hipStream_t s);
 int qp_launch_select(const float* head_sumsq, int n_heads, int64_t n, int64_t k, int32_t* kept, uint16_t* norm_bits,
-                     void* ws, int largest, hipStream_t s);
+                     void* ws, int largest, hipStream_t s, const uint16_t* keys_in = nullptr);
 int qp_launch_gather_kv(const void* k_src, const void* v_src, int64_t src_head_stride, const int32_t* idx, int64_t k,
                         int hkv, void* k_dst, void* v_dst, int64_t dst_head_stride, int64_t dst_row0, hipStream_t s);
 int qp_launch_gather_rows(const void* src, const int32_t* idx, int64_t k, int64_t row_bytes, void* dst, hipStream_t s);

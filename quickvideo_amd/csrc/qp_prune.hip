@@ -115,7 +115,7 @@ __device__ __forceinline__ void find_bucket_256(const unsigned* hist, int nh, in
 template <bool kLds>
 __global__ __launch_bounds__(1024) void select_kernel(const float* __restrict__ head_sumsq, int n_heads, int n, int k,
                                                       int32_t* __restrict__ kept, uint16_t* __restrict__ norm_bits_out,
-                                                      uint16_t* __restrict__ keys_glb, int largest) {
+                                                      uint16_t* __restrict__ keys_glb, int largest, const uint16_t* __restrict__ keys_in) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned* hist = (unsigned*)smem;            // 256
   unsigned* scan = hist + 256;                 // 256
@@ -125,12 +125,17 @@ __global__ __launch_bounds__(1024) void select_kernel(const float* __restrict__ 
   uint16_t* keys = kLds ? (uint16_t*)(tot + 4) : keys_glb;       // n
   const int tid = threadIdx.x;
 
-  for (int t = tid; t < n; t += 1024) {
-    float s = head_sumsq[t];
-    for (int h = 1; h < n_heads; ++h) s = s + head_sumsq[(int64_t)h * n + t];
-    uint16_t b = f32_to_bf16_bits(sqrt_rn_f32(s));
-    keys[t] = largest ? (uint16_t)~b : b;          // k largest == k smallest of the complemented pattern (ties: lowest index)
-    if (norm_bits_out) norm_bits_out[t] = b;
+  if (keys_in) {                                   // ready-made 16-bit sort keys (qp_select_keys: norm keys, complemented query scores)
+    if (kLds) for (int t = tid; t < n; t += 1024) keys[t] = keys_in[t];
+    else keys = const_cast<uint16_t*>(keys_in);    // large n: stream them from where they are
+  } else {
+    for (int t = tid; t < n; t += 1024) {
+      float s = head_sumsq[t];
+      for (int h = 1; h < n_heads; ++h) s = s + head_sumsq[(int64_t)h * n + t];
+      uint16_t b = f32_to_bf16_bits(sqrt_rn_f32(s));
+      keys[t] = largest ? (uint16_t)~b : b;        // k largest == k smallest of the complemented pattern (ties: lowest index)
+      if (norm_bits_out) norm_bits_out[t] = b;
+    }
   }
   if (tid < 256) hist[tid] = 0;
   __syncthreads();
@@ -487,16 +492,17 @@ int qp_launch_prune_tail_inplace(const uint16_t* norm_keys, int64_t n, int64_t k
 static size_t select_smem_bytes(int64_t n) { return (256 + 256 + 16 + 4 + 4) * 4 + (size_t)((n + 7) / 8 * 8) * 2; }
 
 int qp_launch_select(const float* head_sumsq, int n_heads, int64_t n, int64_t k, int32_t* kept, uint16_t* norm_bits,
-                     void* ws, int largest, hipStream_t s) {
+                     void* ws, int largest, hipStream_t s, const uint16_t* keys_in) {
   if (n > 65536) {
-    if (ws == nullptr) return qp_fail(QP_ERR_WORKSPACE, "select: n=%lld > 65536 needs a workspace of qp_select_workspace_bytes(n)", (long long)n);
-    select_kernel<false><<<1, 1024, select_smem_bytes(0), s>>>(head_sumsq, n_heads, (int)n, (int)k, kept, norm_bits, (uint16_t*)ws, largest);
+    if (ws == nullptr && keys_in == nullptr)
+      return qp_fail(QP_ERR_WORKSPACE, "select: n=%lld > 65536 needs a workspace of qp_select_workspace_bytes(n)", (long long)n);
+    select_kernel<false><<<1, 1024, select_smem_bytes(0), s>>>(head_sumsq, n_heads, (int)n, (int)k, kept, norm_bits, (uint16_t*)ws, largest, keys_in);
     return qp_check_launch("select(global keys)");
   }
   size_t smem = select_smem_bytes(n);
   static std::atomic<unsigned long long> lds_ok{0};
   if (int rc = qp_opt_in_lds(lds_ok, (const void*)select_kernel<true>, 160 * 1024 - 64, "select")) return rc;
-  select_kernel<true><<<1, 1024, smem, s>>>(head_sumsq, n_heads, (int)n, (int)k, kept, norm_bits, nullptr, largest);
+  select_kernel<true><<<1, 1024, smem, s>>>(head_sumsq, n_heads, (int)n, (int)k, kept, norm_bits, nullptr, largest, keys_in);
   return qp_check_launch("select");
 }
 

@@ -454,8 +454,8 @@ class QuickPrefillEngine:
             raise NotImplementedError("query-attention-score pruning runs on one GPU (no tensor / group-token / layer-pipeline parallel form)")
         if cfg.enable and isinstance(cfg.prefill_prune_starting_layer, int) and cfg.prefill_prune_starting_layer >= 0:
             raise NotImplementedError("query-attention-score pruning + hidden-state pruning: the reference drops the prompt rows there")
-        if n > getattr(ops, "PRUNE_KEYS_MAX_N", 8192):
-            raise NotImplementedError(f"query-attention-score pruning: groups of at most {ops.PRUNE_KEYS_MAX_N} tokens (got {n})")
+        if n > 32768:
+            raise NotImplementedError(f"query-attention-score pruning: groups of at most 32768 tokens (one softmax row of qp_query_scores lives in LDS; got {n})")
         by_vnorm = QUERY_PRUNE_MODES[cfg.top_k_predict_type]
         L = self.n_layers_total
         cos, sin = ops.mrope_table(pos.contiguous(), s.mrope_section, s.rope_theta, D)
@@ -501,7 +501,11 @@ class QuickPrefillEngine:
                     vss = self.b_ss
                 ops.query_scores(q[n:], kn, stride, n, self.hq, self.hkv, D, self.b_keys, value_sumsq=vss)
                 idx = self.b_idx[:k_keep]
-                ops.prune_keys(self.b_keys, n, k_keep, kn, vn, stride, self.hkv, D, self.arena.k(l), self.arena.v(l), hs, past, idx)
+                if n <= ops.PRUNE_KEYS_MAX_N:
+                    ops.prune_keys(self.b_keys, n, k_keep, kn, vn, stride, self.hkv, D, self.arena.k(l), self.arena.v(l), hs, past, idx)
+                else:                                                        # large group: select on the ready-made keys + gather
+                    ops.select_keys(self.b_keys, n, k_keep, idx)
+                    ops.gather_kv(kn, vn, stride, idx, k_keep, self.hkv, D, self.arena.k(l), self.arena.v(l), hs, past)
                 self.arena.len[l] = past + k_keep
                 if self.kept_trace is not None:
                     self.kept_trace.append((l, idx.clone()))

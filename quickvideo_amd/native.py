@@ -52,6 +52,7 @@ SIGNATURES = {
     "qp_key_sumsq": (_i32, [_vp, _vp, _i64, _i64, _i64, _i32, _i32, _vp, _vp]),
     "qp_select_workspace_bytes": (_sz, [_i64]),
     "qp_select_k_smallest": (_i32, [_vp, _vp, _i32, _i64, _i64, _vp, _vp, _i32, _vp, _sz, _vp]),
+    "qp_select_keys": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp]),
     "qp_gather_kv": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _i64, _vp]),
     "qp_prune_staged": (_i32, [_vp, _vp, _i32, _i64, _i64, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _i64, _vp, _vp, _i32, _vp]),
     "qp_prune_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32]),
@@ -235,6 +236,10 @@ class QuickPrefillOps:
         self._check(self.lib.qp_select_k_smallest(self.ctx, head_sumsq.data_ptr(), n_heads_total, n, k, kept_idx.data_ptr(),
                                                   _ptr(norm_bits), int(mode), self._select_ws.data_ptr(), self._select_ws.numel(),
                                                   self._stream()))
+
+    def select_keys(self, norm_keys, n, k, kept_idx):
+        """k smallest of n ready-made 16-bit sort keys (ties -> lowest index), ascending index list; any n."""
+        self._check(self.lib.qp_select_keys(self.ctx, norm_keys.data_ptr(), n, k, kept_idx.data_ptr(), self._stream()))
 
     def gather_kv(self, k_src, v_src, src_head_stride, idx, k, n_kv, head_dim, k_dst, v_dst, dst_head_stride, dst_row0):
         self._check(self.lib.qp_gather_kv(self.ctx, k_src.data_ptr(), v_src.data_ptr(), src_head_stride, idx.data_ptr(), k, n_kv,

@@ -69,6 +69,9 @@ class OracleOps:
         nb = O.key_norms_bf16(ss)
         kept_idx[:k].copy_(torch.from_numpy(O.select_k_largest(nb, k) if (mode & 1) else O.select_k_smallest(nb, k)))
 
+    def select_keys(self, norm_keys, n, k, kept_idx):
+        kept_idx[:k].copy_(torch.from_numpy(O.select_k_smallest(norm_keys[:n].numpy().view(np.uint16), k)))
+
     def gather_kv(self, k_src, v_src, src_head_stride, idx, k, n_kv, D, k_dst, v_dst, dst_head_stride, dst_row0):
         ii = idx[:k].long()
         n_src = int(ii.max()) + 1

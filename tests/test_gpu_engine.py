@@ -283,6 +283,36 @@ def test_engine_query_based_vs_oracle(pt):
     assert same / tot >= 0.9, same / tot
 
 
+def test_engine_query_based_large_group_vs_oracle():
+    """Query-score pruning on a group of more than 8192 tokens (the single-group / large-group settings of the reference,
+    `video_group_size` up to the whole video): the score keys go through qp_select_keys + qp_gather_kv instead of the one-launch
+    prune.  8448-token group, tiny dims, vs the oracle's restatement of LVUCache.update's scoring."""
+    pt = "query_attention_weights"
+    spec_o, w, plan, pos, delta, embeds = make_case(48, 32, 44, 48, 15, 20)            # ONE group of 24 x 352 = 8448 (+15) tokens
+    assert max(plan.tokens) > 8192
+    m = plan.tail_len
+    cfg = LVUConfig("x", top_p=0.5, video_group_size=48, top_k_predict_type=pt)
+    dw = DecoderWeights.from_named(TINY, w, "cuda:0")
+    eng = QuickPrefillEngine(dw, cfg, capacity=embeds.shape[0] + 8 + m, max_group_tokens=max(plan.tokens) + m, device="cuda:0")
+    eng.kept_trace = []
+    post, e, start = torch.from_numpy(pos).cuda(), embeds.cuda(), 0
+    for n in plan.tokens:
+        eng.prefill_group(e[start:start + n], post[:, start:start + n + m], prompt_embeds=e[-m:])
+        start += n
+    logits = eng.prefill_tail(e[start:], post[:, start:]).cpu()
+    ref = O.group_prefill(w, spec_o, embeds, pos, plan.tokens, O.PruneCfg(top_p=0.5, top_k_predict_type=pt))
+    assert eng.arena.len == ref["cache_len"]
+    check_logits(logits.numpy(), ref["logits"].numpy())
+    flat = [k for g in ref["kept"] for k in g]
+    tot = same = 0
+    for (l, got), want in zip(eng.kept_trace, flat):
+        if want is not None:
+            g = got.cpu().numpy()
+            assert len(g) == len(want) and np.all(np.diff(g) > 0)
+            tot += len(want); same += len(set(g.tolist()) & set(want.tolist()))
+    assert same / tot >= 0.9, same / tot
+
+
 def test_engine_cfg3_shape_two_layers_vs_oracle():
     """BASELINE.json configs[2] as a whole-engine run at the real layer width: groups of 2880 tokens (32 frames of 280x504), rho = 0.25
     (k = 720), three groups + tail through two 7B-dim layers vs the oracle: cache lengths exact, logits within tolerance, kept sets."""

@@ -294,6 +294,20 @@ def test_prune_tail_inplace_under_load(ops):
     assert bad == 0, f"{bad} of 100 in-place prunes differ from the oracle"
 
 
+@pytest.mark.parametrize("n,k", [(1, 1), (777, 300), (8193, 4000), (20000, 19999), (65536, 100), (70001, 35000)])
+def test_select_keys_any_size(ops, n, k):
+    """qp_select_keys: the select on ready-made 16-bit sort keys (what the RoPE kernel / qp_norm_keys / qp_query_scores emit), for
+    groups beyond qp_prune_keys' 8192 tokens: ascending list of the k smallest keys, ties -> lowest index, bit-exact vs the oracle;
+    few distinct values (many ties) on purpose."""
+    rs = np.random.RandomState(n + k)
+    keys = (16000 + rs.randint(0, 40, n) * 3).astype(np.uint16)
+    kd = torch.from_numpy(keys.view(np.int16)).cuda()
+    idx = torch.full((k,), -1, dtype=torch.int32, device="cuda")
+    ops.select_keys(kd, n, k, idx)
+    torch.cuda.synchronize()
+    assert np.array_equal(idx.cpu().numpy(), O.select_k_smallest(keys, k))
+
+
 def test_prune_keys_special_values_and_largest(ops):
     n, hkv = 300, 4
     keys = torch.zeros(hkv, n, D, dtype=torch.bfloat16)
