@@ -550,6 +550,7 @@ def pipeline_leg(name, eng, device, modes=("overlapped", "sequential"), warm_vid
     m = QwenVLNative(eng.w, vis, device, name=model)
     m.engine = eng                                               # same engine (KV arena, tuned GEMM plans) as the headline pass
     pipe = PrefillPipeline(m, eng.cfg, SyntheticProcessor(eng.spec), ops=eng.ops)
+    pipe.measure_vit_alone = True
     threads = int(os.environ.setdefault("QUICKCODEC_CORES", str(min(16, os.cpu_count() or 16))))   # the reference's timing scripts use 16
     dec = "&decode_h=1080&decode_w=1920"
     if name in ("cfg4", "cfg4s", "cfg4x2"):     # a 1-hour (or 6-minute) video at 8 fps sampled at 2 fps; planned at the model's frame size

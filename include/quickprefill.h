@@ -186,7 +186,8 @@ int qp_query_scores(qp_ctx* ctx, const void* q_prompt, const void* k_group, int6
  * lane, <= 64 KB per workgroup), signals "rows loaded", waits for the (at most two, always LOWER) slices whose source rows its
  * destination rows overlap, and stores to [past_len, past_len+k) — the compaction never bounces through HBM scratch.  The wait is
  * deadlock-free because it only points downwards and the whole grid (<= 512 workgroups) fits on the device at once, which the
- * library checks with the occupancy API.  The workspace then only holds the keys and the flags (2.25 bytes per token).  Larger
+ * library checks with the occupancy API (keep at most two such calls in flight at once on a device — e.g. on two streams — so that the
+ * grids together still fit).  The workspace then only holds the keys and the flags (2.25 bytes per token).  Larger
  * groups use the round-1 form (sums -> select -> gather into the workspace -> copy back). */
 size_t qp_prune_workspace_bytes(int64_t n, int64_t k, int n_kv_heads, int head_dim);
 int qp_prune_tail(qp_ctx* ctx, void* k_cache, void* v_cache, int64_t head_stride, int64_t past_len, int64_t n,

@@ -50,7 +50,7 @@ def chat_lvu_model(self, messages, _overlap: bool = True, **generation_kwargs):
     # the reference prints these six lines (qwen25_lvu.py:748-753) from unsynchronised host clocks; here: the producer's time inside
     # the frame source, the ViT by itself, the device-synchronised group loop, decode, e2e, first token
     print(f"total time spent fetching frames was: {t.sequential_fetch if not _overlap else t.producer_busy}")
-    print(f"total time spent on processor was: {t.vit_uncontended}")
+    print(f"total time spent on processor was: {t.vit_uncontended or t.vit_span}")     # GPU patchify + ViT (its span on the ViT stream)
     print(f"total time spent on prefill was: {t.prefill}")
     print(f"total time spent on decoding was: {t.decode}")
     print(f"total time spent on e2e fetching and decoding was: {t.e2e}")

@@ -73,6 +73,7 @@ class Timings:
     gpu_stall_vit: float = 0.0         # main stream idle because ViT(g) was not finished although its frames were there (ViT not hidden)
     vit_span: float = 0.0              # sum of ViT(g) start->end on its own stream WHILE the prefill shares the CUs (contended)
     vit_uncontended: float = 0.0       # ViT of one group replayed alone after the run, x groups: what the tower costs by itself
+                                       # (only with PrefillPipeline.measure_vit_alone; 0 otherwise)
 
 
 class _GpuProgress(threading.Thread):
@@ -185,6 +186,7 @@ class PrefillPipeline:
         self._tower = None
         self.vit_stream = torch.cuda.Stream(model.device) if self.use_gpu else None
         self.last_timings: Optional[Timings] = None
+        self.measure_vit_alone = False            # bench.py: replay one group's ViT pass after the run, GPU otherwise idle (3 extra passes)
 
     @property
     def tower(self) -> VisionTower:
@@ -382,7 +384,7 @@ class PrefillPipeline:
         tm.producer_busy, tm.producer_blocked, tm.producer_copy = prod.t_busy, prod.t_blocked, prod.t_copy
         if self.use_gpu and trace:
             self._device_breakdown(tm, origin, trace)
-            if os.environ.get("QP_PIPELINE_VIT_REPLAY", "1") == "1" and last_frames is not None:
+            if self.measure_vit_alone and last_frames is not None:
                 tm.vit_uncontended = self._vit_alone(last_frames) * G
         self.last_timings = tm
         return out

@@ -388,7 +388,7 @@ def test_lvu_generate_on_gpu(capsys):
         obj = lvu.LVU(lvu.LVUConfig("synthetic:tiny", model_type=mt, top_p=0.5, video_group_size=4, num_frames=16), model=m)
         outs.append(obj.generate("What is shown?", video, max_new_tokens=4))
         t = obj._pipeline.last_timings
-        assert t.groups == 4 and t.ttft > 0 and t.vit_uncontended > 0 and t.gpu_prefill_busy > 0
+        assert t.groups == 4 and t.ttft > 0 and t.vit_span > 0 and t.gpu_prefill_busy > 0
     assert outs[0] == outs[1] and outs[0][0].count("<tok_") == 4
     assert "total time spent on prefill was" in capsys.readouterr().out
 
