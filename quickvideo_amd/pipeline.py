@@ -118,6 +118,7 @@ class _Producer(threading.Thread):
         self.h2d_done = [None] * depth      # per slot: event after the last H2D copy out of the pinned buffer (copy stream)
         self.read_done = [None] * depth     # per slot: event after the consumer's last GPU read of the device buffer (ViT stream)
         self.t_busy = self.t_blocked = self.t_copy = 0.0    # host seconds: in next(reader) / waiting for a slot / filling + enqueueing
+        self.cancelled = threading.Event()
 
     def run(self):
         try:
@@ -129,6 +130,8 @@ class _Producer(threading.Thread):
                 self.t_busy += t1 - t0
                 self.slots_free.acquire()
                 self.t_blocked += pc() - t1
+                if self.cancelled.is_set():                     # the consumer gave up (exception in the group loop): do not linger
+                    return
                 if self.use_gpu:
                     if self.ring is None:
                         shape = (self.fpg,) + tuple(frames.shape[1:])
@@ -172,6 +175,17 @@ class _Producer(threading.Thread):
         if item is None:
             raise self.exc
         return item
+
+    def cancel(self):
+        """Called by the consumer when it leaves the group loop early: wakes the thread wherever it waits and lets it end."""
+        self.cancelled.set()
+        for _ in range(self.depth + 1):
+            self.slots_free.release()
+        try:
+            while True:
+                self.q.get_nowait()                               # a put() blocked on the full queue returns
+        except queue.Empty:
+            pass
 
     def release(self, g: int = 0, read_done=None):
         """Group g's slot may be refilled; `read_done` = event recorded after the last GPU read of its device buffer."""
@@ -320,32 +334,36 @@ class PrefillPipeline:
         # keys (qwen25_lvu.py:661-664, 684-689); positions are then the group's AND the next tail_len of the sequence
         q_m = plan.tail_len if (self.cfg.query_based and self.cfg.enable) else 0
         tail_emb = eng.embed_tokens(tail) if q_m else None
-        nxt = vit_group(0)
         last_frames = None
-        for g, n in enumerate(plan.tokens):
-            feats, evs, read_done, last_frames = nxt
-            if self.use_gpu:
-                main = torch.cuda.current_stream(dev)
-                main.wait_event(evs[1])
-                # feats was allocated on the ViT stream and is read on the main stream (cat / copy into the engine's buffer): tell
-                # the caching allocator, or ViT(g+2) could be handed the same block while prefill(g) is still queued
-                feats.record_stream(main)
-                p0 = ev_t(); p0.record(main)
-            emb = torch.cat([eng.embed_tokens(prefix), feats], 0) if g == 0 else feats
-            assert emb.shape[0] == n, (emb.shape, n)
-            # prefill(g) is enqueued BEFORE the host asks for group g+1's frames: with a producer-bound source (short videos)
-            # prod.get() blocks until they exist, and the GPU must not sit idle behind that wait (round 2 had the two the other
-            # way round: cfg2's overlapped TTFT carried ~70 ms of it).  ViT(g+1) still runs ahead on its own stream.
-            eng.prefill_group(emb, pos[:, start:start + n + q_m], prompt_embeds=tail_emb)
-            if self.use_gpu:
-                p1 = ev_t(); p1.record(torch.cuda.current_stream(dev))
-                trace.append((evs[2], evs[0], evs[1], p0, p1))
-            prod.release(g, read_done)
-            if g + 1 < G:
-                nxt = vit_group(g + 1)                                # ViT of the next group: own stream, overlaps prefill(g) on the GPU
-            start += n
-            if dbg is not None:
-                dbg.enqueued(evs[1], p1)
+        try:
+            nxt = vit_group(0)
+            for g, n in enumerate(plan.tokens):
+                feats, evs, read_done, last_frames = nxt
+                if self.use_gpu:
+                    main = torch.cuda.current_stream(dev)
+                    main.wait_event(evs[1])
+                    # feats was allocated on the ViT stream and is read on the main stream (cat / copy into the engine's buffer): tell
+                    # the caching allocator, or ViT(g+2) could be handed the same block while prefill(g) is still queued
+                    feats.record_stream(main)
+                    p0 = ev_t(); p0.record(main)
+                emb = torch.cat([eng.embed_tokens(prefix), feats], 0) if g == 0 else feats
+                assert emb.shape[0] == n, (emb.shape, n)
+                # prefill(g) is enqueued BEFORE the host asks for group g+1's frames: with a producer-bound source (short videos)
+                # prod.get() blocks until they exist, and the GPU must not sit idle behind that wait (round 2 had the two the other
+                # way round: cfg2's overlapped TTFT carried ~70 ms of it).  ViT(g+1) still runs ahead on its own stream.
+                eng.prefill_group(emb, pos[:, start:start + n + q_m], prompt_embeds=tail_emb)
+                if self.use_gpu:
+                    p1 = ev_t(); p1.record(torch.cuda.current_stream(dev))
+                    trace.append((evs[2], evs[0], evs[1], p0, p1))
+                prod.release(g, read_done)
+                if g + 1 < G:
+                    nxt = vit_group(g + 1)                                # ViT of the next group: own stream, overlaps prefill(g) on the GPU
+                start += n
+                if dbg is not None:
+                    dbg.enqueued(evs[1], p1)
+        except BaseException:            # leave no producer thread behind that waits for a slot nobody will release
+            prod.cancel()
+            raise
         sync()
         if dbg is not None:
             dbg.stop()

@@ -677,3 +677,37 @@ def test_generation_kwargs_like_hf_generate():
         run(num_beams=4)
     m.generation_defaults = {"do_sample": True, "temperature": 5.0}                      # generation_config.json of a checkpoint
     assert len({run(seed=s) for s in range(4)}) > 1 and run(do_sample=False) == greedy   # explicit kwargs win
+
+
+def test_consumer_failure_does_not_leave_a_producer_thread_behind():
+    """If the group loop raises (here: a KV arena too small for the second group), the producer thread — possibly parked on the ring's
+    semaphore or on a full queue — must be told and end, not wait for a slot nobody will release (a leaked thread per failed request
+    in a long-lived process)."""
+    import threading
+    import time
+    import lvu
+    from quickvideo_amd.engine import QuickPrefillEngine
+    from quickvideo_amd.lvu import load_native_model
+    from quickvideo_amd.pipeline import PrefillPipeline, _Producer
+    from quickvideo_amd.processor import SyntheticProcessor
+    m = load_native_model("synthetic:tiny", device="cpu")
+    pipe = PrefillPipeline(m, lvu.LVUConfig("synthetic:tiny", top_p=0.5, video_group_size=2, num_frames=24), SyntheticProcessor(m.spec),
+                           ops=OracleOps())
+    calls, orig = [0], QuickPrefillEngine.prefill_group
+
+    def failing(self, *a, **kw):
+        calls[0] += 1
+        if calls[0] == 2:
+            raise RuntimeError("KV arena overflow (injected)")
+        return orig(self, *a, **kw)
+    QuickPrefillEngine.prefill_group = failing
+    before = {t.ident for t in threading.enumerate()}
+    try:
+        with pytest.raises(RuntimeError, match="injected"):
+            pipe.generate("What?", "synthetic://?frames=96&h=56&w=84&seed=2&pattern=gradient", max_new_tokens=1)
+    finally:
+        QuickPrefillEngine.prefill_group = orig
+    deadline = time.time() + 5
+    while time.time() < deadline and any(isinstance(t, _Producer) and t.is_alive() for t in threading.enumerate()):
+        time.sleep(0.05)
+    assert not any(isinstance(t, _Producer) and t.is_alive() for t in threading.enumerate() if t.ident not in before)
