@@ -240,7 +240,8 @@ def test_prune_keys_spread_over_high_bytes(ops):
 
 @pytest.mark.parametrize("past,n,k,hkv", [(0, 1, 1, 4), (3, 2, 1, 2), (0, 16, 16, 1), (5, 17, 16, 4), (100, 64, 64, 4), (7, 1025, 1, 4),
                                           (1120, 2240, 1120, 4), (0, 3073, 5, 4), (2887, 5760, 2880, 4), (11, 6145, 3000, 1),
-                                          (0, 8192, 4096, 4), (480, 960, 480, 8), (9, 8192, 8191, 2), (40, 9000, 4500, 4)])
+                                          (0, 8192, 4096, 4), (480, 960, 480, 8), (9, 8192, 8191, 2), (40, 9000, 4500, 4),
+                                          (250000, 2240, 1120, 4)])          # last: the 1-hour video's steady state (cfg4, group 224)
 def test_prune_tail_inplace_edge_sizes(ops, past, n, k, hkv):
     """qp_prune_tail (round 3: norm keys + ONE in-place select/compact launch with a slice-ordered hand-shake; n > 8192 keeps the
     round-1 staged form): kept list and compacted arena rows bit-exact vs the oracle, rows in front of the tail untouched, for
