@@ -140,15 +140,20 @@ __global__ __launch_bounds__(256) void vit_rope_kernel(uint4* __restrict__ qkv, 
     const float* sn = sin_t + t * (half8 * 8) + c * 8;
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
+      // hipcc compiles with -ffp-contract=fast: nothing but this pragma keeps the multiplies and the add from becoming v_pk_fma_f32 (they did, the moment the bf16 conversion became one instruction and the
+      // loop body got vectorised; the result then differs from torch's three separately rounded ops in the last bit)
+#pragma clang fp contract(off)
       float x0 = __uint_as_float(aw[w] << 16), x1 = __uint_as_float(aw[w] & 0xffff0000u);
       float y0 = __uint_as_float(bw[w] << 16), y1 = __uint_as_float(bw[w] & 0xffff0000u);
       float c0 = cs[2 * w], c1 = cs[2 * w + 1], s0 = sn[2 * w], s1 = sn[2 * w + 1];
       // first half: x*cos + (-y)*sin ; second half: y*cos + x*sin
       // separately rounded fp32 mul / mul / add like the torch ops (no fma contraction)
-      ao[w] = (unsigned)f32_to_bf16_bits(__fadd_rn(__fmul_rn(x0, c0), __fmul_rn(-y0, s0))) |
-              ((unsigned)f32_to_bf16_bits(__fadd_rn(__fmul_rn(x1, c1), __fmul_rn(-y1, s1))) << 16);
-      bo[w] = (unsigned)f32_to_bf16_bits(__fadd_rn(__fmul_rn(y0, c0), __fmul_rn(x0, s0))) |
-              ((unsigned)f32_to_bf16_bits(__fadd_rn(__fmul_rn(y1, c1), __fmul_rn(x1, s1))) << 16);
+      // (plain * and + written HERE: the contract flag of an operation is the one of the scope it is written in, so the header's
+      // __fmul_rn / __fadd_rn — inline functions compiled under contract=fast — would still fuse)
+      const float p00 = x0 * c0, p01 = (-y0) * s0, p10 = x1 * c1, p11 = (-y1) * s1;
+      const float q00 = y0 * c0, q01 = x0 * s0, q10 = y1 * c1, q11 = x1 * s1;
+      ao[w] = (unsigned)f32_to_bf16_bits(p00 + p01) | ((unsigned)f32_to_bf16_bits(p10 + p11) << 16);
+      bo[w] = (unsigned)f32_to_bf16_bits(q00 + q01) | ((unsigned)f32_to_bf16_bits(q10 + q11) << 16);
     }
     qkv[base] = make_uint4(ao[0], ao[1], ao[2], ao[3]);
     qkv[base + half8] = make_uint4(bo[0], bo[1], bo[2], bo[3]);
