@@ -6,7 +6,8 @@ dev = torch.device("cuda:0")
 w = VisionWeights.synthetic(QWEN25_VL_VIT_7B if os.environ.get('QP_VIT_ARCH') == '2.5' else QWEN2_VL_VIT_7B, dev)
 from quickvideo_amd.native import QuickPrefillOps
 tower = VisionTower(w, ops=QuickPrefillOps(dev) if os.environ.get('QP_VIT_OPS','1')=='1' else None)
-frames = torch.randint(0, 256, (16, 3, 560, 1008), dtype=torch.uint8, device=dev)
+H_, W_ = (int(v) for v in os.environ.get("QP_VIT_HW", "560,1008").split(","))     # QP_VIT_HW=392,560: one group of the 1-hour video (cfg4)
+frames = torch.randint(0, 256, (16, 3, H_, W_), dtype=torch.uint8, device=dev)
 def f():
     rows, grid = patchify_frames(frames, w.spec)
     return tower.forward(rows, grid)
@@ -17,5 +18,6 @@ s.record()
 for _ in range(3): f()
 e.record(); torch.cuda.synchronize()
 ms = s.elapsed_time(e) / 3
-fl = w.spec.flops_per_patch() * 23040 + 32 * 8 * 16 * 4 * 2880 * 2880 * 80
+npatch, seq = 8 * (H_ // 14) * (W_ // 14), (H_ // 14) * (W_ // 14)
+fl = w.spec.flops_per_patch() * npatch + 32 * 8 * 16 * 4 * seq * seq * 80
 print(f"ViT group: {ms:.2f} ms, {fl/ms/1e9:.1f} TF (linear+attn flops {fl/1e12:.2f} T)")
