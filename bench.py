@@ -452,6 +452,54 @@ def _cpu_time_group(O, spec, w, ps, sample_layers, n_rows, P, rho, rn):
     return time.perf_counter() - t0
 
 
+def cpu_baseline_check(name, group=None, layers=4):
+    """`--cpu-baseline-check CFG` (minutes of CPU, not part of the default run): how good is the bounded-sample estimator on a LONG
+    video, where no full CPU run is affordable?  Times `layers` oracle decoder layers (distinct weights: 0.5 GB each at 7B dims, beyond
+    any L3) over ALL rows of one mid-video group on its full pruned prefix, and compares with what the default estimator's sample —
+    ONE layer over the first n/8 rows — predicts for the same work."""
+    from oracle import qp_oracle as O
+    model, frames, fh, fw, gs, rho, prefix, tail = CONFIGS[name]
+    ps = PRESETS[model]
+    cores = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(cores)
+    gh, gw = fh // 14, fw // 14
+    plan = planner.plan_groups(frames, gs, gh, gw, prefix, prefix + (frames // 2) * (gh // 2) * (gw // 2) + tail)
+    G = len(plan.tokens)
+    gi = G // 2 if group is None else group
+    ks = [effective_k(n, LVUConfig(model, top_p=rho), 0, ps.n_layers) or n for n in plan.tokens]
+    P = sum(ks[:gi])
+    g = torch.Generator().manual_seed(0)
+    rn = lambda *s_, sc=0.02: (torch.randn(*s_, generator=g) * sc).to(torch.bfloat16)
+    n = plan.tokens[gi]
+    rows = max(64, n // 8)
+    spec1, w1 = _cpu_layers(O, ps, 1, rn)
+    t_sample = _cpu_time_group(O, spec1, w1, ps, 1, rows, P, rho, rn)
+    specL, wL = _cpu_layers(O, ps, layers, rn)
+    t_full = _cpu_time_group(O, specL, wL, ps, layers, n, P, rho, rn)
+    pred = t_sample * (n / rows) * layers
+    return {"config": describe(name), "group": gi, "prefix_rows": P, "cores": cores,
+            "measured": {"layers": layers, "rows": n, "seconds": round(t_full, 2)},
+            "estimator_sample": {"layers": 1, "rows": rows, "seconds": round(t_sample, 3), "predicts_seconds_for_the_measured_work": round(pred, 2)},
+            "estimator_over_measured_speed": round(t_full / pred, 3),
+            "note": "ratio > 1: the estimator reads too FAST by that factor for this group (the figure `cpu_baseline.value` should be divided by)"}
+
+
+def _cpu_error_band(tok_s, G):
+    """How far the bounded-sample estimate can be off, from committed checks on the GPU box's host (not taken in this run)."""
+    if G >= 16:      # long video: one layer over the first n/8 rows of three groups; attention over 250k-500k keys dominates
+        return {"estimator_over_measured_speed": 0.756,
+                "plausible_value_range": [round(tok_s, 3), round(tok_s / 0.756, 3)],
+                "source": "bench.py --cpu-baseline-check cfg4 (profiles/r3_cpu_baseline_check_cfg4.json): 4 distinct layers over ALL 2240 rows of group "
+                          "225 on its 252 007-row prefix took 253 s where this estimator's sample (1 layer, 280 rows) predicts 335 s — long-prefix "
+                          "attention runs MORE efficiently on the CPU with all rows, so the estimate is ~1.3x too slow there; no full CPU run of "
+                          "the 1-hour video is affordable (days)"}
+    return {"estimator_over_measured_speed": [1.25, 2.4],
+            "plausible_value_range": [round(tok_s / 2.4, 3), round(tok_s / 1.25, 3)],
+            "source": "the estimator against FULL oracle runs on the GPU box's host: cfg2 42.6 estimated vs 31.4 measured tok/s (x1.36), cfg3 122.6 vs "
+                      "51.5 (x2.38) — profiles/r2_cpu_full_cfg{2,3}.json; --cpu-baseline-check cfg2: x1.25 (profiles/r3_cpu_baseline_check_cfg2.json): "
+                      "two sampled layers stay warmer in the host's caches than 28 do"}
+
+
 def cpu_baseline(name, sample_layers=2):
     """The CPU oracle (oracle/qp_oracle.py — the checker, used here only as the reported baseline) on a bounded sample.
 
@@ -501,10 +549,7 @@ def cpu_baseline(name, sample_layers=2):
     total = sum((a + b * Pg[i]) * (plan.tokens[i] / rows) for i in range(G)) * (ps.n_layers / sample_layers)
     tok_s = sum(plan.tokens) / total
     return {"value": round(tok_s, 3), "unit": "tokens/s", "cores": cores, "kind": "port", "extrapolated": True,
-            "error_band": {"estimator_reads_high_by": [1.4, 2.4],
-                           "plausible_value_range": [round(tok_s / 2.4, 3), round(tok_s / 1.4, 3)],
-                           "source": "the same three-point estimator against FULL oracle runs on the GPU box's host: cfg2 42.6 estimated vs 31.4 "
-                                     "measured tok/s (x1.36), cfg3 122.6 vs 51.5 (x2.38) — profiles/r2_cpu_full_cfg{2,3}.json"},
+            "error_band": _cpu_error_band(tok_s, G),
             "full_video_cpu_seconds_extrapolated": round(total, 1),
             "points": [{"group": gi, "prefix_rows": p, "seconds": round(t, 3)} for gi, p, t in pts],
             "sample": f"extrapolated (BASELINE.md §3): {sample_layers} of {ps.n_layers} decoder layers (bf16 torch-CPU oracle incl. key-norm "
@@ -861,6 +906,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", default=None, metavar="CFG", help="only run the oracle's FULL prefill of a short config on the host "
                     "cores (cfg1, cfg2, cfg3: minutes) and print its JSON")
+    ap.add_argument("--cpu-baseline-check", default=None, metavar="CFG", help="only check the bounded-sample CPU estimator against a fuller CPU "
+                    "measurement of one mid-video group (4 layers x all rows; minutes) and print its JSON")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the video -> first token leg through the real front end")
     ap.add_argument("--no-decode", action="store_true", help="skip the greedy-decode leg (hipGraph step, ms per token)")
@@ -878,6 +925,9 @@ def main():
     args = ap.parse_args()
     if args.lean:
         args.no_cpu_baseline = args.no_pipeline = args.no_decode = args.no_secondary = True
+    if args.cpu_baseline_check:
+        print(json.dumps(cpu_baseline_check(args.cpu_baseline_check)))
+        return
     if args.cpu_baseline_full:
         full = cpu_baseline_full(args.cpu_baseline_full)
         full["sampled_estimate"] = cpu_baseline(args.cpu_baseline_full)
