@@ -48,7 +48,7 @@ typedef enum qp_status {
 int qp_create(qp_ctx** out, int device);
 void qp_destroy(qp_ctx* ctx);
 const char* qp_last_error(void);
-const char* qp_version(void);
+const char* qp_version(void);          /* "quickprefill-mi355x 0.3 (gfx950)": 0.3 = round 3, prune_mode became a per-call argument */
 int qp_device_cus(const qp_ctx* ctx);
 
 /* Host helper of the overlap producer (no device work): memcpy `bytes` from src to dst (e.g. decoded uint8 frames into a pinned
