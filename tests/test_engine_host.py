@@ -247,3 +247,16 @@ def test_query_based_groups_host_logic(pt):
     # and the mode is not the key-norm mode in disguise
     base = O.group_prefill(w, spec_o, embeds, pos, plan.tokens, O.PruneCfg(top_p=0.5))
     assert any(not np.array_equal(a, b) for a, b in zip(flat, [k for g in base["kept"] for k in g]) if a is not None)
+
+
+def test_bench_cpu_baseline_check_mode_runs_without_a_gpu():
+    """`bench.py --cpu-baseline-check CFG` (the calibration of the bounded-sample CPU estimator; only the oracle runs) prints one JSON
+    object with the measured / predicted seconds and their ratio."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--cpu-baseline-check", "tiny"], capture_output=True, text=True, timeout=300, cwd=root)
+    assert p.returncode == 0, p.stderr[-1000:]
+    d = json.loads(p.stdout.strip().splitlines()[-1])
+    assert d["measured"]["layers"] == 4 and d["estimator_sample"]["layers"] == 1 and d["estimator_over_measured_speed"] > 0
