@@ -1,0 +1,86 @@
+"""Randomised shape fuzzing of the prune seam on the GPU (hypothesis picks the shapes and the key distribution; the CPU oracle is the
+judge): the in-place `qp_prune_tail`, the staged `qp_prune_keys` and `qp_select_keys` must agree with it bit for bit — kept index list,
+compacted rows, nothing written outside [past, past + n)."""
+import numpy as np
+import pytest
+import torch
+from hypothesis import HealthCheck, given, settings, strategies as st
+
+from oracle import qp_oracle as O
+
+pytestmark = pytest.mark.gpu
+D = 128
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from quickvideo_amd.native import QuickPrefillOps
+    return QuickPrefillOps(torch.device("cuda:0"))
+
+
+def _keys(rs, hkv, rows, levels):
+    """Key rows whose norms fall on `levels` distinct magnitudes (few levels = many ties at the threshold)."""
+    x = rs.standard_normal((hkv, rows, D)).astype(np.float32)
+    if levels:
+        x /= np.linalg.norm(x.transpose(1, 0, 2).reshape(rows, -1), axis=1)[None, :, None]
+        x *= (1.0 + rs.randint(0, levels, rows))[None, :, None]
+    return torch.from_numpy(x).to(torch.bfloat16)
+
+
+@settings(max_examples=40, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(past=st.integers(0, 3000), n=st.integers(1, 8192), frac=st.floats(0.001, 1.0), hkv=st.sampled_from([1, 2, 4, 8]),
+       levels=st.sampled_from([0, 0, 3, 40]), mode=st.sampled_from([0, 1, 2, 3]), seed=st.integers(0, 2 ** 16))
+def test_prune_tail_inplace_random_shapes(ops, past, n, frac, hkv, levels, mode, seed):
+    k = max(1, min(n, int(round(frac * n))))
+    rs = np.random.RandomState(seed)
+    keys, vals = _keys(rs, hkv, past + n, levels), _keys(rs, hkv, past + n, levels)
+    cap = past + n + 3
+    kc = torch.zeros(hkv, cap, D, dtype=torch.bfloat16, device="cuda"); vc = torch.zeros_like(kc)
+    kc[:, :past + n] = keys.cuda(); vc[:, :past + n] = vals.cuda()
+    idx = torch.full((k,), -1, dtype=torch.int32, device="cuda")
+    ws = torch.empty(ops.prune_workspace_bytes(n, k, hkv, D), dtype=torch.uint8, device="cuda").random_(0, 256)
+    ops.prune_tail(kc, vc, cap * D, past, n, k, hkv, D, idx, ws, mode=mode)
+    torch.cuda.synchronize()
+    scored = vals if mode & 2 else keys                                    # bit 1: value rows; bit 0: k largest
+    nb = O.key_norms_bf16(O.key_sumsq_heads(O.torch_bf16_to_bits(scored[:, past:].contiguous())))
+    want = O.select_k_largest(nb, k) if mode & 1 else O.select_k_smallest(nb, k)
+    assert np.array_equal(idx.cpu().numpy(), want)
+    ti = torch.from_numpy(want.astype(np.int64)) + past
+    assert torch.equal(kc[:, past:past + k].cpu(), keys[:, ti]) and torch.equal(vc[:, past:past + k].cpu(), vals[:, ti])
+    assert torch.equal(kc[:, :past].cpu(), keys[:, :past]) and torch.count_nonzero(kc[:, past + n:]).item() == 0
+
+
+@settings(max_examples=30, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(n=st.integers(1, 70000), frac=st.floats(0.0005, 1.0), levels=st.sampled_from([2, 40, 5000]), seed=st.integers(0, 2 ** 16))
+def test_select_keys_random_sizes(ops, n, frac, levels, seed):
+    k = max(1, min(n, int(round(frac * n))))
+    rs = np.random.RandomState(seed)
+    keys = (12000 + rs.randint(0, levels, n) * 7).astype(np.uint16)
+    idx = torch.full((k,), -1, dtype=torch.int32, device="cuda")
+    ops.select_keys(torch.from_numpy(keys.view(np.int16)).cuda(), n, k, idx)
+    torch.cuda.synchronize()
+    assert np.array_equal(idx.cpu().numpy(), O.select_k_smallest(keys, k))
+
+
+@settings(max_examples=30, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(past=st.integers(0, 500), n=st.integers(1, 8192), frac=st.floats(0.001, 1.0), hkv=st.sampled_from([1, 2, 4, 8]),
+       levels=st.sampled_from([0, 3, 40]), seed=st.integers(0, 2 ** 16))
+def test_prune_keys_staged_random_shapes(ops, past, n, frac, hkv, levels, seed):
+    k = max(1, min(n, int(round(frac * n))))
+    rs = np.random.RandomState(seed)
+    ks, vs = _keys(rs, hkv, n, levels).cuda(), _keys(rs, hkv, n, levels).cuda()
+    ss = torch.empty(hkv, n, dtype=torch.float32, device="cuda")
+    ops.key_sumsq(ks, n * D, 0, n, hkv, D, ss)
+    nk = torch.zeros(n, dtype=torch.int16, device="cuda")
+    ops.norm_keys(ss, hkv, n, nk)
+    cap = past + k + 2
+    kc = torch.zeros(hkv, cap, D, dtype=torch.bfloat16, device="cuda"); vc = torch.zeros_like(kc)
+    idx = torch.full((k,), -1, dtype=torch.int32, device="cuda")
+    ops.prune_keys(nk, n, k, ks, vs, n * D, hkv, D, kc, vc, cap * D, past, idx)
+    torch.cuda.synchronize()
+    nb = O.key_norms_bf16(O.key_sumsq_heads(O.torch_bf16_to_bits(ks.cpu())))
+    want = O.select_k_smallest(nb, k)
+    assert np.array_equal(idx.cpu().numpy(), want)
+    ti = torch.from_numpy(want.astype(np.int64)).cuda()
+    assert torch.equal(kc[:, past:past + k], ks[:, ti]) and torch.equal(vc[:, past:past + k], vs[:, ti])
+    assert torch.count_nonzero(kc[:, :past]).item() == 0 and torch.count_nonzero(kc[:, past + k:]).item() == 0
