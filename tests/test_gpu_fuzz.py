@@ -84,3 +84,46 @@ def test_prune_keys_staged_random_shapes(ops, past, n, frac, hkv, levels, seed):
     ti = torch.from_numpy(want.astype(np.int64)).cuda()
     assert torch.equal(kc[:, past:past + k], ks[:, ti]) and torch.equal(vc[:, past:past + k], vs[:, ti])
     assert torch.count_nonzero(kc[:, :past]).item() == 0 and torch.count_nonzero(kc[:, past + k:]).item() == 0
+
+
+@settings(max_examples=40, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.function_scoped_fixture])
+@given(n=st.integers(1, 700), P=st.integers(0, 3000), heads=st.sampled_from([(2, 1), (4, 2), (8, 1), (28, 4), (6, 2), (4, 4), (7, 1)]),
+       staged=st.booleans(), sub=st.booleans(), sigma=st.sampled_from([0.3, 1.0, 3.0]), seed=st.integers(0, 2 ** 16),
+       variant=st.sampled_from([None, None, "7", "8", "4"]))
+def test_prefill_attn_random_shapes(ops, n, P, heads, staged, sub, sigma, seed, variant):
+    """qp_prefill_attn[_rows] on random (n, prefix, head layout, staging layout, query sub-range, softmax peakedness, kernel form) vs
+    the oracle's fp32-softmax bottom-right attention: |err| <= 1.5e-2 + 1.5e-2 |ref| (bf16 P and output)."""
+    import os
+    hq, hkv = heads
+    rs = np.random.RandomState(seed)
+    q = torch.from_numpy((rs.standard_normal((n, hq, D)) * sigma).astype(np.float32)).to(torch.bfloat16)
+    k = torch.from_numpy(rs.standard_normal((hkv, P + n, D)).astype(np.float32)).to(torch.bfloat16)
+    v = torch.from_numpy(rs.standard_normal((hkv, P + n, D)).astype(np.float32)).to(torch.bfloat16)
+    ref = O.attention_bottom_right(q.transpose(0, 1), k, v, D ** -0.5).float()
+    q0, nq = (int(rs.randint(0, n)), None) if sub else (0, n)
+    if sub:
+        nq = int(rs.randint(1, n - q0 + 1))
+    cap = P + n + 5
+    kc = torch.full((hkv, cap, D), float("nan"), dtype=torch.bfloat16, device="cuda"); vc = torch.full_like(kc, float("nan"))
+    kc[:, :P] = k[:, :P].cuda(); vc[:, :P] = v[:, :P].cuda()
+    out = torch.empty(nq, hq, D, dtype=torch.bfloat16, device="cuda")
+    old = os.environ.pop("QP_ATTN_VARIANT", None)
+    if variant:
+        os.environ["QP_ATTN_VARIANT"] = variant
+    try:
+        if staged:
+            kn, vn = k[:, P:].contiguous().cuda(), v[:, P:].contiguous().cuda()
+            ops.prefill_attn(q[q0:q0 + nq].contiguous().cuda(), kc, vc, cap * D, P, kn, vn, n * D, n, hq, hkv, D, D ** -0.5, out, q_row0=q0, nq=nq)
+        else:
+            kc[:, P:P + n] = k[:, P:].cuda(); vc[:, P:P + n] = v[:, P:].cuda()
+            ops.prefill_attn(q[q0:q0 + nq].contiguous().cuda(), kc, vc, cap * D, P, kc[:, P:], vc[:, P:], cap * D, n, hq, hkv, D, D ** -0.5, out,
+                             q_row0=q0, nq=nq)
+        torch.cuda.synchronize()
+    finally:
+        os.environ.pop("QP_ATTN_VARIANT", None)
+        if old is not None:
+            os.environ["QP_ATTN_VARIANT"] = old
+    got, want = out.float().cpu(), ref[q0:q0 + nq]
+    assert torch.isfinite(got).all()
+    err = (got - want).abs()
+    assert (err <= 1.5e-2 + 1.5e-2 * want.abs()).all(), (err.max().item(), n, P, heads, q0, nq, variant)

@@ -83,3 +83,34 @@ def test_planner_matches_oracle_and_conserves_tokens(frames, gs, gh, gw, prefix,
     b = O.plan_groups(frames, gs, gh, gw, prefix, T)
     assert a.tokens == b.tokens and a.tail_len == b.tail_len
     assert sum(a.tokens) + a.tail_len == T and all(t >= 0 for t in a.tokens)     # (the reference's float-ratio truncation can yield empty groups on 1-token grids)
+
+
+@settings(max_examples=25, deadline=None, derandomize=True)
+@given(frames=st.sampled_from([4, 8, 12, 16]), gh=st.sampled_from([4, 8]), gw=st.sampled_from([4, 6]), gs=st.sampled_from([0, 2, 4, 6, 8]),
+       prefix=st.integers(1, 12), tail=st.integers(2, 9), top_p=st.sampled_from([None, 0.2, 0.5, 0.9, 1.0]),
+       top_k=st.sampled_from([None, None, 3, 40]), pps=st.sampled_from([None, None, 0, 1, 2]),
+       decay=st.sampled_from([None, None, "linear", "exponential"]), tksl=st.sampled_from([None, None, 1]),
+       mode=st.sampled_from(["key_norms_small", "key_norms_small", "key_norms", "vector_norms_small", "vector_norms"]))
+def test_engine_host_logic_equals_oracle_on_random_configs(frames, gh, gw, gs, prefix, tail, top_p, top_k, pps, decay, tksl, mode):
+    """The engine's host logic (group loop, arena bookkeeping, effective-k incl. decay / starting layers, hidden-state hand-off, prune
+    modes) with the oracle's math plugged in must BE the oracle: same cache lengths, same kept lists, identical logits and arena rows
+    — over random LVUConfig / video geometry combinations (the reference's knobs of lvu_config.py:3-55)."""
+    import torch
+    from tests.oracle_ops import OracleOps
+    from tests.test_engine_host import make_case, run_engine
+    if top_k is None and top_p is None and decay is not None:
+        decay = None                                        # the reference raises there (None * factor): covered by the effective-k table
+    spec_o, w, plan, pos, delta, embeds = make_case(frames, gh, gw, gs, prefix, tail)
+    fac = 0.8 if decay == "exponential" else None
+    cfg = LVUConfig("x", top_p=top_p, top_k=top_k, prefill_prune_starting_layer=pps, top_k_decay_type=decay, top_k_decay_factor=fac,
+                    top_k_starting_layer=tksl, video_group_size=gs, top_k_predict_type=mode)
+    eng, logits = run_engine(w, plan, pos, embeds, cfg, OracleOps())
+    ref = O.group_prefill(w, spec_o, embeds, pos, plan.tokens,
+                          O.PruneCfg(top_k=top_k, top_p=top_p, top_k_decay_type=decay, top_k_decay_factor=fac, prefill_prune_starting_layer=pps,
+                                     top_k_starting_layer=tksl, top_k_predict_type=mode))
+    assert eng.arena.len == ref["cache_len"]
+    for (l, got), want in zip(eng.kept_trace, [k for g in ref["kept"] for k in g]):
+        assert (got is None) == (want is None) and (want is None or np.array_equal(got.numpy(), want))
+    assert torch.equal(logits, ref["logits"])
+    for l in range(spec_o.n_layers):
+        assert torch.equal(eng.arena.k(l)[:, :eng.arena.len[l]], ref["cache"].k[l])
