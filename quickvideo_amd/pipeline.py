@@ -118,6 +118,7 @@ class _Producer(threading.Thread):
         self.h2d_done = [None] * depth      # per slot: event after the last H2D copy out of the pinned buffer (copy stream)
         self.read_done = [None] * depth     # per slot: event after the consumer's last GPU read of the device buffer (ViT stream)
         self.t_busy = self.t_blocked = self.t_copy = 0.0    # host seconds: in next(reader) / waiting for a slot / filling + enqueueing
+        self.t_sem = self.t_sync = self.t_put = 0.0         # split of the waits: ring semaphore / previous H2D out of the pinned slot / full queue
         self.cancelled = threading.Event()
 
     def run(self):
@@ -130,6 +131,7 @@ class _Producer(threading.Thread):
                 self.t_busy += t1 - t0
                 self.slots_free.acquire()
                 self.t_blocked += pc() - t1
+                self.t_sem += pc() - t1
                 if self.cancelled.is_set():                     # the consumer gave up (exception in the group loop): do not linger
                     return
                 if self.use_gpu:
@@ -152,6 +154,7 @@ class _Producer(threading.Thread):
                         self.h2d_done[slot].synchronize()
                     t3 = pc()
                     self.t_blocked += t3 - t2
+                    self.t_sync += t3 - t2
                     # native, GIL-free fill of the pinned slot (qp_host_memcpy through ctypes; 2-10x faster than Tensor.copy_ here,
                     # whose speed follows torch's process-wide intra-op thread count): the launching thread is never starved
                     host_memcpy(host[: frames.shape[0]], frames.contiguous())
@@ -162,8 +165,10 @@ class _Producer(threading.Thread):
                         ev = torch.cuda.Event(enable_timing=True)
                         ev.record(self.copy_stream)
                     self.h2d_done[slot] = ev
-                    self.t_copy += pc() - t3
+                    t4 = pc()
+                    self.t_copy += t4 - t3
                     self.q.put((g, dev[: frames.shape[0]], ev))
+                    self.t_put += pc() - t4
                 else:
                     self.q.put((g, frames.clone(), None))
         except BaseException as e:   # re-raised in the consumer, like interleaved:291-292, 314-316
@@ -399,7 +404,11 @@ class PrefillPipeline:
         sync()
         tm.decode = time.perf_counter() - t_dec
         tm.e2e = time.perf_counter() - t_e2e
-        tm.producer_busy, tm.producer_blocked, tm.producer_copy = prod.t_busy, prod.t_blocked, prod.t_copy
+        tm.producer_busy, tm.producer_blocked, tm.producer_copy = prod.t_busy, prod.t_blocked + prod.t_put, prod.t_copy
+        if os.environ.get("QP_PIPELINE_DEBUG"):
+            import sys
+            print(f"[pipeline] producer waits: ring semaphore {prod.t_sem:.3f} s, previous H2D of the pinned slot {prod.t_sync:.3f} s, full queue "
+                  f"{prod.t_put:.3f} s; consumer in get() {tm.consumer_get_wait:.3f} s", file=sys.stderr, flush=True)
         if self.use_gpu and trace:
             self._device_breakdown(tm, origin, trace)
             if self.measure_vit_alone and last_frames is not None:
