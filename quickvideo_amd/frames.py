@@ -16,6 +16,9 @@ There is no FFmpeg / codec in this image, so real containers cannot be decoded; 
     video on 16 threads, assets/imgs/video_processing_times.png): each worker pads its frame to decode_s * threads / n_frames with a
     sleep when the real work was cheaper (a codec's latency without burning the host); never shortens real work
   * *.npy / *.pt files holding uint8 [F, 3, H, W] (pre-decoded video)
+  * a DIRECTORY of image files (frame_000001.jpg ...; sorted by name; optional `fps.txt` holding the frame rate): every requested
+    frame is DECODED (PIL: JPEG / PNG / ...) and LANCZOS-resized on the reader's worker threads — a real decode workload without
+    FFmpeg (e.g. frames exported once with any tool; the reference keeps such a JPEG frame cache itself, lvu_cache.py:28-49)
 A real decoder plugs in by implementing the same five members.  Environment knobs QUICKCODEC_CORES /
 QUICKCODEC_INTERVALS are read like the reference does (interleaved:391-392) and passed to the reader."""
 from __future__ import annotations
@@ -149,6 +152,51 @@ class ArrayVideoReader(VideoReaderBase):
         return np.ascontiguousarray(self.arr[idx])
 
 
+class ImageFolderVideoReader(VideoReaderBase):
+    """A video as a directory of still images (one per frame, sorted by file name).  next() decodes the requested frames with PIL on
+    `num_threads` workers (decode and resize release the GIL) and resizes them to vr.height x vr.width with the requested
+    interpolation — the work a codec-backed reader does, minus the container."""
+    EXT = (".jpg", ".jpeg", ".png", ".bmp", ".webp")
+
+    def __init__(self, path: str, num_threads: int = 8, num_intervals: int = 64):
+        super().__init__(path, num_threads, num_intervals)
+        self.files = sorted(os.path.join(path, f) for f in os.listdir(path) if f.lower().endswith(self.EXT))
+        if not self.files:
+            raise ValueError(f"{path!r}: no image files ({', '.join(self.EXT)})")
+        fps_file = os.path.join(path, "fps.txt")
+        self.fps = float(open(fps_file).read().strip()) if os.path.exists(fps_file) else 2.0
+        from PIL import Image
+        with Image.open(self.files[0]) as im:
+            self.src_w, self.src_h = im.size
+        self._pool = None
+
+    def __len__(self): return len(self.files)
+    def get_fps(self): return self.fps
+
+    def _one(self, out, j, i, H, W):
+        from PIL import Image
+        flt = {"LANCZOS": Image.LANCZOS, "BICUBIC": Image.BICUBIC, "BILINEAR": Image.BILINEAR, "NEAREST": Image.NEAREST}.get(
+            str(self.interpolation).upper(), Image.LANCZOS)
+        with Image.open(self.files[int(i)]) as im:
+            im = im.convert("RGB")
+            if im.size != (W, H):
+                im = im.resize((W, H), flt)
+            out[j] = np.asarray(im).transpose(2, 0, 1)
+
+    def _frames(self, idx):
+        H, W = self.height or self.src_h, self.width or self.src_w
+        out = np.empty((len(idx), 3, H, W), dtype=np.uint8)
+        if self.num_threads > 1 and len(idx) > 1:
+            if self._pool is None:
+                from concurrent.futures import ThreadPoolExecutor
+                self._pool = ThreadPoolExecutor(max_workers=self.num_threads)
+            list(self._pool.map(lambda ji: self._one(out, ji[0], ji[1], H, W), enumerate(idx)))
+        else:
+            for j, i in enumerate(idx):
+                self._one(out, j, i, H, W)
+        return out
+
+
 def open_video(path, num_threads: Optional[int] = None, num_intervals: Optional[int] = None) -> VideoReaderBase:
     if isinstance(path, VideoReaderBase):
         return path
@@ -167,8 +215,11 @@ def open_video(path, num_threads: Optional[int] = None, num_intervals: Optional[
         return SyntheticVideoReader(p, nt, ni)
     if p.endswith((".npy", ".pt")):
         return ArrayVideoReader(p, nt, ni)
-    raise ValueError(f"cannot open {p!r}: this build has no video codec (no FFmpeg in the image); use synthetic://... or a "
-                     f".npy/.pt file of uint8 [F,3,H,W] frames, or pass a reader object with the InterleavedVideoReader contract")
+    if os.path.isdir(p):
+        return ImageFolderVideoReader(p, nt, ni)
+    raise ValueError(f"cannot open {p!r}: this build has no video codec (no FFmpeg in the image); use synthetic://..., a "
+                     f".npy/.pt file of uint8 [F,3,H,W] frames, a directory of frame images, or pass a reader object with the "
+                     f"InterleavedVideoReader contract")
 
 
 def smart_nframes(total_frames: int, video_fps: float, nframes: Optional[int] = None, fps: Optional[float] = None,

@@ -711,3 +711,33 @@ def test_consumer_failure_does_not_leave_a_producer_thread_behind():
     while time.time() < deadline and any(isinstance(t, _Producer) and t.is_alive() for t in threading.enumerate()):
         time.sleep(0.05)
     assert not any(isinstance(t, _Producer) and t.is_alive() for t in threading.enumerate() if t.ident not in before)
+
+
+def test_image_folder_reader_decodes_and_runs_end_to_end(tmp_path):
+    """A video as a directory of JPEG frames (a real decode workload without FFmpeg): the reader decodes + LANCZOS-resizes on worker
+    threads, any thread count gives the same pixels, and LVU.generate runs on it (planned from the images' own size)."""
+    from PIL import Image
+    import lvu
+    from quickvideo_amd.frames import ImageFolderVideoReader, open_video
+    from quickvideo_amd.lvu import load_native_model
+    rs = np.random.RandomState(0)
+    base = rs.randint(0, 256, (120, 180, 3), dtype=np.uint8)
+    for i in range(24):
+        Image.fromarray(np.roll(base, 5 * i, axis=1)).save(tmp_path / f"frame_{i:05d}.jpg", quality=90)
+    (tmp_path / "fps.txt").write_text("4.0")
+    r = open_video(str(tmp_path), num_threads=1)
+    assert isinstance(r, ImageFolderVideoReader) and len(r) == 24 and r.get_fps() == 4.0 and (r.src_h, r.src_w) == (120, 180)
+    r.height, r.width, r.frame_iter = 56, 84, 4
+    r.process(np.arange(0, 24, 3))
+    a = torch.cat([next(r), next(r)])
+    r4 = open_video(str(tmp_path), num_threads=4)
+    r4.height, r4.width, r4.frame_iter = 56, 84, 8
+    r4.process(np.arange(0, 24, 3))
+    assert torch.equal(next(r4), a) and a.shape == (8, 3, 56, 84)
+    want = np.asarray(Image.open(tmp_path / "frame_00003.jpg").convert("RGB").resize((84, 56), Image.LANCZOS)).transpose(2, 0, 1)
+    assert np.array_equal(a[1].numpy(), want)
+    m = load_native_model("synthetic:tiny", device="cpu")
+    obj = lvu.LVU(lvu.LVUConfig("synthetic:tiny", top_p=0.5, video_group_size=4, num_frames=8), model=m)
+    obj._ops = OracleOps()
+    out = obj.generate("What moves?", str(tmp_path), max_new_tokens=2, eos_token_id=None)
+    assert len(out) == 1 and obj._pipeline.last_timings.groups == 2
