@@ -8,7 +8,6 @@ import numpy as np
 import pytest
 import torch
 
-from oracle import qp_oracle as O
 from tests.oracle_ops import OracleOps
 
 # the chat template shipped with the Qwen2-VL / Qwen2.5-VL checkpoints (chat_template.json [3P]); data, not code of the reference
