@@ -680,6 +680,7 @@ FIRST_TOKEN_ON_RECORD = {
     "cfg3": ([1429], "profiles/r2s_cfg3_lean_bench.json, r1_*"), "cfg4s": ([8854], "profiles/r2s_cfg4s_lean_bench.json, r1_*"),
     "cfg4": ([121400, 6011], "profiles/r2[a-x]_cfg4_1hour_*_bench.json (both tokens occur, also between two runs on one box)"),
     "cfg5": ([93110], "profiles/r2s_cfg5_lean_bench.json, r1_final2_cfg5_bench.json, r1_s6_cfg5_72b_1gpu_bench.json"),
+    "cfg4x2": ([138354], "profiles/r2j_cfg4x2_2hour_lean_bench.json, r3_cfg4x2_2hour_lean_bench.json"),
 }
 
 
