@@ -166,6 +166,7 @@ int qp_launch_linear_tune(qp_ctx* ctx, const void* x, const void* const* ws_list
   if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return qp_fail(QP_ERR_HIP, "qp_linear_tune: hipEventCreate");
   float best = 1e30f;
   int best_i = -1;
+  std::vector<float> t_ms(p.cands.size(), -1.f);
   for (int c = 0; c < (int)p.cands.size(); ++c) {
     if (p.cands[c].workspaceSize > workspace_bytes) continue;
     bool ok = true;
@@ -178,8 +179,14 @@ int qp_launch_linear_tune(qp_ctx* ctx, const void* x, const void* const* ws_list
     (void)hipEventRecord(e1, s);
     if (hipEventSynchronize(e1) != hipSuccess) ok = false;
     float ms = 0.f;
-    if (ok && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && ms < best) { best = ms; best_i = c; }
+    if (ok && hipEventElapsedTime(&ms, e0, e1) == hipSuccess) { t_ms[c] = ms; if (ms < best) { best = ms; best_i = c; } }
   }
+  // Two candidates within timing noise of each other would otherwise win on alternate runs, and a different algorithm is a different
+  // fp32 accumulation order (after 450 groups x 28 layers the first generated token of the 1-hour benchmark flipped between two values
+  // from run to run).  Take the LOWEST-INDEX candidate within 2 % of the fastest: the choice only moves when a candidate sits on that
+  // boundary, at a cost of at most 2 % on one projection.
+  for (int c = 0; c < best_i; ++c)
+    if (t_ms[c] > 0.f && t_ms[c] <= 1.02f * best) { best_i = c; break; }
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
   if (best_i < 0) return qp_fail(QP_ERR_HIP, "qp_linear_tune: no candidate ran");
   p.algo = p.cands[best_i].algo;
