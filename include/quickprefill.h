@@ -134,7 +134,7 @@ int qp_select_k_smallest(qp_ctx* ctx, const float* head_sumsq, int n_heads_total
                          int32_t* kept_idx_out, uint16_t* norm_bits_out, int prune_mode, void* workspace,
                          size_t workspace_bytes, void* stream);
 
-/* The same select on ready-made 16-bit sort keys (uint16 [n]: what qp_rope_append_keys / qp_norm_keys / qp_query_scores emit — bf16
+/* The same select (utils.py:55-57 / 133-136: argsort of the scores, first k; :190-194 the mask) on ready-made 16-bit sort keys (uint16 [n]: what qp_rope_append_keys / qp_norm_keys / qp_query_scores emit — bf16
  * norm patterns, complemented where "largest" is wanted): the k smallest keys, ties -> lowest index, ascending index list.  Any n
  * (keys stay in LDS up to 65536, are streamed from where they are beyond); with qp_gather_kv this is the prune step of groups
  * beyond qp_prune_keys' 8192 tokens when the keys already exist (query-score mode, fused RoPE keys). */
