@@ -450,8 +450,9 @@ class QuickPrefillEngine:
         nt = pos.shape[1]
         n = nt - m
         assert embeds.shape[0] == nt and n > 0 and nt <= self.n_max, f"group of {n}+{m} tokens exceeds max_group_tokens={self.n_max}"
-        if self.tp_on or self.sp_on or self.pp_size > 1:
-            raise NotImplementedError("query-attention-score pruning runs on one GPU (no tensor / group-token / layer-pipeline parallel form)")
+        if self.tp_on or self.sp_on:
+            raise NotImplementedError("query-attention-score pruning has no tensor / group-token parallel form (per-head bf16 score sums would "
+                                      "have to cross ranks in head order); the layer pipeline is supported")
         if cfg.enable and isinstance(cfg.prefill_prune_starting_layer, int) and cfg.prefill_prune_starting_layer >= 0:
             raise NotImplementedError("query-attention-score pruning + hidden-state pruning: the reference drops the prompt rows there")
         if n > 32768:
@@ -699,7 +700,10 @@ class QuickPrefillEngine:
                 raise ValueError("query-based top_k_predict_type: prefill_group needs the prompt embeddings (qwen25_lvu.py:684-686)")
             m = prompt_embeds.shape[0]
             assert pos.shape[1] == embeds.shape[0] + m, "positions for the group's tokens AND the appended prompt tokens are required"
-            self._forward_segment_query(torch.cat([embeds, prompt_embeds], 0), pos, m)
+            # layer pipeline: the n + m rows (group + appended prompt) travel from stage to stage like any segment
+            x, _ = self._pp_in(torch.cat([embeds, prompt_embeds], 0), pos.shape[1], prune=False)
+            h = self._forward_segment_query(x, pos, m)
+            self._pp_out(h)
             self.seq_pos += embeds.shape[0]
             return
         x, rows = self._pp_in(embeds, pos.shape[1], prune=True)

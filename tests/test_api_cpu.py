@@ -383,6 +383,66 @@ def test_layer_pipeline_gloo(world, pps):
                 assert (a is None) == (b is None) and (a is None or np.array_equal(a, b))
 
 
+def _pp_query_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from quickvideo_amd.engine import QuickPrefillEngine
+    from quickvideo_amd.lvu_config import LVUConfig
+    from quickvideo_amd.spec import TextSpec
+    from quickvideo_amd.weights import DecoderWeights, pp_layer_split
+    L = 4
+    dims = dict(hidden=256, n_heads=4, n_kv_heads=2, head_dim=128, intermediate=256, n_layers=L, vocab=128)
+    so, spec = O.TextSpec(**dims), TextSpec(**dims)
+    w = {k: v.to(torch.bfloat16) for k, v in O.synthetic_text_weights(so, seed=7, norm_jitter=0.1).items()}
+    rs = np.random.RandomState(5)
+    groups, m = [33, 40, 29], 9
+    T = sum(groups) + m
+    embeds = torch.from_numpy(rs.standard_normal((T, 256)).astype(np.float32) * 0.5).to(torch.bfloat16)
+    pos = torch.from_numpy(np.tile(np.arange(T, dtype=np.int64), (3, 1)))
+    cfg = LVUConfig("x", top_p=0.5, video_group_size=4, top_k_predict_type="query_attention_weights")
+
+    def run(eng):
+        eng.kept_trace = []
+        st = 0
+        for n in groups:
+            eng.prefill_group(embeds[st:st + n], pos[:, st:st + n + m], prompt_embeds=embeds[-m:]); st += n
+        return eng.prefill_tail(embeds[st:], pos[:, st:])
+
+    l0, l1 = pp_layer_split(L, world, rank)
+    stage = QuickPrefillEngine(DecoderWeights.from_named(spec, w, "cpu", layer_range=(l0, l1)), cfg, capacity=T + 8, max_group_tokens=max(groups) + m,
+                               device="cpu", ops=OracleOps(), pp_group=dist.group.WORLD, pp_rank=rank, pp_size=world)
+    logits = run(stage)
+    ret[f"len{rank}"] = list(stage.arena.len)
+    ret[f"kept{rank}"] = [None if k is None else k.numpy().copy() for _, k in stage.kept_trace]
+    if rank == world - 1:
+        ret["logits"] = logits.numpy()
+    if rank == 0:
+        full = QuickPrefillEngine(DecoderWeights.from_named(spec, w, "cpu"), cfg, capacity=T + 8, max_group_tokens=max(groups) + m, device="cpu",
+                                  ops=OracleOps())
+        ret["ref_logits"], ret["ref_len"] = run(full).numpy(), list(full.arena.len)
+        ret["ref_kept"] = [None if k is None else k.numpy().copy() for _, k in full.kept_trace]
+        ref = O.group_prefill(w, so, embeds, pos.numpy(), groups, O.PruneCfg(top_p=0.5, top_k_predict_type="query_attention_weights"))
+        ret["oracle_len"], ret["oracle_logits"] = ref["cache_len"], ref["logits"].numpy()
+    dist.destroy_process_group()
+
+
+def test_layer_pipeline_with_query_score_pruning_gloo():
+    """Query-attention-score pruning (prompt-appended groups, lvu_cache.py:97-117) across two layer-pipeline stages: the n + m rows travel
+    between the stages; cache lengths, kept lists and logits equal the single-process engine's, which equals the oracle."""
+    world = 2
+    ret = mp.Manager().dict()
+    mp.spawn(_pp_query_worker, args=(world, 36900 + os.getpid() % 2000, ret), nprocs=world, join=True)
+    assert ret["len0"] + ret["len1"] == ret["ref_len"] == ret["oracle_len"]
+    assert np.array_equal(ret["logits"], ret["ref_logits"]) and np.array_equal(ret["logits"], ret["oracle_logits"])
+    L, segs = 4, 4
+    for s in range(segs):
+        for l in range(L):
+            a = ret["kept0"][s * 2 + l] if l < 2 else ret["kept1"][s * 2 + l - 2]
+            b = ret["ref_kept"][s * L + l]
+            assert (a is None) == (b is None) and (a is None or np.array_equal(a, b))
+
+
 # ---------------------------------------------------------------- layer pipeline of group-token parallel stages (pp2 x sp2)
 def _ppsp_worker(rank, world, port, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
