@@ -447,7 +447,18 @@ __global__ __launch_bounds__(kThreads) void prune_tail_inplace_kernel(const uint
 #pragma unroll
     for (int h = 0; h < 8; ++h) if (h < hkv) { rk[h] = ks[h * hs16]; rv[h] = vs[h * hs16]; }
   }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the rows are IN the registers before anyone may overwrite them
+  // The rows must be IN the registers before anyone may overwrite them.  Each loaded vector is made an operand of an (empty) volatile
+  // asm: the data dependence makes the compiler wait for the loads right here, and the volatile flag store below cannot move above it.
+  // (A `"memory"` clobber would do the same but forces rk / rv into scratch memory: every row then went to HBM-backed scratch and
+  // back — rocprofv3 FETCH_SIZE / WRITE_SIZE read exactly 2x the algorithmic bytes.)
+  if (have) {
+#pragma unroll
+    for (int h = 0; h < 8; ++h)
+      if (h < hkv) {
+        asm volatile("" : "+v"(rk[h].x), "+v"(rk[h].y), "+v"(rk[h].z), "+v"(rk[h].w));
+        asm volatile("" : "+v"(rv[h].x), "+v"(rv[h].y), "+v"(rv[h].z), "+v"(rv[h].w));
+      }
+  }
   __syncthreads();
   // (3) publish, (4) wait for the lower slices whose source rows [base, base+nk) covers.  RELAXED device-scope atomics: the flag
   // carries no data (it says "my loads have retired", which the s_waitcnt above established locally), so neither side needs the L2
@@ -458,7 +469,6 @@ __global__ __launch_bounds__(kThreads) void prune_tail_inplace_kernel(const uint
     if (dep < slice && !(dbg & 2))                       // (dbg: developer probe of the wait's cost, results then UNSAFE)
       while (__hip_atomic_load(&flags[dep], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {}
   }
-  asm volatile("" ::: "memory");
   __syncthreads();
   // (5) store
   if (have) {
