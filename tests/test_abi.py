@@ -113,3 +113,28 @@ def test_header_is_plain_c_and_library_has_no_torch_dependency(tmp_path):
     libs = re.findall(r"NEEDED.*\[(.*?)\]", needed)
     assert libs and not [l for l in libs if re.search(r"torch|c10|python", l)], libs
     build_c_caller(str(tmp_path / "abi_c"))                     # compiles and links here; runs on the GPU box (tests/test_gpu_ops.py)
+
+
+def test_hbm_bound_kernels_use_no_scratch(tmp_path):
+    """The byte-moving kernels of the path (prune / select / gather, RoPE + append, RMSNorm / SwiGLU glue) must keep their rows in
+    registers: scratch memory is HBM-backed, so a kernel that parks staged rows there moves every byte twice — exactly what the
+    first in-place prune did until rocprofv3's FETCH_SIZE / WRITE_SIZE showed 2.0x the algorithmic traffic.  Cross-compiles the
+    three files to gfx950 assembly (no GPU needed) and reads each kernel's private segment size and spill counts."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    csrc = os.path.join(ROOT, "quickvideo_amd", "csrc")
+    seen = 0
+    for name in ("qp_prune", "qp_rope", "qp_elementwise"):
+        out = tmp_path / f"{name}.s"
+        subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", str(out),
+                        os.path.join(csrc, f"{name}.hip")], check=True, capture_output=True, timeout=600)
+        text = out.read_text()
+        for m in re.finditer(r"\.name:\s+(\S+)\n(?:.*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)\n(?:.*\n)*?\s+\.vgpr_spill_count:\s+(\d+)", text):
+            kernel, private, spills = m.group(1), int(m.group(2)), int(m.group(3))
+            assert private == 0 and spills == 0, f"{name}: {kernel} uses {private} B of scratch per lane ({spills} spilled VGPRs)"
+            seen += 1
+    assert seen >= 15
