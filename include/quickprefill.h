@@ -185,11 +185,17 @@ int qp_query_scores(qp_ctx* ctx, const void* q_prompt, const void* k_group, int6
  * 16-token slice finds the threshold by a radix select in LDS, STAGES the K/V rows of its kept tokens in registers (<= 256 B per
  * lane, <= 64 KB per workgroup), signals "rows loaded", waits for the (at most two, always LOWER) slices whose source rows its
  * destination rows overlap, and stores to [past_len, past_len+k) — the compaction never bounces through HBM scratch.  The wait is
- * deadlock-free because it only points downwards and the whole grid (<= 512 workgroups) fits on the device at once, which the
- * library checks with the occupancy API (keep at most two such calls in flight at once on a device — e.g. on two streams — so that the
- * grids together still fit).  The workspace then only holds the keys and the flags (2.25 bytes per token).  Larger
- * groups use the round-1 form (sums -> select -> gather into the workspace -> copy back). */
+ * deadlock-free because it only points downwards, the whole grid (<= 512 workgroups) fits at once on the CUs the stream may use
+ * (occupancy API x the stream's CU mask; otherwise the staged form runs) and the context keeps at most ONE in-place grid in flight: a
+ * call on a different stream than the previous one is ordered behind it on the device (hipStreamWaitEvent; no host wait).  Callers
+ * may therefore use any number of streams.  (Inside a stream capture the library records no events: the captured stream orders its
+ * own nodes.)  The in-place workspace only holds the keys and the flags (2.25 bytes per token).  Larger groups use the round-1 form
+ * (sums -> select -> gather into the workspace -> copy back), which needs room for the kept rows.
+ *   qp_prune_workspace_bytes(...)            an upper bound, sufficient for either form on any device / stream (no context needed)
+ *   qp_prune_tail_workspace_bytes(ctx, ...)  the exact size for this context and stream (NULL = an unmasked stream): the small
+ *                                            in-place figure only when qp_prune_tail will take that form there */
 size_t qp_prune_workspace_bytes(int64_t n, int64_t k, int n_kv_heads, int head_dim);
+size_t qp_prune_tail_workspace_bytes(const qp_ctx* ctx, int64_t n, int64_t k, int n_kv_heads, int head_dim, void* stream);
 int qp_prune_tail(qp_ctx* ctx, void* k_cache, void* v_cache, int64_t head_stride, int64_t past_len, int64_t n,
                   int64_t k, int n_kv_heads, int head_dim, int32_t* kept_idx_out, int prune_mode, void* workspace,
                   size_t workspace_bytes, void* stream);

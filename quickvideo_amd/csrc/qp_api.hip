@@ -56,6 +56,7 @@ int qp_create(qp_ctx** out, int device) {
 
 void qp_destroy(qp_ctx* ctx) {
   if (!ctx) return;
+  if (ctx->tail_ev) (void)hipEventDestroy(ctx->tail_ev);
   qp_lt_destroy(ctx->lt);                      // hipBLASLt handles / plans of this context
   delete ctx;
 }
@@ -297,18 +298,43 @@ int qp_prune_staged(qp_ctx* ctx, const float* head_sumsq, int n_heads_total, int
 // the workspace -> copy back;  workspace = [head_sumsq fp32 Hkv*n | pad][K rows Hkv*k*D bf16 | pad][V rows | pad].
 static size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 static inline bool tail_inplace_ok(int64_t n, int n_kv_heads) {
-  static const bool staged = getenv("QP_PRUNE_TAIL_STAGED") != nullptr;    // developer A/B switch (tools/bench_prune_tail.py): round-1 form
-  return !staged && n <= 8192 && n_kv_heads <= 8;
+#ifdef QP_EXPERIMENTS
+  static const bool staged = getenv("QP_PRUNE_TAIL_STAGED") != nullptr;    // `make EXPERIMENTS=1` only: A/B switch to the round-1 form (tools/bench_prune_tail.py)
+  if (staged) return false;
+#endif
+  return n <= 8192 && n_kv_heads <= 8;
 }
 static inline int64_t tail_slices(int64_t n) { return (n + 15) / 16; }
 
 static size_t staged_tail_bytes(int64_t n, int64_t k, int n_kv_heads, int head_dim) {
   return align256((size_t)n_kv_heads * n * 4) + 2 * align256((size_t)n_kv_heads * k * head_dim * 2) + 256;
 }
+static size_t inplace_tail_bytes(int64_t n) { return align256((size_t)n * 2) + align256((size_t)tail_slices(n) * 4); }
 
+// CUs `s` may run on: the population count of its CU mask (hipExtStreamCreateWithCUMask / HSA_CU_MASK); the device's count when the
+// runtime reports none.  The in-place grid must fit on THESE, not on the whole device.
+static int qp_stream_cus(const qp_ctx* ctx, hipStream_t s) {
+  uint32_t mask[32] = {0};
+  if (hipExtStreamGetCUMask(s, 32, mask) != hipSuccess) { (void)hipGetLastError(); return ctx->cus; }
+  int bits = 0;
+  for (int i = 0; i < 32; ++i) bits += __builtin_popcount(mask[i]);
+  return (bits > 0 && bits < ctx->cus) ? bits : ctx->cus;
+}
+
+// Upper bound that is sufficient whatever form qp_prune_tail picks (no context: the device's capacity is unknown here).
 size_t qp_prune_workspace_bytes(int64_t n, int64_t k, int n_kv_heads, int head_dim) {
   if (n <= 0 || k <= 0 || n_kv_heads <= 0 || head_dim <= 0) return 256;
-  if (tail_inplace_ok(n, n_kv_heads)) return align256((size_t)n * 2) + align256((size_t)tail_slices(n) * 4);
+  const size_t a = staged_tail_bytes(n, k, n_kv_heads, head_dim), b = inplace_tail_bytes(n);
+  return a > b ? a : b;
+}
+
+// Exact size for THIS context on `stream` (NULL = an unmasked stream): the small in-place figure (2.25 B per token) only when
+// qp_prune_tail will take the in-place form there — the same decision, from the same inputs.
+size_t qp_prune_tail_workspace_bytes(const qp_ctx* ctx, int64_t n, int64_t k, int n_kv_heads, int head_dim, void* stream) {
+  if (n <= 0 || k <= 0 || n_kv_heads <= 0 || head_dim <= 0) return 256;
+  if (ctx && tail_inplace_ok(n, n_kv_heads) &&
+      tail_slices(n) <= qp_prune_tail_inplace_capacity(stream ? qp_stream_cus(ctx, (hipStream_t)stream) : ctx->cus))
+    return inplace_tail_bytes(n);
   return staged_tail_bytes(n, k, n_kv_heads, head_dim);
 }
 
@@ -322,25 +348,46 @@ int qp_prune_tail(qp_ctx* ctx, void* k_cache, void* v_cache, int64_t head_stride
              "qp_prune_tail: need past_len >= 0 and 0 < k <= n (k=%lld n=%lld)", (long long)k, (long long)n);
   QP_REQUIRE(n <= 65536, QP_ERR_UNSUPPORTED, "qp_prune_tail: n=%lld > 65536", (long long)n);
   QP_REQUIRE(head_stride % 8 == 0 && head_stride >= (past_len + n) * head_dim, QP_ERR_INVALID, "qp_prune_tail: head stride too small");
-  // in place only when the whole grid of the second launch is resident at once (see qp_prune.hip: that is what makes its
-  // slice-ordered wait deadlock-free); 512 workgroups at most, an MI355X holds 1024
-  const bool inplace = tail_inplace_ok(n, n_kv_heads) && tail_slices(n) <= qp_prune_tail_inplace_capacity(ctx->cus);
-  const size_t need = inplace ? qp_prune_workspace_bytes(n, k, n_kv_heads, head_dim) : staged_tail_bytes(n, k, n_kv_heads, head_dim);
-  QP_REQUIRE(workspace_bytes >= need, QP_ERR_WORKSPACE, "qp_prune_tail: workspace %zu < %zu bytes%s", workspace_bytes, need,
-             (!inplace && tail_inplace_ok(n, n_kv_heads)) ? " (this device cannot hold the in-place grid at once: the staged form needs the larger scratch)" : "");
-  QP_REQUIRE(aligned16(k_cache) && aligned16(v_cache) && aligned16(workspace), QP_ERR_INVALID, "qp_prune_tail: alignment");
   hipStream_t s = (hipStream_t)stream;
+  // in place only when the whole grid of the second launch can be resident at once on the CUs this stream may use (see qp_prune.hip:
+  // that, and one such grid in flight per context, is what makes its slice-ordered wait deadlock-free); 512 workgroups at most, an
+  // unmasked MI355X holds 1024
+  const bool inplace = tail_inplace_ok(n, n_kv_heads) && tail_slices(n) <= qp_prune_tail_inplace_capacity(qp_stream_cus(ctx, s));
+  const size_t need = inplace ? inplace_tail_bytes(n) : staged_tail_bytes(n, k, n_kv_heads, head_dim);
+  QP_REQUIRE(workspace_bytes >= need, QP_ERR_WORKSPACE, "qp_prune_tail: workspace %zu < %zu bytes%s", workspace_bytes, need,
+             (!inplace && tail_inplace_ok(n, n_kv_heads)) ? " (this stream's CUs cannot hold the in-place grid at once: the staged form needs the larger "
+             "scratch — size it with qp_prune_workspace_bytes, or qp_prune_tail_workspace_bytes for this stream)" : "");
+  QP_REQUIRE(aligned16(k_cache) && aligned16(v_cache) && aligned16(workspace), QP_ERR_INVALID, "qp_prune_tail: alignment");
   unsigned char* ws = (unsigned char*)workspace;
   const int largest = qp_mode_largest(prune_mode);
   const void* scored = qp_mode_values(prune_mode) ? v_cache : k_cache;
   if (inplace) {
     uint16_t* keys = (uint16_t*)ws;
     int* sync_words = (int*)(ws + align256((size_t)n * 2));
+    // ONE in-place grid in flight per context: a call on another stream than the previous one waits (on the device) for that one's
+    // event.  Inside a stream capture the event dance is skipped — the captured stream orders its own nodes; a caller that replays
+    // several such graphs at once owns that ordering.
+    std::lock_guard<std::mutex> guard(ctx->tail_mu);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusActive;
+    if (!capturing) {
+      if (!ctx->tail_ev && hipEventCreateWithFlags(&ctx->tail_ev, hipEventDisableTiming) != hipSuccess)
+        return qp_fail(QP_ERR_HIP, "qp_prune_tail: hipEventCreate failed");
+      if (ctx->tail_pending && ctx->tail_stream != s && hipStreamWaitEvent(s, ctx->tail_ev, 0) != hipSuccess)
+        return qp_fail(QP_ERR_HIP, "qp_prune_tail: hipStreamWaitEvent failed");
+    }
     // launch 1: 16-bit norm key of every tail token (all KV heads of a token in one 16-lane group) + clears the sync words
     int rc = qp_launch_tail_keys(scored, head_stride, past_len, n, n_kv_heads, keys, largest, sync_words, (int)tail_slices(n), s);
     if (rc) return rc;
     // launch 2: radix select per 16-token slice, kept rows staged in registers, slice-ordered hand-shake, stores to [past, past+k)
-    return qp_launch_prune_tail_inplace(keys, n, k, k_cache, v_cache, head_stride, past_len, n_kv_heads, kept_idx_out, sync_words, s);
+    rc = qp_launch_prune_tail_inplace(keys, n, k, k_cache, v_cache, head_stride, past_len, n_kv_heads, kept_idx_out, sync_words, s);
+    if (rc) return rc;
+    if (!capturing) {
+      if (hipEventRecord(ctx->tail_ev, s) != hipSuccess) return qp_fail(QP_ERR_HIP, "qp_prune_tail: hipEventRecord failed");
+      ctx->tail_stream = s;
+      ctx->tail_pending = true;
+    }
+    return QP_OK;
   }
   float* sumsq = (float*)ws;
   unsigned char* kt = ws + align256((size_t)n_kv_heads * n * 4);

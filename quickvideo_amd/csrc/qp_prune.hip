@@ -336,13 +336,14 @@ int qp_launch_prune_keys(const uint16_t* norm_keys, int64_t n, int64_t k, const 
 //                             workgroup (1) loads the K/V rows of its kept tokens into registers (<= 2*hkv*16 B per lane),
 //                             (2) publishes flag[slice] = 1 ("my loads have retired"), (3) waits for the flags of the (<= 2)
 //                             LOWER slices whose rows it is about to overwrite, (4) stores.
-//   Why the wait cannot deadlock: a slice waits only for lower slices and never the other way round (no cycle), and the launcher
-//   only uses this kernel when the WHOLE grid fits on the device at once (grid <= CUs x workgroups per CU from the occupancy
-//   API; n <= 8192 needs <= 512 workgroups, an MI355X holds 1024) — so waiting workgroups can never occupy every slot a not yet
-//   dispatched lower slice needs; workgroups of OTHER kernels in those slots finish on their own.  (The same argument a
-//   cooperative launch makes; verified with a second stream keeping all CUs busy, tests/test_gpu_ops.py.)  An atomic ticket
-//   (slice = start order) would drop even that condition, but 360 same-address device atomics serialise at ~25 ns each: +3-4 us per
-//   launch (measured, profiles/r3_prune_tail_old_vs_new.json), on a 10 us kernel.
+//   Why the wait cannot deadlock: a slice waits only for lower slices and never the other way round (no cycle), and a not yet
+//   dispatched lower slice always finds a slot, because (a) the launcher only uses this kernel when the WHOLE grid fits at once on
+//   the CUs THE STREAM MAY USE (its CU mask, hipExtStreamGetCUMask; x workgroups per CU from the occupancy API: n <= 8192 needs
+//   <= 512 workgroups, an unmasked MI355X holds 1024), and (b) the context keeps at most ONE such grid in flight — a call on another
+//   stream is ordered behind the previous call's event (qp_api.hip: qp_prune_tail) — so the spinning workgroups of other in-place
+//   grids can never fill the slots; workgroups of every OTHER kernel finish on their own.  Where (a) fails the staged form runs.
+//   (An atomic ticket — slice = start order — would need neither condition, but 360 same-address device atomics serialise at
+//   ~25 ns each: +3-4 us per launch, measured in profiles/r3_prune_tail_old_vs_new.json, on a 10 us kernel.)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void tail_keys_kernel(const uint4* __restrict__ rows, int64_t hs16, int64_t row0, int n, int hkv,
                                                         uint16_t* __restrict__ norm_keys, int largest, int* __restrict__ sync_words,
@@ -380,7 +381,7 @@ int qp_launch_tail_keys(const void* rows, int64_t head_stride, int64_t row0, int
 template <int kThreads>
 __global__ __launch_bounds__(kThreads) void prune_tail_inplace_kernel(const uint16_t* __restrict__ keys_g, int n, int k, uint4* k_cache,
                                                                       uint4* v_cache, int64_t hs16, int64_t past, int hkv,
-                                                                      int32_t* __restrict__ kept, int* sync_words, int dbg) {
+                                                                      int32_t* __restrict__ kept, int* sync_words) {
   constexpr int QP_TAIL_TS = kThreads / 16;
   constexpr int kWaves = kThreads / 64;
   __shared__ __attribute__((aligned(16))) uint16_t keys[QP_PRUNE_MAX_N];
@@ -466,7 +467,7 @@ __global__ __launch_bounds__(kThreads) void prune_tail_inplace_kernel(const uint
   if (tid == 0) __hip_atomic_store(&flags[slice], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (nk > 0 && tid < 2) {
     const int dep = tid == 0 ? base / QP_TAIL_TS : (base + nk - 1) / QP_TAIL_TS;
-    if (dep < slice && !(dbg & 2))                       // (dbg: developer probe of the wait's cost, results then UNSAFE)
+    if (dep < slice)
       while (__hip_atomic_load(&flags[dep], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {}
   }
   __syncthreads();
@@ -493,9 +494,8 @@ int qp_prune_tail_inplace_capacity(int cus) {
 
 int qp_launch_prune_tail_inplace(const uint16_t* norm_keys, int64_t n, int64_t k, void* k_cache, void* v_cache, int64_t head_stride,
                                  int64_t past_len, int hkv, int32_t* kept, int* sync_words, hipStream_t s) {
-  static const int dbg = getenv("QP_TAIL_DBG") ? atoi(getenv("QP_TAIL_DBG")) : 0;          // developer probe (UNSAFE results): 2 = no wait
   prune_tail_inplace_kernel<256><<<(unsigned)((n + 15) / 16), 256, 0, s>>>(norm_keys, (int)n, (int)k, (uint4*)k_cache, (uint4*)v_cache,
-                                                                         head_stride / 8, past_len, hkv, kept, sync_words, dbg);
+                                                                         head_stride / 8, past_len, hkv, kept, sync_words);
   return qp_check_launch("prune_tail_inplace");
 }
 

@@ -26,6 +26,21 @@ from .lvu_config import LVUConfig, NORM_PRUNE_MODES, QUERY_PRUNE_MODES, effectiv
 from .weights import DecoderWeights
 
 
+_TUNE_FAILURES: dict = {}       # (projection, rows, weight shape, bias) -> message: every shape hipBLASLt plan selection failed for
+
+
+def _tune_failed(shape_key, exc) -> None:
+    """qp_linear_tune threw for this projection shape: the engine stays on torch.mm there (a correct but possibly slower GEMM — a
+    broken plan path would otherwise cost ~5 % of the pass and nobody would know).  Logged once per shape on stderr and kept in
+    `engine._TUNE_FAILURES` (bench.py prints the table in its line)."""
+    if shape_key in _TUNE_FAILURES:
+        return
+    _TUNE_FAILURES[shape_key] = f"{type(exc).__name__}: {exc}"
+    import sys
+    print(f"[quickprefill] hipBLASLt plan selection failed for {shape_key}: {type(exc).__name__}: {exc} — staying on torch.mm for this shape",
+          file=sys.stderr, flush=True)
+
+
 def sp_row_ranges(n: int, world: int, rank: int):
     """Group-token parallel row assignment: the n rows are cut into 2*world chunks of ceil(n / (2*world)) rows; rank r owns
     chunks r and 2*world-1-r, which balances the causal attention work.  Returns ((a0, a1), (b0, b1)), possibly empty ranges."""
@@ -222,8 +237,9 @@ class QuickPrefillEngine:
             try:
                 self.ops.linear_tune(x, ws, bias, out, self.ops.ACT_NONE)
                 self._lt_tuned[lk] = True
-            except Exception:                         # no usable candidate: stay on torch.mm for this shape
+            except Exception as e:                    # no usable candidate: stay on torch.mm for this shape — and SAY so, once per shape
                 self._lt_tuned[lk] = False
+                _tune_failed(lk, e)
         if not self._lt_tuned[lk]:
             return False
         self.ops.linear_act(x, w, bias, out, self.ops.ACT_NONE)
@@ -258,8 +274,8 @@ class QuickPrefillEngine:
                         ms = self._time(lambda: self.ops.linear_act(x, w, bias, out, self.ops.ACT_NONE))
                         if ms < best[0] and ms < 0.97 * whole:
                             best = (ms, "lt")
-                    except Exception:                 # no usable candidate for this shape: keep torch.mm
-                        pass
+                    except Exception as e:            # no usable candidate for this shape: keep torch.mm — and SAY so, once per shape
+                        _tune_failed(pk, e)
                 plan = best[1]
                 if os.environ.get("QP_ENGINE_DEBUG"):
                     print(f"[engine] {key} n={n}: whole {whole * 1e3:.0f} us -> {plan} {best[0] * 1e3:.0f} us", flush=True)

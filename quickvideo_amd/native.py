@@ -56,6 +56,7 @@ SIGNATURES = {
     "qp_gather_kv": (_i32, [_vp, _vp, _vp, _i64, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _i64, _vp]),
     "qp_prune_staged": (_i32, [_vp, _vp, _i32, _i64, _i64, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _i64, _vp, _vp, _i32, _vp]),
     "qp_prune_workspace_bytes": (_sz, [_i64, _i64, _i32, _i32]),
+    "qp_prune_tail_workspace_bytes": (_sz, [_vp, _i64, _i64, _i32, _i32, _vp]),
     "qp_prune_tail": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _vp, _i32, _vp, _sz, _vp]),
     "qp_gather_rows": (_i32, [_vp, _vp, _vp, _i64, _i64, _vp, _vp]),
     "qp_sp_unpack": (_i32, [_vp, _vp, _i32, _i32, _i64, _i32, _i64, _vp, _vp, _i64, _vp, _vp]),
@@ -253,7 +254,12 @@ class QuickPrefillOps:
                                              dst_row0, kept_idx.data_ptr(), _ptr(norm_bits), int(mode), self._stream()))
 
     def prune_workspace_bytes(self, n, k, n_kv, head_dim) -> int:
+        """Upper bound: enough for either form of qp_prune_tail on any device / stream."""
         return int(self.lib.qp_prune_workspace_bytes(n, k, n_kv, head_dim))
+
+    def prune_tail_workspace_bytes(self, n, k, n_kv, head_dim) -> int:
+        """Exact size on this context and the current stream (the 2.25 B/token in-place figure only when that form will run)."""
+        return int(self.lib.qp_prune_tail_workspace_bytes(self.ctx, n, k, n_kv, head_dim, self._stream()))
 
     def prune_tail(self, k_cache, v_cache, head_stride, past_len, n, k, n_kv, head_dim, kept_idx, workspace, mode: int = 0):
         self._check(self.lib.qp_prune_tail(self.ctx, k_cache.data_ptr(), v_cache.data_ptr(), head_stride, past_len, n, k, n_kv,

@@ -241,7 +241,7 @@ class PrefillPipeline:
         gs = cfg.video_group_size
         plan = planner.plan_groups(nframes, gs, gh, gw, len(prompt.prefix_ids), T, vs.temporal_patch_size, vs.spatial_merge_size)
         # Qwen2.5-VL: tokens_per_second * second_per_grid_t with second_per_grid_t = temporal_patch / sampled fps
-        sample_fps = nframes / max(total / vfps, 1e-9)             # qwen-vl-utils: video_sample_fps = nframes / total_frames * video_fps
+        sample_fps = nframes / max(total, 1e-6) * vfps             # the reference's own expression and operation order (qwen25_lvu.py:243, interleaved:408)
         q25 = spec.temporal_scale < 0                                # Qwen2.5-VL: HF's float32 expression (planner.temporal_ids)
         pos, delta = planner.mrope_positions(len(prompt.prefix_ids), (nframes // vs.temporal_patch_size, gh, gw), len(prompt.tail_ids),
                                              vs.spatial_merge_size, spec.temporal_scale if not q25 else 1.0,

@@ -63,7 +63,8 @@ def test_product_never_imports_oracle():
     assert not offenders, offenders
 
 
-@pytest.mark.parametrize("src_name,kernel,min_kernels", [("qp_attn_s6.hip", "attn_fwd_kernel_s6", 4), ("qp_attn_s7.hip", "attn_fwd_kernel_s7", 2)])
+@pytest.mark.parametrize("src_name,kernel,min_kernels", [("quickvideo_amd/csrc/qp_attn_s6.hip", "attn_fwd_kernel_s6", 4),
+                                                         ("tools/experiments/qp_attn_s7.hip", "attn_fwd_kernel_s7", 2)])
 def test_pipelined_attention_kernel_does_not_spill(src_name, kernel, min_kernels):
     """attn_fwd_kernel_s6 / _s7 issue LDS reads by hand and wait for them with counted s_waitcnt statements that carry no register
     operands; a compiler spill of a fragment register between the read and its wait would store a value that has not landed
@@ -73,9 +74,9 @@ def test_pipelined_attention_kernel_does_not_spill(src_name, kernel, min_kernels
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         pytest.skip("hipcc not available")
-    src = os.path.join(ROOT, "quickvideo_amd", "csrc", src_name)
+    src = os.path.join(ROOT, src_name)
     r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "--cuda-device-only", "-S", "-o", os.devnull,
-                        "-Rpass-analysis=kernel-resource-usage", src], capture_output=True, text=True, timeout=600)
+                        "-I" + os.path.join(ROOT, "quickvideo_amd", "csrc"), "-Rpass-analysis=kernel-resource-usage", src], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     blocks = re.split(r"remark: Function Name: ", r.stderr)[1:]
     seen = 0

@@ -295,6 +295,63 @@ def test_prune_tail_inplace_under_load(ops):
     assert bad == 0, f"{bad} of 100 in-place prunes differ from the oracle"
 
 
+def test_prune_tail_inplace_many_streams_and_cu_mask(ops):
+    """the in-place launch spin-waits on lower slices, so the library — not the caller — has to keep the condition that
+    makes the wait safe.  (1) SIX streams issue in-place prunes at once (the header used to allow two): the context orders a call on a
+    new stream behind the previous call's event, so every result is exact and nothing hangs.  (2) A stream restricted to 16 CUs by a CU
+    mask cannot hold the 360-workgroup grid: the size query for THAT stream returns the staged figure, qp_prune_tail takes the staged
+    form there (and says so when handed only the in-place workspace), results exact."""
+    import ctypes
+    from quickvideo_amd.native import QuickPrefillError
+    past, n, k, hkv = 2887, 5760, 2880, 4
+    rs = np.random.RandomState(12)
+    keys = torch.from_numpy(rs.standard_normal((hkv, past + n, D)).astype(np.float32)).to(torch.bfloat16).cuda()
+    vals = torch.from_numpy(rs.standard_normal((hkv, past + n, D)).astype(np.float32)).to(torch.bfloat16).cuda()
+    ko, vo = O.torch_bf16_to_bits(keys.cpu()).copy(), O.torch_bf16_to_bits(vals.cpu()).copy()
+    ref_idx, _ = O.prune_tail(ko, vo, past, n, k)
+    want_k, want_v = torch.from_numpy(ko[:, :past + k].view(np.int16)).cuda(), torch.from_numpy(vo[:, :past + k].view(np.int16)).cuda()
+    small = ops.prune_tail_workspace_bytes(n, k, hkv, D)
+    assert small == -(-n * 2 // 256) * 256 + -(-((n + 15) // 16) * 4 // 256) * 256           # 2.25 B per token on an unmasked stream
+    assert ops.prune_workspace_bytes(n, k, hkv, D) >= small
+    streams = [torch.cuda.Stream() for _ in range(6)]
+    torch.cuda.synchronize()
+    runs = []
+    for rep in range(20):
+        for st in streams:
+            with torch.cuda.stream(st):
+                kc, vc = keys.clone(), vals.clone()
+                idx = torch.full((k,), -1, dtype=torch.int32, device="cuda")
+                ws = torch.empty(small, dtype=torch.uint8, device="cuda")
+                ops.prune_tail(kc, vc, (past + n) * D, past, n, k, hkv, D, idx, ws)
+                runs.append((kc, vc, idx, ws))
+    torch.cuda.synchronize()
+    bad = sum(int(not (torch.equal(kc[:, :past + k].view(torch.int16), want_k) and torch.equal(vc[:, :past + k].view(torch.int16), want_v)
+                       and np.array_equal(idx.cpu().numpy(), ref_idx))) for kc, vc, idx, _ in runs)
+    assert bad == 0, f"{bad} of {len(runs)} in-place prunes on six streams differ from the oracle"
+    # (2) a CU-masked stream (16 CUs of XCD-interleaved numbering): hipExtStreamCreateWithCUMask through the HIP runtime torch loaded
+    hip = ctypes.CDLL("libamdhip64.so")
+    mask = (ctypes.c_uint32 * 8)(*([0x00010001] * 8))                                      # 16 bits set
+    raw = ctypes.c_void_p()
+    assert hip.hipExtStreamCreateWithCUMask(ctypes.byref(raw), 8, mask) == 0
+    try:
+        ext = torch.cuda.ExternalStream(raw.value)
+        with torch.cuda.stream(ext):
+            need = ops.prune_tail_workspace_bytes(n, k, hkv, D)
+            assert need > small, "a 16-CU stream cannot hold 360 workgroups x 33 KB of LDS: the staged form (larger scratch) must be chosen"
+            kc, vc = keys.clone(), vals.clone()
+            idx = torch.full((k,), -1, dtype=torch.int32, device="cuda")
+            with pytest.raises(QuickPrefillError, match="staged form"):
+                ops.prune_tail(kc, vc, (past + n) * D, past, n, k, hkv, D, idx, torch.empty(small, dtype=torch.uint8, device="cuda"))
+            ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+            ops.prune_tail(kc, vc, (past + n) * D, past, n, k, hkv, D, idx, ws)
+            ext.synchronize()
+            assert torch.equal(kc[:, :past + k].view(torch.int16), want_k) and torch.equal(vc[:, :past + k].view(torch.int16), want_v)
+            assert np.array_equal(idx.cpu().numpy(), ref_idx)
+    finally:
+        torch.cuda.synchronize()
+        hip.hipStreamDestroy(raw)
+
+
 @pytest.mark.parametrize("n,k", [(1, 1), (777, 300), (8193, 4000), (20000, 19999), (65536, 100), (70001, 35000)])
 def test_select_keys_any_size(ops, n, k):
     """qp_select_keys: the select on ready-made 16-bit sort keys (what the RoPE kernel / qp_norm_keys / qp_query_scores emit), for

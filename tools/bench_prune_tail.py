@@ -1,7 +1,7 @@
 """qp_prune_tail (the public in-place seam) at the cfg2 / cfg4 / cfg5 group shapes: HIP-event time per call, back to back and
 with a GEMM between calls (cold instruction cache, like in a layer loop).  Run twice for the A/B of round 3's report:
     python tools/bench_prune_tail.py                          # round 3: norm keys + one in-place launch
-    QP_PRUNE_TAIL_STAGED=1 python tools/bench_prune_tail.py   # round 1/2: sums -> 1-workgroup select -> gather to scratch -> copy back
+    QP_PRUNE_TAIL_STAGED=1 python tools/bench_prune_tail.py   # (library built with `make EXPERIMENTS=1`) round 1/2: sums -> 1-workgroup select -> gather to scratch -> copy back
 Prints one JSON line."""
 import json
 import os
