@@ -599,10 +599,120 @@ def gen_vit_towers():
     json.dump(meta, open(os.path.join(OUT, "gv10_vit_towers.json"), "w"))
 
 
+# ---------------------------------------------------------------- GV4: frame count + frame size from the video entry
+NFRAMES_ELES = [{}, {"fps": 1}, {"fps": 2}, {"fps": 0.5}, {"fps": 4.0}, {"fps": 2, "min_frames": 16}, {"fps": 2, "max_frames": 128},
+                {"fps": 2, "min_frames": 7, "max_frames": 65}, {"fps": 1, "max_frames": 768}, {"nframes": 64}, {"nframes": 7}, {"nframes": 5},
+                {"nframes": 7200}, {"nframes": 3}, {"nframes": 1}, {"nframes": 128}, {"fps": 2, "nframes": 64}]
+NFRAMES_VIDEOS = [(4, 2.0), (37, 24.0), (64, 2.0), (257, 29.97), (1800, 30.0), (7200, 2.0), (28800, 8.0), (28416, 24.0), (86313, 23.976),
+                  (216000, 60.0), (2, 30.0), (1, 25.0)]
+SIZE_ELES = [{}, {"max_pixels": 10 ** 7}, {"max_pixels": 392 * 560}, {"max_pixels": 200 * 28 * 28}, {"max_pixels": 360 * 420},
+             {"min_pixels": 256 * 28 * 28}, {"min_pixels": 16 * 28 * 28}, {"min_pixels": 256 * 28 * 28, "max_pixels": 300 * 28 * 28},
+             {"min_pixels": 900 * 28 * 28}, {"total_pixels": 7200 * 392 * 560 // 2}, {"total_pixels": 7200 * 392 * 560 // 2 + 7200 * 14 * 28},
+             {"total_pixels": 128000 * 28 * 28 * 0.9}, {"total_pixels": 1000 * 28 * 28}, {"total_pixels": 10 ** 9, "max_pixels": 400 * 28 * 28},
+             {"resized_height": 280, "resized_width": 420}, {"resized_height": 300, "resized_width": 500, "max_pixels": 10 ** 7},
+             {"resized_height": 280}]
+SIZE_VIDEOS = [(nf, h, w) for nf in (2, 16, 64, 256, 512, 768, 7200, 14400)
+               for (h, w) in ((1080, 1920), (720, 1280), (392, 560), (480, 640), (2160, 3840), (360, 640), (240, 320), (1920, 1080), (300, 2000))]
+# (sizes that smart_resize would shrink below ONE 28-pixel patch row are left out: transformers' smart_resize floors them to 28 where
+#  qwen-vl-utils 0.0.10 returns 0 — a frame the reference cannot process either)
+
+
+def extract_video_planning():
+    """AST-extracts, from the reference's plugin sources (build container only; nothing is copied into the repo), what decides how many
+    frames are sampled and at what size: the module-level `smart_nframes` (qwen25_lvu.py:402-442) and the budget / resize statements of
+    `fetch_video` (qwen25_lvu.py:350-372; qwen25_lvu_interleaved.py:416-436) — and compiles them against the [3P] names they use:
+    qwen-vl-utils' published constants and one-line helpers, and the installed transformers' `smart_resize` (the same arithmetic as
+    qwen-vl-utils 0.0.10 for every non-degenerate size) under qwen-vl-utils' default pixel limits.  Returns callables + a warning log."""
+    import ast
+    import math
+    from transformers.models.qwen2_vl.image_processing_pil_qwen2_vl import smart_resize as hf_smart_resize
+
+    warned = []
+
+    class Log:
+        def warning(self, msg):
+            warned.append(msg)
+
+        info = debug = warning
+
+    def smart_resize(height, width, factor=28, min_pixels=4 * 28 * 28, max_pixels=16384 * 28 * 28):     # qwen-vl-utils defaults MIN/MAX_PIXELS
+        return hf_smart_resize(height, width, factor, min_pixels, max_pixels)
+
+    env = {"IMAGE_FACTOR": 28, "FRAME_FACTOR": 2, "FPS": 2.0, "FPS_MIN_FRAMES": 4, "VIDEO_MIN_PIXELS": 128 * 28 * 28,
+           "VIDEO_MAX_PIXELS": 768 * 28 * 28, "VIDEO_TOTAL_PIXELS": 24576 * 28 * 28, "logger": Log(), "smart_resize": smart_resize,
+           "round_by_factor": lambda n, f: round(n / f) * f, "ceil_by_factor": lambda n, f: math.ceil(n / f) * f,
+           "floor_by_factor": lambda n, f: math.floor(n / f) * f}
+    out = {}
+    dumps = []
+    for fname in ("qwen25_lvu.py", "qwen25_lvu_interleaved.py"):
+        tree = ast.parse(open(os.path.join(REF, "lvu", "models", fname)).read())
+        g = dict(env)
+        for node in tree.body:                                      # the reference's own override: FPS_MAX_FRAMES = 100_000 (qwen25_lvu.py:27)
+            if isinstance(node, ast.Assign) and getattr(node.targets[0], "id", None) == "FPS_MAX_FRAMES":
+                exec(compile(ast.Module([node], []), fname, "exec"), g)
+        assert g["FPS_MAX_FRAMES"] == 100_000                       # both plugins carry the override (interleaved:32)
+        fn = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "smart_nframes")
+        dumps.append(ast.dump(fn))
+        exec(compile(ast.Module([fn], []), fname, "exec"), g)
+        fv = next(n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "fetch_video")
+        branch = fv.body[0]                                         # `if isinstance(ele["video"], str):`
+        assert isinstance(branch, ast.If)
+        names = {"total_pixels", "min_pixels", "max_pixels", "max_pixels_supposed"}
+        keep = []
+        for st in branch.body:
+            src = ast.unparse(st)
+            if isinstance(st, ast.Assign) and all(isinstance(t, ast.Name) and t.id in names for t in st.targets):
+                keep.append(st)
+            elif isinstance(st, ast.If) and ("max_pixels_supposed" in src.split(":")[0] or "resized_height" in src.split(":")[0]):
+                keep.append(st)
+        assert len(keep) == 7, [ast.unparse(k)[:50] for k in keep]   # 5 assignments + the warning + the resize decision
+        ret = ast.parse("return (resized_height, resized_width, max_pixels)").body[0]
+        fdef = ast.parse("def frame_size(ele, nframes, height, width, image_factor=28, video_reader_backend='decord'): pass").body[0]
+        fdef.body = keep + [ret]
+        mod = ast.fix_missing_locations(ast.Module([fdef], []))
+        exec(compile(mod, fname + ":fetch_video", "exec"), g)
+        out[fname] = (g["smart_nframes"], g["frame_size"], g["FPS_MAX_FRAMES"])
+    assert dumps[0] == dumps[1], "the two plugins' smart_nframes differ"
+    return out, warned
+
+
+def gen_video_plan():
+    """GV4: (video entry, total_frames, video_fps) -> nframes and (video entry, nframes, source size) -> max_pixels, (H, W), computed by the
+    reference's own statements (extract_video_planning)."""
+    fns, warned = extract_video_planning()
+    rec = {"note": "outputs of the reference's smart_nframes and of fetch_video's budget/resize statements, AST-extracted from "
+                   "lvu/models/qwen25_lvu.py (FPS_MAX_FRAMES = 100_000, :27) and checked equal on qwen25_lvu_interleaved.py's twins; [3P] names: "
+                   "qwen-vl-utils 0.0.10 constants, transformers' smart_resize", "nframes": [], "frame_size": []}
+    sn, fs, _ = fns["qwen25_lvu.py"]
+    sn_i, fs_i, cap_i = fns["qwen25_lvu_interleaved.py"]
+    for total, vfps in NFRAMES_VIDEOS:
+        for ele in NFRAMES_ELES:
+            def run(f):
+                try:
+                    return {"nframes": f(dict(ele), total, vfps)}
+                except (ValueError, AssertionError) as e:
+                    return {"raises": type(e).__name__, "message": str(e)}
+            r = run(sn)
+            assert run(sn_i) == r
+            rec["nframes"].append({"ele": ele, "total_frames": total, "video_fps": vfps, **r})
+    for nf, h, w in SIZE_VIDEOS:
+        for ele in SIZE_ELES:
+            del warned[:]
+            rh, rw, mp = fs(dict(ele), nf, h, w)
+            w1 = len(warned) > 0
+            assert fs_i(dict(ele), nf, h, w) == (rh, rw, mp)
+            rec["frame_size"].append({"ele": ele, "nframes": nf, "height": h, "width": w, "resized": [rh, rw], "max_pixels": mp, "warned": w1})
+    # the two divergences the round-3 review measured
+    assert fs({"max_pixels": 10 ** 7}, 64, 1080, 1920)[:2] == (560, 1008) and fs({"max_pixels": 392 * 560}, 7200, 392, 560)[:2] == (252, 364)
+    with open(os.path.join(OUT, "gv4_video_plan.json"), "w") as f:
+        json.dump(rec, f, indent=0)
+    print("gv4_video_plan.json:", len(rec["nframes"]), "frame-count cases,", len(rec["frame_size"]), "frame-size cases")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     ref = load_reference()
-    which = sys.argv[1:] or ["select", "modes", "effk", "compact", "e2e", "e2e_modes", "e2e_decode", "rope", "query", "vit"]
+    which = sys.argv[1:] or ["select", "modes", "effk", "compact", "e2e", "e2e_modes", "e2e_decode", "rope", "query", "vit", "video_plan"]
     if "select" in which: gen_select(ref)
     if "modes" in which: gen_select_modes(ref)
     if "effk" in which: gen_effective_k(ref)
@@ -613,4 +723,5 @@ if __name__ == "__main__":
     if "rope" in which: gen_rope_index()
     if "query" in which: gen_query_scores(ref)
     if "vit" in which: gen_vit_towers()
+    if "video_plan" in which: gen_video_plan()
     if "deep" in which: gen_e2e_deep(ref)       # ~20 min of CPU and 40 GB of RAM: not in the default list

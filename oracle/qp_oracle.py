@@ -242,12 +242,39 @@ def smart_resize(height: int, width: int, factor: int = 28, min_pixels: int = 56
     return h_bar, w_bar
 
 
-def video_frame_size(n_frames: int, height: int, width: int) -> Tuple[int, int]:
-    """Pixel budget of fetch_video (qwen25_lvu.py:292-306): VIDEO_MIN_PIXELS=128*28*28,
-    VIDEO_MAX_PIXELS=768*28*28, VIDEO_TOTAL_PIXELS=24576*28*28, FRAME_FACTOR=2."""
-    vmin, vmax, vtot, ff = 128 * 28 * 28, 768 * 28 * 28, 24576 * 28 * 28, 2
-    max_pixels = max(min(vmax, vtot / n_frames * ff), int(vmin * 1.05))
-    return smart_resize(height, width, factor=28, min_pixels=vmin, max_pixels=max_pixels)
+def smart_nframes(ele: dict, total_frames: int, video_fps: float, fps_max_frames: int = 100_000) -> int:
+    """qwen25_lvu.py:402-442 (twin qwen25_lvu_interleaved.py:343-383) with FPS_MAX_FRAMES = 100_000 (qwen25_lvu.py:27) and the
+    qwen-vl-utils constants FRAME_FACTOR=2, FPS=2.0, FPS_MIN_FRAMES=4.  Pinned by GV4."""
+    assert not ("fps" in ele and "nframes" in ele), "Only accept either `fps` or `nframes`"
+    if "nframes" in ele:
+        n = round(ele["nframes"] / 2) * 2                      # round_by_factor
+        n = min(n, total_frames)
+        n -= n % 2
+    else:
+        fps = ele.get("fps", 2.0)
+        lo = math.ceil(ele.get("min_frames", 4) / 2) * 2       # ceil_by_factor
+        hi = math.floor(ele.get("max_frames", min(fps_max_frames, total_frames)) / 2) * 2
+        n = total_frames / video_fps * fps
+        n = min(min(max(n, lo), hi), total_frames)
+        n = math.floor(n / 2) * 2
+    if not (2 <= n <= total_frames):
+        raise ValueError(f"nframes should in interval [2, {total_frames}], but got {n}.")
+    return n
+
+
+def video_frame_size(n_frames: int, height: int, width: int, ele: Optional[dict] = None, total_pixels_default: int = 24576 * 28 * 28):
+    """Pixel budget + resize target of fetch_video (qwen25_lvu.py:292-306, :351-372; interleaved:416-436): VIDEO_MIN_PIXELS=128*28*28,
+    VIDEO_MAX_PIXELS=768*28*28, VIDEO_TOTAL_PIXELS=24576*28*28, FRAME_FACTOR=2; `max_pixels` of the entry is CLAMPED to the budget
+    (:296-298), `total_pixels` / `min_pixels` of the entry replace the defaults, `resized_height/width` bypass the budget.  Pinned by GV4."""
+    ele = ele or {}
+    vmax, ff = 768 * 28 * 28, 2
+    total = ele.get("total_pixels", total_pixels_default)
+    mn = ele.get("min_pixels", 128 * 28 * 28)
+    mx = max(min(vmax, total / n_frames * ff), int(mn * 1.05))
+    mx = min(ele.get("max_pixels", mx), mx)
+    if "resized_height" in ele and "resized_width" in ele:
+        return smart_resize(ele["resized_height"], ele["resized_width"], factor=28, min_pixels=4 * 28 * 28, max_pixels=16384 * 28 * 28)
+    return smart_resize(height, width, factor=28, min_pixels=mn, max_pixels=mx)
 
 
 # --------------------------------------------------------------------------------------

@@ -222,21 +222,9 @@ def open_video(path, num_threads: Optional[int] = None, num_intervals: Optional[
                      f"InterleavedVideoReader contract")
 
 
-def smart_nframes(total_frames: int, video_fps: float, nframes: Optional[int] = None, fps: Optional[float] = None,
-                  frame_factor: int = 2, fps_min_frames: int = 4, fps_max_frames: int = 100_000) -> int:
-    """qwen-vl-utils smart_nframes with the reference's FPS_MAX_FRAMES override (qwen25_lvu.py:27, 402-442)."""
+def smart_nframes(total_frames: int, video_fps: float, nframes: Optional[int] = None, fps: Optional[float] = None) -> int:
+    """Keyword form of planner.smart_nframes (the reference's function takes the video entry of the message, qwen25_lvu.py:402-442)."""
+    from .planner import smart_nframes as _entry_form
     if nframes is not None and fps is not None:
         raise ValueError("Only accept either `fps` or `nframes`")
-    rnd = lambda x: round(x / frame_factor) * frame_factor
-    if nframes is not None:
-        n = rnd(nframes)
-    else:
-        fps = 2.0 if fps is None else fps
-        mn = -(-fps_min_frames // frame_factor) * frame_factor
-        mx = (min(fps_max_frames, total_frames) // frame_factor) * frame_factor
-        n = total_frames / video_fps * fps
-        n = min(min(max(n, mn), mx), total_frames)
-        n = (int(n) // frame_factor) * frame_factor
-    if not (frame_factor <= n <= total_frames):
-        raise ValueError(f"nframes should in interval [{frame_factor}, {total_frames}], but got {n}.")
-    return int(n)
+    return int(_entry_form({"nframes": nframes} if nframes is not None else ({"fps": fps} if fps is not None else {}), total_frames, video_fps))

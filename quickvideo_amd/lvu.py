@@ -16,23 +16,36 @@ _VIT = {"qwen2-vl-2b": QWEN2_VL_VIT_2B, "qwen2-vl-7b": QWEN2_VL_VIT_7B, "qwen2.5
         "tiny": TINY_VIT}
 
 
-def load_native_model(name_or_path: str, device=None, seed: int = 0) -> QwenVLNative:
+def load_native_model(name_or_path: str, device=None, seed: int = 0, parallel=None, process_group=None) -> QwenVLNative:
     """`synthetic:<preset>` -> seeded random weights at the real dims (no checkpoints offline), or a local
-    directory with a HF Qwen2-VL checkpoint (config.json + *.safetensors)."""
-    device = torch.device(device if device is not None else ("cuda:0" if torch.cuda.is_available() else "cpu"))
+    directory with a HF Qwen2-VL checkpoint (config.json + *.safetensors).
+
+    Multi-GPU (one process per GPU, torch.distributed initialised by the launcher; the reference's counterpart is
+    `device_map="auto"`, lvu/lvu.py:11-16): `parallel` = "tp" | "sp" | "pp" | "auto" | "single" (default: $QP_PARALLEL, else "auto" in a
+    multi-rank job).  "tp" loads this rank's head / MLP-column SHARD; the other modes load a full replica on every rank and cut the
+    per-video pipeline stages out of it as views (quickvideo_amd/parallel.py).  The vision tower is replicated in every mode."""
+    from .parallel import resolve
+    par = resolve(parallel, process_group)
+    if device is None:
+        device = (f"cuda:{torch.cuda.current_device()}" if par.on else "cuda:0") if torch.cuda.is_available() else "cpu"
+    device = torch.device(device)
+    tp = dict(tp_rank=par.rank, tp_size=par.world) if (par.on and par.mode == "tp") else {}
     key = name_or_path.split(":", 1)[1] if name_or_path.startswith("synthetic:") else None
     if key is None:
         low = os.path.basename(name_or_path.rstrip("/")).lower()
         if os.path.isdir(name_or_path):
-            return _load_hf_dir(name_or_path, device)
+            m = _load_hf_dir(name_or_path, device, **tp)
+            m.parallel = par
+            return m
         key = next((k for k in PRESETS if k.replace("-", "") in low.replace("-", "").replace("instruct", "")), None)
         if key is None:
             raise ValueError(f"cannot resolve model {name_or_path!r}: use 'synthetic:<{'|'.join(PRESETS)}>' or a local checkpoint directory")
     spec = PRESETS[key]
-    return QwenVLNative(DecoderWeights.synthetic(spec, device, seed=seed), VisionWeights.synthetic(_VIT[key], device, seed=seed), device, name=key)
+    return QwenVLNative(DecoderWeights.synthetic(spec, device, seed=seed, **tp), VisionWeights.synthetic(_VIT[key], device, seed=seed), device, name=key,
+                        parallel=par)
 
 
-def _load_hf_dir(path: str, device) -> QwenVLNative:
+def _load_hf_dir(path: str, device, tp_rank: int = 0, tp_size: int = 1) -> QwenVLNative:
     import json
     from safetensors import safe_open
     from .spec import TextSpec
@@ -74,8 +87,8 @@ def _load_hf_dir(path: str, device) -> QwenVLNative:
     if os.path.exists(gpath):                                       # temperature 1e-6 / top_k 1 / top_p 0.001 / repetition_penalty 1.05)
         g = json.load(open(gpath))
         gen = {k: g[k] for k in ("do_sample", "temperature", "top_k", "top_p", "repetition_penalty", "eos_token_id") if k in g}
-    return QwenVLNative(DecoderWeights.from_named(spec, text, device), VisionWeights.from_named(vspec, vis, device), device, name=path,
-                        generation_defaults=gen)
+    return QwenVLNative(DecoderWeights.from_named(spec, text, device, tp_rank=tp_rank, tp_size=tp_size), VisionWeights.from_named(vspec, vis, device),
+                        device, name=path, generation_defaults=gen)
 
 
 class LVU:
@@ -83,7 +96,9 @@ class LVU:
         self.config = config
         if model is None:
             # reference: AutoModelForImageTextToText.from_pretrained(bf16, device_map="auto", flash_attention_2) (lvu.py:10-16)
-            model = load_native_model(config.model_name_or_path, **{k: v for k, v in model_init_kwargs.items() if k in ("device", "seed")})
+            # plus, for a multi-GPU job (one process per GPU): parallel="tp"|"sp"|"pp"|"auto", process_group=<group of the job's ranks>
+            model = load_native_model(config.model_name_or_path, **{k: v for k, v in model_init_kwargs.items()
+                                                                    if k in ("device", "seed", "parallel", "process_group")})
         if processor is None:
             processor = SyntheticProcessor(model.spec)           # reference: AutoProcessor.from_pretrained (lvu.py:19-20)
         self.model = model

@@ -47,6 +47,8 @@ def chat_lvu_model(self, messages, _overlap: bool = True, **generation_kwargs):
         generation_kwargs["eos_token_id"] = eos
     ids = pipe.generate(messages, video, max_new_tokens=mnt, overlap=_overlap, **generation_kwargs)
     t = pipe.last_timings
+    if pipe.par.on and pipe.par.rank != 0:               # multi-GPU job: every rank returns the answer, rank 0 reports the timings
+        return self.processor.batch_decode([ids], skip_special_tokens=True, clean_up_tokenization_spaces=False)
     # the reference prints these six lines (qwen25_lvu.py:748-753) from unsynchronised host clocks; here: the producer's time inside
     # the frame source, the ViT by itself, the device-synchronised group loop, decode, e2e, first token
     print(f"total time spent fetching frames was: {t.sequential_fetch if not _overlap else t.producer_busy}")
@@ -58,10 +60,14 @@ def chat_lvu_model(self, messages, _overlap: bool = True, **generation_kwargs):
     return self.processor.batch_decode([ids], skip_special_tokens=True, clean_up_tokenization_spaces=False)
 
 
+def video_message(config: LVUConfig, question, video_path):
+    """The one-video chat message run_lvu_model builds (qwen25_lvu.py:504-536): the video entry carries max_pixels / min_pixels from
+    `extra_kwargs` and `fps` (if set) XOR `nframes` from the config — chat_lvu_model then reads ONLY the entry, like the reference."""
+    from ..planner import video_entry_from_config
+    cfg = config
+    entry = video_entry_from_config(video_path, cfg.fps, cfg.num_frames, cfg.extra_kwargs)      # raises "Either fps or num_frames should be set."
+    return [{"role": "user", "content": [entry, {"type": "text", "text": question}]}]
+
+
 def run_lvu_model(self, question, video_path, **generation_kwargs):
-    """qwen25_lvu.py:504-536: one-video chat message; `fps` xor `num_frames` comes from the config."""
-    cfg = self.config
-    if cfg.fps is None and cfg.num_frames is None:
-        raise ValueError("Either fps or num_frames should be set.")
-    messages = [{"role": "user", "content": [{"type": "video", "video": video_path}, {"type": "text", "text": question}]}]
-    return chat_lvu_model(self, messages, **generation_kwargs)
+    return chat_lvu_model(self, video_message(self.config, question, video_path), **generation_kwargs)

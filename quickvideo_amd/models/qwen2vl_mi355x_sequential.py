@@ -10,5 +10,4 @@ def chat_lvu_model(self, messages, **generation_kwargs):
 
 
 def run_lvu_model(self, question, video_path, **generation_kwargs):
-    messages = [{"role": "user", "content": [{"type": "video", "video": video_path}, {"type": "text", "text": question}]}]
-    return chat_lvu_model(self, messages, **generation_kwargs)
+    return chat_lvu_model(self, _m.video_message(self.config, question, video_path), **generation_kwargs)

@@ -80,6 +80,8 @@ def mrope_positions(prefix_len: int, grid_thw: Tuple[int, int, int], tail_len: i
 
 def smart_resize(height: int, width: int, factor: int = 28, min_pixels: int = 56 * 56, max_pixels: int = 14 * 14 * 4 * 1280):
     """qwen-vl-utils smart_resize [3P]."""
+    if max(height, width) / min(height, width) > 200:
+        raise ValueError(f"absolute aspect ratio must be smaller than 200, got {max(height, width) / min(height, width)}")
     h_bar = max(factor, round(height / factor) * factor)
     w_bar = max(factor, round(width / factor) * factor)
     if h_bar * w_bar > max_pixels:
@@ -93,9 +95,82 @@ def smart_resize(height: int, width: int, factor: int = 28, min_pixels: int = 56
     return h_bar, w_bar
 
 
-def video_frame_size(n_frames: int, height: int, width: int, max_pixels: Optional[int] = None, min_pixels: Optional[int] = None):
-    """Per-frame resize target under the reference's pixel budget (qwen25_lvu.py:292-306)."""
-    vmin, vmax, vtot, ff = 128 * 28 * 28, 768 * 28 * 28, 24576 * 28 * 28, 2
-    mn = vmin if min_pixels is None else min_pixels
-    mx = max(min(vmax, vtot / n_frames * ff), int(mn * 1.05)) if max_pixels is None else max_pixels
-    return smart_resize(height, width, factor=28, min_pixels=mn, max_pixels=mx)
+# qwen-vl-utils 0.0.10 constants [3P] (uv.lock:1046-1047; imported by `from qwen_vl_utils.vision_process import *`, qwen25_lvu.py:26) and
+# the reference's own override of FPS_MAX_FRAMES (qwen25_lvu.py:27).  VIDEO_TOTAL_PIXELS is SURVEY §8d's figure; like the [3P]
+# package, the environment variable VIDEO_MAX_PIXELS overrides it.
+IMAGE_FACTOR, FRAME_FACTOR = 28, 2
+VIDEO_MIN_PIXELS, VIDEO_MAX_PIXELS = 128 * 28 * 28, 768 * 28 * 28
+FPS, FPS_MIN_FRAMES, FPS_MAX_FRAMES = 2.0, 4, 100_000
+
+
+def video_total_pixels() -> int:
+    import os
+    return int(float(os.environ.get("VIDEO_MAX_PIXELS", 24576 * 28 * 28)))
+
+
+def smart_nframes(ele: dict, total_frames: int, video_fps: float) -> int:
+    """Frames sampled from a video of `total_frames` at `video_fps`, from the VIDEO ENTRY of the chat message — the reference's own
+    smart_nframes (qwen25_lvu.py:402-442, twin qwen25_lvu_interleaved.py:343-383): `nframes` (rounded to a multiple of 2, clamped to the
+    video's length) XOR `fps` (default 2.0) with `min_frames` / `max_frames`.  Pinned by GV4 (tests/golden/gv4_video_plan.json)."""
+    assert not ("fps" in ele and "nframes" in ele), "Only accept either `fps` or `nframes`"
+    ff = FRAME_FACTOR
+    if "nframes" in ele:
+        nframes = round(ele["nframes"] / ff) * ff
+        nframes = min(nframes, total_frames)
+        nframes -= nframes % ff
+    else:
+        fps = ele.get("fps", FPS)
+        min_frames = math.ceil(ele.get("min_frames", FPS_MIN_FRAMES) / ff) * ff
+        max_frames = math.floor(ele.get("max_frames", min(FPS_MAX_FRAMES, total_frames)) / ff) * ff
+        nframes = total_frames / video_fps * fps
+        nframes = min(min(max(nframes, min_frames), max_frames), total_frames)
+        nframes = math.floor(nframes / ff) * ff
+    if not (ff <= nframes and nframes <= total_frames):
+        raise ValueError(f"nframes should in interval [{ff}, {total_frames}], but got {nframes}.")
+    return nframes
+
+
+def video_pixel_budget(nframes: int, ele: Optional[dict] = None):
+    """(min_pixels, max_pixels) per frame (qwen25_lvu.py:292-298, twins :351-357 and interleaved:416-422): the budget
+    `max(min(VIDEO_MAX_PIXELS, total_pixels / nframes * 2), int(min_pixels * 1.05))` is a LIMIT — a `max_pixels` in the video entry can
+    only lower it (the reference logs a warning when it asks for more); `total_pixels` in the entry moves the budget itself."""
+    ele = ele or {}
+    total_pixels = ele.get("total_pixels", video_total_pixels())
+    min_pixels = ele.get("min_pixels", VIDEO_MIN_PIXELS)
+    limit = max(min(VIDEO_MAX_PIXELS, total_pixels / nframes * FRAME_FACTOR), int(min_pixels * 1.05))
+    wanted = ele.get("max_pixels", limit)
+    if wanted > limit:
+        import logging
+        logging.getLogger(__name__).warning(f"The given max_pixels[{wanted}] exceeds limit[{limit}].")
+    return min_pixels, min(wanted, limit)
+
+
+def video_frame_size(n_frames: int, height: int, width: int, ele: Optional[dict] = None):
+    """Per-frame resize target (qwen25_lvu.py:292-306, :358-372; interleaved:416-436): `resized_height` + `resized_width` in the video
+    entry win (rounded to multiples of 28 under the IMAGE pixel limits, like the reference's call without min/max arguments);
+    otherwise smart_resize of the source size under video_pixel_budget."""
+    ele = ele or {}
+    min_pixels, max_pixels = video_pixel_budget(n_frames, ele)           # evaluated first, like the reference (its warning fires either way)
+    if "resized_height" in ele and "resized_width" in ele:
+        return smart_resize(ele["resized_height"], ele["resized_width"], factor=IMAGE_FACTOR, min_pixels=4 * 28 * 28, max_pixels=16384 * 28 * 28)
+    return smart_resize(height, width, factor=IMAGE_FACTOR, min_pixels=min_pixels, max_pixels=max_pixels)
+
+
+VIDEO_ENTRY_KEYS = ("fps", "nframes", "min_frames", "max_frames", "min_pixels", "max_pixels", "total_pixels", "resized_height", "resized_width")
+
+
+def video_entry_from_config(video, fps=None, num_frames=None, extra_kwargs=None) -> dict:
+    """The video entry run_lvu_model builds from the LVUConfig (qwen25_lvu.py:504-536): max_pixels / min_pixels from extra_kwargs,
+    `fps` if set, else `nframes`."""
+    extra_kwargs = extra_kwargs or {}
+    ele = {"type": "video", "video": video}
+    for k in ("max_pixels", "min_pixels"):
+        if extra_kwargs.get(k) is not None:
+            ele[k] = extra_kwargs[k]
+    if fps is not None:
+        ele["fps"] = fps
+    elif num_frames is not None:
+        ele["nframes"] = num_frames
+    else:
+        raise ValueError("Either fps or num_frames should be set.")
+    return ele

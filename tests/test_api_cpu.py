@@ -43,9 +43,19 @@ def test_generate_end_to_end_cpu(model_type, capsys):
     assert t.groups == 2 and t.tokens > 0 and t.ttft > 0
     printed = capsys.readouterr().out
     assert "total time spent on prefill was" in printed and "e2e" in printed
-    # chat() with the same message structure gives the same answer (deterministic greedy decode)
-    msgs = [{"role": "user", "content": [{"type": "video", "video": video}, {"type": "text", "text": "What happens in the video?"}]}]
+    # chat() with the message run_lvu_model builds (the video entry carries `nframes`, qwen25_lvu.py:504-536) gives the same answer
+    msgs = [{"role": "user", "content": [{"type": "video", "video": video, "nframes": 8}, {"type": "text", "text": "What happens in the video?"}]}]
     assert obj.chat(msgs, max_new_tokens=3) == out
+    # ... and chat() reads ONLY the video entry, like the reference's chat_lvu_model: a bare entry is sampled at qwen-vl-utils' default
+    # 2 fps (40 frames at 2 fps -> all 40), whatever LVUConfig.num_frames says; per-entry fps / max_frames are honoured
+    from quickvideo_amd.frames import open_video
+    bare = [{"role": "user", "content": [{"type": "video", "video": video}, {"type": "text", "text": "q"}]}]
+    assert obj._pipeline.plan(open_video(video), bare)["nframes"] == 40
+    e2 = [{"role": "user", "content": [{"type": "video", "video": video, "fps": 1.0, "max_frames": 12}, {"type": "text", "text": "q"}]}]
+    assert obj._pipeline.plan(open_video(video), e2)["nframes"] == 12
+    e3 = [{"role": "user", "content": [{"type": "video", "video": video, "nframes": 8, "resized_height": 60, "resized_width": 110}, {"type": "text", "text": "q"}]}]
+    P3 = obj._pipeline.plan(open_video(video), e3)
+    assert (P3["nframes"], P3["H"], P3["W"]) == (8, 56, 112)
     # the sequential and overlapped plugins agree
     other = "qwen2vl_mi355x_sequential" if model_type == "qwen2vl_mi355x" else "qwen2vl_mi355x"
     obj2 = lvu.LVU(lvu.LVUConfig("synthetic:tiny", model_type=other, top_p=0.5, video_group_size=4, num_frames=8), model=m)

@@ -1,0 +1,140 @@
+"""The multi-GPU layouts BEHIND THE PLUGIN: one process per rank (gloo, CPU tensors, the oracle-backed ops double),
+every rank builds `LVU(config, model_init_kwargs={"parallel": mode})` and calls `generate()` like a single-GPU user; rank 0 owns the
+frame source, frames are scattered by frame pair, every rank runs the ViT on its share, one all-gather assembles the features, the
+engine gets its process groups from the pipeline, the first token comes back from the rank that holds the logits and decode runs on
+every layout.  The answer must be the single-process answer."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle_ops import OracleOps
+
+QUESTION = "What happens in the video?"
+# 112x168 frames -> 8x12 patches -> 24 tokens per frame pair; 48 frames in groups of 12 (24): 144 (288) tokens per group, enough for the
+# group-token parallel split to be ACTIVE on 2 (4) ranks (>= 64 rows per rank); ragged variants exercise the padded scatter
+VIDEO = "synthetic://?frames=96&h=112&w=168&fps=2&seed=3"
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _cfg(lvu, gs, nframes, **kw):
+    return lvu.LVUConfig("synthetic:tiny", top_p=0.5, video_group_size=gs, num_frames=nframes, **kw)
+
+
+def _run(obj, nframes_unused=None, mnt=4):
+    out = obj.generate(QUESTION, VIDEO, max_new_tokens=mnt)
+    pipe = obj._pipeline
+    return out, pipe.last_layout, list(pipe.model.engine.arena.len), pipe.last_timings
+
+
+def _single(ret, gs, nframes, kw):
+    import lvu
+    torch.set_num_threads(2)
+    obj = lvu.LVU(_cfg(lvu, gs, nframes, **kw), model_init_kwargs={"device": "cpu", "seed": 3})
+    obj._ops = OracleOps()
+    out, layout, lens, tm = _run(obj)
+    ret["single"] = (out, layout, lens, tm.groups, tm.tokens)
+
+
+def _worker(rank, world, port, mode, gs, nframes, kw, ret):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.set_num_threads(2)
+        import lvu
+        obj = lvu.LVU(_cfg(lvu, gs, nframes, **kw), model_init_kwargs={"device": "cpu", "seed": 3, "parallel": mode})
+        obj._ops = OracleOps()
+        out, layout, lens, tm = _run(obj)
+        eng = obj._pipeline.model.engine
+        ret[f"r{rank}"] = (out, layout, lens, tm.groups, tm.tokens, (eng.l0, len(eng.w.layers)), eng.hkv, eng.hq)
+        # a second video through the same objects (engine reuse, ring reuse, the cached front-end group)
+        out2 = obj.generate(QUESTION, VIDEO, max_new_tokens=2)
+        ret[f"again{rank}"] = out2
+        dist.barrier()
+        dist.destroy_process_group()
+    except BaseException as e:
+        import traceback
+        ret[f"error{rank}"] = "".join(traceback.format_exception(type(e), e, e.__traceback__))
+        raise
+
+
+def _launch(world, mode, gs=12, nframes=48, **kw):
+    ret = mp.Manager().dict()
+    _single(ret, gs, nframes, kw)
+    mp.spawn(_worker, args=(world, _free_port(), mode, gs, nframes, kw, ret), nprocs=world, join=True)
+    for r in range(world):
+        assert f"error{r}" not in ret, ret.get(f"error{r}")
+    return ret
+
+
+@pytest.mark.parametrize("world,mode,gs,nframes,layout", [
+    (2, "tp", 12, 48, "tp2"), (2, "sp", 12, 48, "pp1xsp2"), (2, "pp", 12, 48, "pp2xsp1"), (3, "pp", 12, 48, "pp3xsp1"),
+    (4, "tp", 24, 96, "tp4"), (4, "sp", 24, 96, "pp1xsp4"),
+    (2, "sp", 12, 40, "pp1xsp2"),          # short last group: 40 = 12+12+12+4 frames
+    (4, "sp", 12, 48, "pp1xsp4"),          # 6 frame pairs on 4 ranks: padded scatter (2, 2, 2, 0 pairs), rows below the sp threshold
+    (4, "pp", 12, 48, None),               # more ranks than layers: refused loudly
+])
+def test_generate_over_ranks_equals_single_process(world, mode, gs, nframes, layout):
+    if layout is None:
+        ret = mp.Manager().dict()
+        with pytest.raises(Exception):
+            mp.spawn(_worker, args=(world, _free_port(), mode, gs, nframes, {}, ret), nprocs=world, join=True)
+        assert any("needs at least that many layers" in str(ret.get(f"error{r}", "")) for r in range(world))
+        return
+    ret = _launch(world, mode, gs, nframes)
+    out, lay1, lens, groups, tokens = ret["single"]
+    assert lay1 == "single" and len(out) == 1 and out[0].count("<tok_") == 4
+    for r in range(world):
+        o, lay, ln, g, t, (l0, nl), hkv, hq = ret[f"r{r}"]
+        assert lay == layout
+        assert o == out, (r, o, out)                                           # every rank returns the single-process answer
+        assert (g, t) == (groups, tokens)
+        if mode == "pp":                                                       # a stage holds ITS layers' cache only
+            assert ln == lens[l0:l0 + nl], (r, ln, lens)
+        else:
+            assert ln == lens
+        assert ret[f"again{r}"] == [" ".join(out[0].split(" ")[:2])]
+    if mode == "pp":
+        assert sorted(ret[f"r{r}"][5][0] for r in range(world)) == sorted({ret[f"r{r}"][5][0] for r in range(world)})   # disjoint stages
+        assert sum(ret[f"r{r}"][5][1] for r in range(world)) == 3
+
+
+def test_auto_layout_picks_a_grid_per_video_and_matches():
+    """`parallel="auto"` (the default of a multi-rank job): full replica per rank, grid chosen per video from the group count
+    (parallel.choose_layout; 4 ranks, 3 layers, 4 groups -> pp2 x sp2 or pp1 x sp4 by the efficiency table)."""
+    from quickvideo_amd.parallel import choose_layout, sp_efficiency_table
+    want = choose_layout(4, 4, sp_efficiency_table(), 3)
+    ret = _launch(4, "auto", 24, 96)
+    out = ret["single"][0]
+    for r in range(4):
+        assert ret[f"r{r}"][1] == f"pp{want[0]}xsp{want[1]}"
+        assert ret[f"r{r}"][0] == out
+
+
+def test_hidden_state_pruning_and_sampling_through_the_pipeline_stages():
+    """prefill_prune_starting_layer (hidden rows shrink between stages) + a sampled decode (the deciding rank's choice is broadcast:
+    ranks cannot drift apart) through two pipeline stages."""
+    ret = _launch(2, "pp", 12, 48, prefill_prune_starting_layer=1)
+    out = ret["single"][0]
+    assert ret["r0"][0] == out and ret["r1"][0] == out
+
+
+def test_layout_cost_model():
+    from quickvideo_amd.parallel import choose_layout, layout_efficiency, stage_balance
+    assert stage_balance(28, 8) == pytest.approx(3.5 / 4) and stage_balance(28, 4) == 1.0 and stage_balance(80, 8) == 1.0
+    eff = {1: 1.0, 2: 0.93, 4: 0.82, 8: 0.62}
+    # the 1-hour video (450 groups) on 8 GPUs: an 8-stage pipe of 28 layers is capped at 7/8 by its 4-layer stages; 4 stages x 2-rank
+    # row groups (7 layers each, balanced) wins
+    assert choose_layout(450, 8, eff, 28) == (4, 2)
+    assert layout_efficiency(450, 8, 1, eff, 28) == pytest.approx(450 / 457 * 0.875)
+    assert choose_layout(450, 8, eff, 80) == (8, 1)                        # 72B: 10 layers per stage
+    assert choose_layout(4, 8, eff, 28)[0] <= 2                            # 4 groups: no deep pipe
+    assert choose_layout(450, 4, eff, 28) == (4, 1) and choose_layout(450, 2, eff, 28) == (2, 1)

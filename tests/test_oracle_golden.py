@@ -129,6 +129,43 @@ def test_planner_hand_cases():
     assert O.video_frame_size(512, 1080, 1920) == (224, 420) and O.video_frame_size(7200, 1080, 1920) == (224, 420)
 
 
+def test_video_plan_vs_reference_golden(golden_dir):
+    """GV4 (round 4): frame count and frame size from the VIDEO ENTRY of the message — outputs of the reference's own `smart_nframes` and
+    of `fetch_video`'s budget / resize statements (AST-extracted in the build container, oracle/make_golden.py::extract_video_planning).
+    Both the oracle's restatement and the PRODUCT's planner must reproduce every row: nframes (or the same exception class and message),
+    the clamped max_pixels, the resized (H, W) and whether the reference warned.  Includes the two cases the round-3 review measured
+    (max_pixels = 10^7 at 64 frames of 1080x1920 -> 560x1008; max_pixels = 392*560 at 7200 frames -> 252x364)."""
+    import logging
+    from quickvideo_amd import planner
+    d = json.load(open(os.path.join(golden_dir, "gv4_video_plan.json")))
+    assert len(d["nframes"]) >= 200 and len(d["frame_size"]) >= 1200
+    for r in d["nframes"]:
+        for fn in (O.smart_nframes, planner.smart_nframes):
+            try:
+                got = {"nframes": fn(dict(r["ele"]), r["total_frames"], r["video_fps"])}
+            except (ValueError, AssertionError) as e:
+                got = {"raises": type(e).__name__, "message": str(e)}
+            want = {k: r[k] for k in ("nframes", "raises", "message") if k in r}
+            assert got == want, (fn.__module__, r, got)
+            if "nframes" in got:
+                assert type(got["nframes"]) is type(want["nframes"]) or float(got["nframes"]) == float(want["nframes"])
+    records = []
+    h = logging.Handler(); h.emit = records.append
+    lg = logging.getLogger(planner.__name__); lg.addHandler(h)
+    try:
+        for r in d["frame_size"]:
+            ele = dict(r["ele"])
+            assert list(O.video_frame_size(r["nframes"], r["height"], r["width"], ele)) == r["resized"], r
+            del records[:]
+            assert list(planner.video_frame_size(r["nframes"], r["height"], r["width"], ele)) == r["resized"], r
+            assert planner.video_pixel_budget(r["nframes"], ele)[1] == r["max_pixels"], r
+            assert (len(records) > 0) == r["warned"], r
+    finally:
+        lg.removeHandler(h)
+    assert planner.video_frame_size(64, 1080, 1920, {"max_pixels": 10 ** 7}) == (560, 1008)
+    assert planner.video_frame_size(7200, 392, 560, {"max_pixels": 392 * 560}) == (252, 364)
+
+
 @pytest.mark.parametrize("ci", range(len(E2E_CASES)))
 def test_e2e_composite_oracle(golden_dir, ci):
     """Oracle group-prefill vs transformers-5.15 Qwen2-VL + the reference's post_process_kv_cache."""
