@@ -45,6 +45,7 @@ from quickvideo_amd.engine import QuickPrefillEngine, sp_row_ranges  # noqa: E40
 from quickvideo_amd.lvu_config import LVUConfig, effective_k  # noqa: E402
 from quickvideo_amd.spec import PRESETS  # noqa: E402
 from quickvideo_amd.weights import DecoderWeights, pp_layer_split  # noqa: E402
+from quickvideo_amd import parallel as qp_parallel  # noqa: E402
 
 CONFIGS = {
     # name: (model, frames, frame_h, frame_w, group_size, rho, prefix, tail)
@@ -53,6 +54,10 @@ CONFIGS = {
     "cfg3": ("qwen2-vl-7b", 256, 280, 504, 32, 0.25, 15, 30),
     "cfg4s": ("qwen2-vl-7b", 720, 392, 560, 16, 0.5, 15, 30),     # 1/10 of the 1-hour video (100k tokens)
     "cfg4": ("qwen2-vl-7b", 7200, 392, 560, 16, 0.5, 15, 30),      # synthetic 1-hour video, ~1M vision tokens (the metric's workload)
+    # the reference's OWN operating point for the 1-hour video: 7200 frames at the reference's pixel budget — a 1080x1920
+    # source comes out at 224x420 (S = 120 tokens per frame pair) -> 432 015 tokens, 450 groups of 960.  The number that can stand beside
+    # the reference README's "1-hour video ~ 20 s" with the token count stated.
+    "cfg4ref": ("qwen2-vl-7b", 7200, 224, 420, 16, 0.5, 15, 30),
     "cfg4x2": ("qwen2-vl-7b", 14400, 392, 560, 16, 0.5, 15, 30),   # 2-hour video, ~2M vision tokens, 57.8 GB of pruned KV: capacity point, not the metric
     "cfg5": ("qwen2-vl-72b", 512, 224, 420, 16, 0.5, 15, 30),      # 72B: TP=8 in BASELINE.json; also fits ONE MI355X (145 GB of 288 GB)
     "tiny": ("tiny", 16, 112, 168, 4, 0.5, 5, 7),
@@ -175,20 +180,10 @@ class Telemetry(threading.Thread):
 # ----------------------------------------------------------------------------------------------------------------------
 # multi-GPU layout
 # ----------------------------------------------------------------------------------------------------------------------
-def choose_layout(n_groups, world, eff_sp):
-    """(pp, sp) with pp * sp == world for `--parallel auto`: a layer pipeline of pp stages, each a group-token parallel group of
-    sp ranks.  Model: the pipe is busy G / (G + pp - 1) of the time; an sp group of s ranks runs at eff_sp[s] of a single GPU
-    (measured at start-up by probe_sp_efficiency: GEMMs at M = n/s, the K/V all-gather over RCCL, the replicated prune)."""
-    best, best_eff = (world, 1), -1.0
-    pp = 1
-    while pp <= world:
-        sp = world // pp
-        if pp * sp == world and sp in eff_sp:
-            eff = n_groups / (n_groups + pp - 1) * eff_sp[sp]
-            if eff > best_eff + 1e-9:
-                best, best_eff = (pp, sp), eff
-        pp *= 2
-    return best
+def choose_layout(n_groups, world, eff_sp, n_layers=None):
+    """(pp, sp) with pp * sp == world for `--parallel auto`: the product's own cost model (quickvideo_amd/parallel.py::choose_layout — pipe
+    fill/drain, the heaviest stage's layer count, the measured sp efficiency), fed with the table probe_sp_efficiency measures at start-up."""
+    return qp_parallel.choose_layout(n_groups, world, eff_sp, n_layers)
 
 
 def probe_sp_efficiency(name, device, rank, world, single_dev):
@@ -586,65 +581,161 @@ def _leg_record(t, overlap, reader_threads):
            "host_consumer_blocked_in_queue_get_ms": ms(t.consumer_get_wait)}
     if not overlap:
         rec["fetch_all_frames_before_gpu_ms"] = ms(t.sequential_fetch)
+    if t.group_gaps:
+        gaps = sorted(g * 1e3 for g in t.group_gaps[1:])                  # (group 0 waits for its own frames + ViT by construction)
+        if gaps:
+            q = lambda f: round(gaps[min(len(gaps) - 1, int(f * len(gaps)))], 3)
+            rec["gpu"]["main_stream_gap_before_group_ms"] = {"p50": q(0.5), "p90": q(0.9), "p99": q(0.99), "max": round(gaps[-1], 3),
+                                                            "sum": round(sum(gaps), 2), "groups": len(gaps)}
+    if t.layout != "single":
+        rec["layout"] = t.layout
     return rec
 
 
-def pipeline_leg(name, eng, device, modes=("overlapped", "sequential"), warm_video=None):
+class HostStress:
+    """Saturates the host while a pipeline leg runs: one numpy thread per core (GIL released inside the array ops: the cores are busy,
+    the way a real decoder pool keeps them) plus `python_threads` pure-Python spinners (they HOLD the GIL between switch intervals: what the
+    reference's processor thread does to the launching thread, qwen25_lvu_interleaved.py:303-340)."""
+
+    def __init__(self, numpy_threads, python_threads=2):
+        self.stop, self.threads, self.iters = threading.Event(), [], [0] * (numpy_threads + python_threads)
+        for i in range(numpy_threads):
+            self.threads.append(threading.Thread(target=self._numpy, args=(i,), daemon=True))
+        for i in range(python_threads):
+            self.threads.append(threading.Thread(target=self._python, args=(numpy_threads + i,), daemon=True))
+        self.numpy_threads, self.python_threads = numpy_threads, python_threads
+
+    def _numpy(self, i):
+        import numpy as np
+        a = np.random.RandomState(i).randint(0, 256, (1080, 1920, 3), dtype=np.uint8)
+        while not self.stop.is_set():
+            a = np.bitwise_xor(np.roll(a, 7, axis=0), np.uint8(37))
+            self.iters[i] += 1
+
+    def _python(self, i):
+        x = 0
+        while not self.stop.is_set():
+            for k in range(20000):
+                x = (x * 1103515245 + k) & 0xffffffff
+            self.iters[i] += 1
+
+    def __enter__(self):
+        for t in self.threads:
+            t.start()
+        return self
+
+    def __exit__(self, *exc):
+        self.stop.set()
+        for t in self.threads:
+            t.join(timeout=5)
+
+
+def pipeline_leg(name, eng, device, modes=("overlapped", "sequential"), warm_video=None, model=None, decode_s_per_hour=REFERENCE_DECODE_S_PER_HOUR,
+                 stress=None, reader_threads=None, vit_alone=True, video_override=None, entry_extra=None):
     """video -> first token with the real front end: COSTED synthetic frame source (every frame produced at 1080x1920 on a pool of
     QUICKCODEC_CORES threads and LANCZOS-resized to the model's frame size, padded to the reference's published decoder cost:
-    21.3 s per hour of video) -> pinned ring -> H2D on a copy stream -> GPU normalise/patchify + ViT on a second stream -> group
-    prefill -> tail -> first token id on the host.  Both plugins: overlapped (producer thread runs ahead of the GPU) and sequential
-    (every frame fetched first, qwen25_lvu.py:551-575); `overlap` = what the first hides of the second."""
+    21.3 s per hour of video; `decode_s_per_hour=0`: un-padded, the real work only) -> pinned ring -> H2D on a copy stream -> GPU
+    normalise/patchify + ViT on a second stream -> group prefill -> tail -> first token id on the host.  Both plugins: overlapped
+    (producer thread runs ahead of the GPU) and sequential (every frame fetched first, qwen25_lvu.py:551-575); `overlap` = what the
+    first hides of the second.  `model`: a QwenVLNative built for a multi-GPU job (lvu.load_native_model(parallel=...)) — every rank
+    calls this function, rank 0 owns the frame source, the record comes from rank 0.  `stress`: (numpy threads, python threads) of
+    HostStress running beside the leg."""
     from quickvideo_amd.frames import open_video
     from quickvideo_amd.pipeline import PrefillPipeline, QwenVLNative
     from quickvideo_amd.processor import SyntheticProcessor
     from quickvideo_amd.vit import VisionWeights
     from quickvideo_amd.lvu import _VIT
-    model, frames, fh, fw, gs, rho, prefix, tail = CONFIGS[name]
-    vis = VisionWeights.synthetic(_VIT[model], device, seed=0)
-    m = QwenVLNative(eng.w, vis, device, name=model)
-    m.engine = eng                                               # same engine (KV arena, tuned GEMM plans) as the headline pass
-    pipe = PrefillPipeline(m, eng.cfg, SyntheticProcessor(eng.spec), ops=eng.ops)
-    pipe.measure_vit_alone = True
+    mname, frames, fh, fw, gs, rho, prefix, tail = CONFIGS[name]
+    if model is None:
+        vis = VisionWeights.synthetic(_VIT[mname], device, seed=0)
+        m = QwenVLNative(eng.w, vis, device, name=mname)
+        m.engine = eng                                           # same engine (KV arena, tuned GEMM plans) as the headline pass
+        pipe = PrefillPipeline(m, eng.cfg, SyntheticProcessor(eng.spec), ops=eng.ops)
+    else:
+        m = model
+        pipe = PrefillPipeline(m, lvu_config_for(name), SyntheticProcessor(m.spec))
+    lead = pipe.par.rank == 0
+    pipe.measure_vit_alone = vit_alone
+    if reader_threads is not None:
+        os.environ["QUICKCODEC_CORES"] = str(reader_threads)
     threads = int(os.environ.setdefault("QUICKCODEC_CORES", str(min(16, os.cpu_count() or 16))))   # the reference's timing scripts use 16
     dec = "&decode_h=1080&decode_w=1920"
+    pad = lambda secs: f"&decode_s={decode_s_per_hour * secs / 3600:.4f}" if decode_s_per_hour > 0 else ""
     if name in ("cfg4", "cfg4s", "cfg4x2"):     # a 1-hour (or 6-minute) video at 8 fps sampled at 2 fps; planned at the model's frame size
         secs = frames * 4 / 8.0
-        video = f"synthetic://?frames={frames * 4}&h={fh}&w={fw}&fps=8&seed=1{dec}&decode_s={REFERENCE_DECODE_S_PER_HOUR * secs / 3600:.4f}"
+        video = f"synthetic://?frames={frames * 4}&h={fh}&w={fw}&fps=8&seed=1{dec}{pad(secs)}"
         warm = f"synthetic://?frames=256&h={fh}&w={fw}&fps=8&seed=2{dec}" if warm_video is None else warm_video
+    elif name == "cfg4ref":                     # the same hour of video, 1080x1920 source: the reference's own budget picks 224x420
+        secs = frames * 4 / 8.0
+        video = f"synthetic://?frames={frames * 4}&h=1080&w=1920&fps=8&seed=1{dec}{pad(secs)}"
+        warm = f"synthetic://?frames=256&h=1080&w=1920&fps=8&seed=2{dec}"
     else:
         secs = frames * 4 / 2.0
-        video = f"synthetic://?frames={frames * 4}&h=1080&w=1920&fps=2&seed=1{dec}&decode_s={REFERENCE_DECODE_S_PER_HOUR * secs / 3600:.4f}"
+        video = f"synthetic://?frames={frames * 4}&h=1080&w=1920&fps=2&seed=1{dec}{pad(secs)}"
         warm = video
+    if video_override is not None:              # e.g. a directory of JPEG frames (frames.ImageFolderVideoReader)
+        video = video_override
     res = {}
+
+    def messages(v, nf=None):
+        msg = video_messages(name, v, nf)
+        if entry_extra:
+            msg[0]["content"][0].pop("total_pixels", None)
+            msg[0]["content"][0].update(entry_extra)
+        return msg
+
     for mode in modes:
         overlap = mode == "overlapped"
-        # short clip of the same geometry (pinned ring, ViT GEMM plans), or the video itself
-        pipe.generate(video_messages(name, warm, 64 if warm != video else None), warm, max_new_tokens=1, overlap=overlap)
-        rd = open_video(video)
-        pipe.generate(video_messages(name, rd), rd, max_new_tokens=1, overlap=overlap)
+        # short clip of the same geometry (pinned ring, ViT GEMM plans), or the video itself.  cfg4ref's warm clip must be planned at the
+        # full video's frame size (the budget depends on the frame count): resized_height / resized_width in the entry
+        wm = video_messages(name, warm, 64 if warm != video else None)
+        if name == "cfg4ref":
+            wm[0]["content"][0].update(resized_height=fh, resized_width=fw)
+        pipe.generate(wm, warm, max_new_tokens=1, overlap=overlap)
+        rd = open_video(video) if lead else video
+        burner = HostStress(*stress) if (stress and lead) else None
+        if burner:
+            burner.__enter__()
+        try:
+            pipe.generate(messages(rd), rd, max_new_tokens=1, overlap=overlap)
+        finally:
+            if burner:
+                burner.__exit__()
+        if not lead:
+            continue
         res[mode] = _leg_record(pipe.last_timings, overlap, threads)
         res[mode]["producer"]["real_work_thread_seconds"] = round(getattr(rd, "work_seconds", 0.0), 2)
-        progress(f"video -> first token, {mode}: {res[mode]['ttft_ms']} ms")
+        if burner:
+            res[mode]["host_stress"] = {"numpy_threads": burner.numpy_threads, "python_threads_holding_the_gil": burner.python_threads,
+                                        "host_cores": os.cpu_count(), "numpy_iterations": sum(burner.iters[:burner.numpy_threads]),
+                                        "python_iterations": sum(burner.iters[burner.numpy_threads:])}
+        progress(f"video -> first token, {name} {mode}{' under host stress' if burner else ''}: {res[mode]['ttft_ms']} ms")
+    if not lead:
+        return None
     if "overlapped" in res and "sequential" in res:
         cost = res["sequential"]["fetch_all_frames_before_gpu_ms"]
         hidden = res["sequential"]["ttft_ms"] - res["overlapped"]["ttft_ms"]
         G = res["sequential"]["groups"]
         hideable = min(cost, res["sequential"]["group_loop_ms"] * (G - 1) / G)     # the last group's GPU work always follows the last frame
+        gl_o, gl_s = res["overlapped"]["group_loop_ms"], res["sequential"]["group_loop_ms"]
         res["overlap"] = {"producer_cost_ms": cost, "ttft_sequential_ms": res["sequential"]["ttft_ms"], "ttft_overlapped_ms": res["overlapped"]["ttft_ms"],
                           "hidden_ms": round(hidden, 2), "hidden_frac_of_producer_cost": round(hidden / cost, 3) if cost > 0 else None,
                           "hideable_ms": round(hideable, 2), "hidden_frac_of_hideable": round(hidden / hideable, 3) if hideable > 0 else None,
+                          "group_loop_ms_overlapped_over_sequential": round(gl_o / gl_s, 4) if gl_s > 0 else None,
                           "definition": "producer_cost = wall time of fetching every frame group before the GPU starts (sequential plugin); "
                                         "hidden = ttft(sequential) - ttft(overlapped); hideable = min(producer_cost, GPU time of all groups but "
-                                        "the last): a producer-bound video (GPU time < producer cost, e.g. cfg2) cannot hide more than its GPU time"}
+                                        "the last): a producer-bound video (GPU time < producer cost, e.g. cfg2) cannot hide more than its GPU time; "
+                                        "both plugins run the ViT exactly one group ahead of the LLM (round 4), so their GPU sides are the same schedule"}
     res["frame_source"] = (f"synthetic, costed: each of the {frames} sampled frames is produced at 1080x1920 and LANCZOS-resized (PIL) to {fh}x{fw} on "
-                           f"{threads} threads (QUICKCODEC_CORES), padded to {REFERENCE_DECODE_S_PER_HOUR} s per hour of video at that thread count "
-                           f"(the reference's QuickCodec figure; no codec in the image); video length {secs:.0f} s")
+                           f"{threads} threads (QUICKCODEC_CORES), " +
+                           (f"padded to {decode_s_per_hour} s per hour of video at that thread count (the reference's QuickCodec figure; no codec in "
+                            f"the image)" if decode_s_per_hour > 0 else "UN-PADDED: the real generate + resize work only") + f"; video length {secs:.0f} s")
     res["note"] = ("clock starts when the video is opened and stops when the first generated token id is on the host; ViT: Qwen2-VL 32-layer tower, "
                    "random weights.  producer.busy = time inside next(reader); producer.blocked = waiting for a ring slot (GPU-bound, not "
                    "producer-bound); gpu.stall_waiting_for_frames = main stream idle between two groups BEFORE the next group's frames were uploaded "
                    "(the only true frame wait); gpu.stall_waiting_for_vit = idle after that, until the group's ViT pass finished; vit_alone = "
-                   "the tower on one group with the GPU otherwise idle, x groups")
+                   "the tower on one group with the GPU otherwise idle, x groups; main_stream_gap_before_group_ms = distribution of the idle gap "
+                   "in front of each group on the LLM stream (late frames, late ViT, or an unscheduled launch thread)")
     return res
 
 
@@ -881,6 +972,64 @@ def attach_hbm_kernels(res, name, world):
                                                                  "traffic_bytes", "traffic_over_algorithmic")} for k, v in d["kernels"].items()}}
 
 
+def host_contention_leg(eng, device):
+    """Does the overlap survive a host that is actually busy?  (the costed source mostly sleeps.)  The 6-minute video
+    (cfg4s: 45 groups of 2240 tokens — short groups, so the launch thread matters MORE than on the 1-hour video), un-padded frame
+    source, overlapped plugin, three times: (a) idle host; (b) one numpy burner per host core + 2 pure-Python threads holding the GIL,
+    all running for the whole leg; (c) the same stress with the frames coming from 720 JPEG files (1080x1920, written once to /tmp) through
+    ImageFolderVideoReader — a real decode (libjpeg) + LANCZOS resize per frame.  Reported: prefill tokens/s incl. ViT, TTFT, the GPU's
+    wait for frames and the idle-gap distribution of the LLM stream; `gpu_loss_frac` = 1 - tok/s(stressed) / tok/s(idle)."""
+    import shutil
+    import tempfile
+    from concurrent.futures import ThreadPoolExecutor
+    cores = os.cpu_count() or 16
+    out = {"host_cores": cores}
+    out["idle_host"] = pipeline_leg("cfg4s", eng, device, modes=("overlapped",), decode_s_per_hour=0, vit_alone=False)["overlapped"]
+    out["stressed_host"] = pipeline_leg("cfg4s", eng, device, modes=("overlapped",), decode_s_per_hour=0, stress=(cores, 2), vit_alone=False)["overlapped"]
+    tmp = tempfile.mkdtemp(prefix="qp_jpeg_frames_", dir="/tmp")
+    try:
+        import numpy as np
+        from PIL import Image
+        tex = np.random.RandomState(5).randint(0, 256, (1080, 1920, 3), dtype=np.uint8)
+        tex = np.asarray(Image.fromarray(tex).resize((240, 135)).resize((1920, 1080), Image.BILINEAR))   # smooth: compresses like a photo
+
+        def write(i):
+            Image.fromarray(np.roll(tex, (i * 3) % 1080, axis=0)).save(os.path.join(tmp, f"frame_{i:06d}.jpg"), quality=85)
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=min(32, cores)) as pool:
+            list(pool.map(write, range(720)))
+        with open(os.path.join(tmp, "fps.txt"), "w") as f:
+            f.write("2.0")
+        size_mb = sum(os.path.getsize(os.path.join(tmp, f)) for f in os.listdir(tmp)) / 1e6
+        leg = pipeline_leg("cfg4s", eng, device, modes=("overlapped",), decode_s_per_hour=0, stress=(cores, 2), vit_alone=False, video_override=tmp,
+                           entry_extra={"resized_height": 392, "resized_width": 560})
+        out["stressed_host_jpeg_folder"] = leg["overlapped"]
+        out["stressed_host_jpeg_folder"]["frames_on_disk"] = {"files": 720, "megabytes": round(size_mb, 1), "write_seconds": round(time.perf_counter() - t0, 1),
+                                                              "size": "1080x1920 JPEG q85"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    a, b, c = (out[k]["prefill_tokens_per_s_with_vit"] for k in ("idle_host", "stressed_host", "stressed_host_jpeg_folder"))
+    out["gpu_loss_frac"] = {"stressed_vs_idle": round(1 - b / a, 4), "stressed_jpeg_vs_idle": round(1 - c / a, 4)}
+    out["what"] = ("cfg4s (6-minute video, 45 groups), un-padded frame source, overlapped plugin; stress = one numpy burner per host core + 2 "
+                   "pure-Python spinners holding the GIL for the whole leg; the producer is a Python thread whose only work is next(reader) + a "
+                   "GIL-free memcpy + three stream-ordered enqueues (DESIGN 1)")
+    return out
+
+
+def secondary_cfg4ref(args, device, weights):
+    """The reference's OWN operating point for the 1-hour video: 7200 frames at the reference's pixel budget -> 224x420,
+    432 015 tokens — one full timed pass (its own roofline fraction) + the overlapped video -> first token through the front end."""
+    a = argparse.Namespace(**vars(args)); a.steps, a.warmup, a.window = 10, 1, None
+    res, eng, ctx = measure(a, "cfg4ref", device, 0, 1, "single", (1, 1), None, weights=weights, timing="inline")
+    out = {"workload": describe("cfg4ref"), "prefill_tokens": ctx["tokens"], "steps": 10, "step": "1/10 of the video's group loop", **res,
+           "beside": "the reference README's '1-hour video ~ 20 s' claim (README.md:44; other hardware, real checkpoint, its own decoder)"}
+    if not args.no_pipeline:
+        leg = pipeline_leg("cfg4ref", eng, device, modes=("overlapped",), vit_alone=False)
+        out["video_to_first_token"] = leg
+        out["value_with_vit"] = leg["overlapped"]["prefill_tokens_per_s_with_vit"]
+    return out
+
+
 def secondary_cfg2(args, device, weights):
     """Round 1's headline (BASELINE.json configs[1]) kept as a secondary block: 5 full passes + the front-end TTFT."""
     a = argparse.Namespace(**vars(args)); a.steps, a.warmup, a.window = 5, 2, None
@@ -998,7 +1147,7 @@ def main():
             torch.cuda.empty_cache()
         if args.parallel in ("both", "auto"):
             eff_sp = probe_sp_efficiency(name, device, rank, world, single_dev)
-            layout = choose_layout(n_groups_, world, eff_sp)
+            layout = choose_layout(n_groups_, world, eff_sp, PRESETS[CONFIGS[name][0]].n_layers)
         else:
             layout = {"sp": (1, world), "pp": (world, 1)}[args.parallel]
         parallel = "sp" if layout[0] == 1 else "pp" if layout[1] == 1 else "ppsp"
@@ -1015,7 +1164,8 @@ def main():
     attach_traffic(res.get("roofline"), name, world)
     attach_hbm_kernels(res, name, world)
 
-    legs = {"decode": None, "peaked": None, "video_to_first_token": None, "cfg2": None, "cpu_baseline": None}
+    legs = {"decode": None, "peaked": None, "video_to_first_token": None, "host_contention": None, "cfg4ref": None, "cfg2": None,
+            "cpu_baseline": None}
     emitted = threading.Lock()
 
     def emit(note=None):
@@ -1041,6 +1191,17 @@ def main():
             "algorithmic_tflop_per_pass": res["algorithmic_tflop_per_pass"], "mfma_frac_whole_pass": res["mfma_frac_whole_pass"],
             "roofline": res.get("roofline"),
         }
+        v2f = legs.get("video_to_first_token")
+        if v2f and v2f.get("overlapped"):
+            # the reference's own definition of the metric: total_prefill spans H2D + ViT + all layers (qwen25_lvu.py:674-717)
+            out["value_with_vit"] = v2f["overlapped"]["prefill_tokens_per_s_with_vit"]
+            out["value_with_vit_definition"] = ("prefilled tokens / device-synchronised group loop of the overlapped front end (frame upload + GPU "
+                                                "patchify + ViT + all layers + prune, every group) — the reference's total_prefill span; `value` is the same "
+                                                "loop fed with ViT-output embeddings resident in HBM")
+            out["ttft_ms"] = v2f["overlapped"]["ttft_ms"]
+        from quickvideo_amd.engine import _TUNE_FAILURES
+        if _TUNE_FAILURES:
+            out["gemm_plan_failures"] = {str(k): v for k, v in _TUNE_FAILURES.items()}
         rec = FIRST_TOKEN_ON_RECORD.get(name)
         if rec:
             out["first_token_check"] = {"on_record": rec[0], "match": res["first_token"] in rec[0], "source": rec[1]}
@@ -1088,6 +1249,12 @@ def main():
         if not args.no_pipeline:
             legs["video_to_first_token"] = pipeline_leg(name, eng, device)
             progress("video -> first token leg done")
+        if not args.no_pipeline and not args.no_secondary and name in ("cfg4", "cfg4s") and CONFIGS[name][0] == "qwen2-vl-7b":
+            legs["host_contention"] = host_contention_leg(eng, device)
+            progress("host contention leg done")
+        if not args.no_secondary and name == "cfg4":
+            legs["cfg4ref"] = secondary_cfg4ref(args, device, eng.w)
+            progress("secondary cfg4ref block done (the reference's own operating point)")
         if not args.no_secondary and name != "cfg2" and CONFIGS[name][0] == "qwen2-vl-7b":
             legs["cfg2"] = secondary_cfg2(args, device, eng.w)
             progress("secondary cfg2 block done")
@@ -1095,6 +1262,27 @@ def main():
             legs["cpu_baseline"] = cpu_baseline(name)
             progress("cpu baseline done")
         aux_done.set()
+    elif not args.no_pipeline and not args.window:
+        # N > 1: video -> first token THROUGH THE PLUGIN'S PIPELINE on the same ranks (rank 0 owns the frame source; frames scattered by
+        # frame pair, ViT data-parallel + all-gather, the layout's engine, the deciding rank's token broadcast).  The measured engines
+        # are dropped first: the pipeline builds its own from a model loaded the way `LVU(model_init_kwargs={"parallel": ...})` does.
+        from quickvideo_amd.lvu import load_native_model
+        del eng
+        ctx.pop("embeds", None)
+        torch.cuda.empty_cache()
+        mode = "tp" if parallel == "tp" else {"both": "auto", "auto": "auto", "sp": "sp", "pp": "pp"}[args.parallel]
+        mdl = load_native_model(f"synthetic:{CONFIGS[name][0]}", device=device, seed=0, parallel=mode)
+        mdl.parallel.sp_efficiency = eff_sp
+        legs["video_to_first_token"] = pipeline_leg(name, None, device, model=mdl, vit_alone=False)
+        progress("video -> first token leg done")
+        if tp_block is not None and parallel != "tp":               # ... and once through the north_star's contract layout
+            del mdl
+            torch.cuda.empty_cache()
+            mdl = load_native_model(f"synthetic:{CONFIGS[name][0]}", device=device, seed=0, parallel="tp")
+            v = pipeline_leg(name, None, device, modes=("overlapped",), model=mdl, vit_alone=False)
+            if rank == 0:
+                tp_block["video_to_first_token"] = v
+            progress("video -> first token leg (tp) done")
     emit()
     if world > 1 or preflight is not None:
         torch.distributed.destroy_process_group()

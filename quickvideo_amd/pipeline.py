@@ -76,6 +76,9 @@ class Timings:
     vit_span: float = 0.0              # sum of ViT(g) start->end on its own stream WHILE the prefill shares the CUs (contended)
     vit_uncontended: float = 0.0       # ViT of one group replayed alone after the run, x groups: what the tower costs by itself
                                        # (only with PrefillPipeline.measure_vit_alone; 0 otherwise)
+    group_gaps: Optional[list] = None  # per group: seconds the main stream sat idle in front of it (prefill(g-1) end -> prefill(g) start):
+                                       # a late frame, a late ViT pass, or a launch thread that was not scheduled (host contention)
+    layout: str = "single"             # multi-GPU grid this video ran on (parallel.py)
 
 
 class _GpuProgress(threading.Thread):
@@ -582,6 +585,7 @@ class PrefillPipeline:
             self._device_breakdown(tm, origin, trace)
             if self.measure_vit_alone and last_frames is not None and not par.on:
                 tm.vit_uncontended = self._vit_alone(last_frames) * G
+        tm.layout = self.last_layout
         self.last_timings = tm
         return out
 
@@ -592,9 +596,11 @@ class PrefillPipeline:
         could not have started ViT(g) (frame wait, the producer's fault); after it the ViT simply was not finished (the tower's)."""
         at = lambda e: origin.elapsed_time(e) * 1e-3
         prev_end = 0.0
+        tm.group_gaps = []
         for h2d, v0, v1, p0, p1 in trace:
             t_h2d, t_v0, t_v1, t_p0, t_p1 = at(h2d), at(v0), at(v1), at(p0), at(p1)
             stall = max(0.0, t_p0 - prev_end)
+            tm.group_gaps.append(stall)
             frames_part = min(stall, max(0.0, t_h2d - prev_end))
             tm.gpu_stall_frames += frames_part
             tm.gpu_stall_vit += stall - frames_part

@@ -42,6 +42,13 @@ def test_bench_two_ranks_on_one_gpu_reproduce_the_single_gpu_token():
     assert two["n_gpus"] == 2 and two["rccl_ranks"]["world_size"] == 2 and two["rccl_ranks"]["backend"] == "gloo"
     assert two["tp"]["parallelism"] == "tp2" and "sp_efficiency_probe" in two
     assert two["first_token"] == one["first_token"] == two["tp"]["first_token"]              # same model under every layout
+    # round 4: the N > 1 line carries video -> first token THROUGH THE PLUGIN'S PIPELINE (rank-0 producer, scattered frames, data-parallel
+    # ViT + all-gather, the layout's engine), both plugins for the main layout and the overlapped one for the tp contract layout
+    v = two["video_to_first_token"]
+    assert v["overlapped"]["ttft_ms"] > 0 and v["sequential"]["ttft_ms"] > 0 and v["overlapped"]["layout"].startswith("pp")
+    assert v["overlapped"]["tokens"] == two["config"]["prefill_tokens"] and v["overlapped"]["groups"] == two["config"]["groups"]
+    assert two["value_with_vit"] == v["overlapped"]["prefill_tokens_per_s_with_vit"] and two["ttft_ms"] == v["overlapped"]["ttft_ms"]
+    assert two["tp"]["video_to_first_token"]["overlapped"]["layout"] == "tp2"
 
 
 def test_bench_prints_its_line_when_an_auxiliary_leg_overruns():

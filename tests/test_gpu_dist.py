@@ -206,3 +206,56 @@ def test_tp2_ranks_on_one_gpu_reproduce_single_process_kept_lists():
     assert np.array_equal(ret["kept0"][0], ref[0]), f"layer-0 kept list differs from the single-process engine (overlap {ov0:.4f})"
     assert same_rows
     assert ov1 >= 0.95, ov1
+
+
+# ---------------------------------------------------------------- round 4: the layouts behind the plugin, two ranks sharing the GPU
+_PLUGIN_VIDEO = "synthetic://?frames=96&h=112&w=168&fps=2&seed=3"
+
+
+def _plugin_worker(rank, world, port, mode, ret):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        import torch.distributed as dist
+        torch.cuda.set_device(0)
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        import lvu
+        cfg = lvu.LVUConfig("synthetic:tiny", top_p=0.5, video_group_size=12, num_frames=48)
+        obj = lvu.LVU(cfg, model_init_kwargs={"device": "cuda:0", "seed": 3, "parallel": mode})
+        out = obj.generate("What happens in the video?", _PLUGIN_VIDEO, max_new_tokens=4)
+        pipe = obj._pipeline
+        torch.cuda.synchronize()
+        ret[f"{mode}{rank}"] = (out, pipe.last_layout, list(pipe.model.engine.arena.len), pipe.last_timings.ttft)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+    except BaseException as e:
+        import traceback
+        ret[f"error_{mode}{rank}"] = "".join(traceback.format_exception(type(e), e, e.__traceback__))
+        raise
+
+
+def test_plugin_generate_two_ranks_on_one_gpu_equals_single_process():
+    """`LVU(..., model_init_kwargs={"parallel": mode}).generate()` on TWO ranks sharing the GPU (gloo) reproduces
+    the single-process answer THROUGH THE PIPELINE — rank-0 producer + pinned ring, frames to the other rank, data-parallel ViT on the
+    HIP kernels + all-gather, the layout's engine with its groups, the deciding rank's token broadcast, eager decode on every layout.
+    pp / sp move rows between identical replicas (same kernels, same numbers up to the attention tiling): tokens equal.  tp sums
+    head / column partials in a different order (bf16 all-reduce): the FIRST token must match, the answer is compared and reported."""
+    ret = mp.Manager().dict()
+    mp.spawn(_plugin_worker, args=(1, _free_port(), "single", ret), nprocs=1, join=True)
+    assert "error_single0" not in ret, ret.get("error_single0")
+    out1, lay1, lens1, _ = ret["single0"]
+    assert lay1 == "single" and out1[0].count("<tok_") == 4
+    for mode, layout in (("pp", "pp2xsp1"), ("sp", "pp1xsp2"), ("tp", "tp2")):
+        mp.spawn(_plugin_worker, args=(2, _free_port(), mode, ret), nprocs=2, join=True)
+        for r in range(2):
+            assert f"error_{mode}{r}" not in ret, ret.get(f"error_{mode}{r}")
+            out, lay, lens, ttft = ret[f"{mode}{r}"]
+            assert lay == layout and ttft > 0
+            assert out == ret[f"{mode}0"][0]                                    # both ranks return the same answer
+            assert out[0].split(" ")[0] == out1[0].split(" ")[0], (mode, out, out1)   # the first token is the single-process one
+            if mode != "tp":
+                assert out == out1, (mode, out, out1)
+            if mode == "sp":
+                assert lens == lens1
+        print(mode, ret[f"{mode}0"][0], "single:", out1)
