@@ -80,13 +80,18 @@ SIGNATURES = {
 }
 
 
-def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
-    """dlopen the C-ABI library and bind every symbol the header declares (no compute, no GPU needed)."""
+def load_library(path: str = LIB_PATH, hold_gil: bool = False) -> ctypes.CDLL:
+    """dlopen the C-ABI library and bind every symbol the header declares (no compute, no GPU needed).
+    hold_gil: bind through ctypes.PyDLL — the interpreter lock is KEPT across the call.  The operator object does that for its
+    kernel-launch entry points: a launch returns in microseconds, whereas dropping the lock around each of the ~350 calls of a frame
+    group hands it to any other Python thread that wants it, and getting it back costs up to a switch interval (5 ms) EACH time
+    (measured with one busy Python thread beside the group loop: bench.py host_contention).  Long host-side calls (qp_host_memcpy in the
+    producer thread) stay on the lock-free binding."""
     if not os.path.exists(path):
         raise QuickPrefillUnavailable(
             f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             f"(or `make -C quickvideo_amd/csrc`). There is no CPU fallback for the QuickPrefill hot path.")
-    lib = ctypes.CDLL(path)
+    lib = (ctypes.PyDLL if hold_gil else ctypes.CDLL)(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)            # AttributeError if the .so does not export a declared symbol
         fn.restype, fn.argtypes = res, args
@@ -120,7 +125,7 @@ class QuickPrefillOps:
         if not torch.cuda.is_available():
             raise QuickPrefillUnavailable("no HIP device visible to torch: the QuickPrefill engine needs an MI355X (gfx950); "
                                           "there is no CPU fallback")
-        self.lib = load_library()
+        self.lib = load_library(hold_gil=os.environ.get("QP_CTYPES_RELEASE_GIL") != "1")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         h = _vp()
         self._check(self.lib.qp_create(ctypes.byref(h), self.device.index or 0))
