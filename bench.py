@@ -228,6 +228,7 @@ def probe_sp_efficiency(name, device, rank, world, single_dev):
         del eng
     for s, t in times.items():
         eff[s] = round(times[1] / (s * t), 4)
+    probe_sp_efficiency.layer_ms_mid_video = times[1] / 2 * 1e3         # one decoder layer on one GPU, this group size, mid-video prefix
     return eff
 
 
@@ -593,50 +594,50 @@ def _leg_record(t, overlap, reader_threads):
 
 
 class HostStress:
-    """Saturates the host while a pipeline leg runs, the way a decoder pool does: `native_threads` threads of GIL-FREE native work
-    (sha-256 over a shared 64 MB buffer: ~40 ms per call without the GIL, so the cores are busy and the interpreter lock is barely
-    touched) plus `python_threads` pure-Python spinners that HOLD the GIL between switch intervals — what the reference's processor
-    thread does to the launching thread (qwen25_lvu_interleaved.py:303-340).  `max_seconds`: the burners stop by themselves after that
-    long, so a starved leg still ends (reported as `cut_after_s`)."""
+    """Saturates the host while a pipeline leg runs.  `native` burner PROCESSES (one per host core: `python -c` busy loops in their own
+    interpreters — they share nothing with this process, exactly like a decoder's native worker pool or another job on the box) keep
+    every core busy; `python_threads` pure-Python spinner THREADS in this process hold the interpreter lock between switch intervals —
+    what the reference's HF-processor thread does to the launching thread (qwen25_lvu_interleaved.py:303-340).  Every burner ends by
+    itself after `max_seconds`, so a starved leg still finishes (reported as `cut_after_s`).
+    (A first version ran the core burners as 256 Python THREADS of GIL-free sha-256 calls: each still takes the lock twice per call, and a
+    lock holder that the saturated scheduler parks keeps every other thread of the process waiting — the leg ran 45x slower, an artefact
+    of the stress harness, not of the pipeline: profiles/r4_host_contention_thread_burners.json.)"""
+    CODE = "import time,sys\nt=time.perf_counter()+float(sys.argv[1])\nx=0\nwhile time.perf_counter()<t:\n for k in range(200000): x=(x*1103515245+k)&0xffffffff\n"
 
-    def __init__(self, native_threads, python_threads=1, max_seconds=120.0):
-        self.stop, self.threads = threading.Event(), []
-        self.iters = [0] * (native_threads + python_threads)
-        self.buf = bytes(64 << 20)
-        for i in range(native_threads):
-            self.threads.append(threading.Thread(target=self._native, args=(i,), daemon=True))
+    def __init__(self, native, python_threads=1, max_seconds=90.0):
+        self.native, self.python_threads, self.max_seconds = native, python_threads, max_seconds
+        self.stop, self.threads, self.procs, self.iters, self.cut, self.t0 = threading.Event(), [], [], [0] * python_threads, False, None
         for i in range(python_threads):
-            self.threads.append(threading.Thread(target=self._python, args=(native_threads + i,), daemon=True))
-        self.native_threads, self.python_threads, self.max_seconds, self.cut = native_threads, python_threads, max_seconds, False
-        self.t0 = None
-
-    def _expired(self):
-        if time.perf_counter() - self.t0 > self.max_seconds:
-            self.cut = True
-            self.stop.set()
-        return self.stop.is_set()
-
-    def _native(self, i):
-        import hashlib
-        while not self._expired():
-            hashlib.sha256(self.buf).digest()
-            self.iters[i] += 1
+            self.threads.append(threading.Thread(target=self._python, args=(i,), daemon=True))
 
     def _python(self, i):
         x = 0
-        while not self._expired():
+        while not self.stop.is_set():
+            if time.perf_counter() - self.t0 > self.max_seconds:
+                self.cut = True
+                break
             for k in range(20000):
                 x = (x * 1103515245 + k) & 0xffffffff
             self.iters[i] += 1
 
     def __enter__(self):
         self.t0 = time.perf_counter()
+        self.procs = [subprocess.Popen([sys.executable, "-S", "-c", self.CODE, str(self.max_seconds)], stdout=subprocess.DEVNULL,
+                                       stderr=subprocess.DEVNULL) for _ in range(self.native)]
+        time.sleep(0.5)                                             # let them all reach their loops
         for t in self.threads:
             t.start()
         return self
 
     def __exit__(self, *exc):
         self.stop.set()
+        if time.perf_counter() - self.t0 > self.max_seconds:
+            self.cut = True
+        for p in self.procs:                                        # exactly the processes started above
+            if p.poll() is None:
+                p.kill()
+        for p in self.procs:
+            p.wait()
         for t in self.threads:
             t.join(timeout=5)
 
@@ -717,9 +718,8 @@ def pipeline_leg(name, eng, device, modes=("overlapped", "sequential"), warm_vid
         res[mode] = _leg_record(pipe.last_timings, overlap, threads)
         res[mode]["producer"]["real_work_thread_seconds"] = round(getattr(rd, "work_seconds", 0.0), 2)
         if burner:
-            res[mode]["host_stress"] = {"native_gil_free_threads": burner.native_threads, "python_threads_holding_the_gil": burner.python_threads,
-                                        "host_cores": os.cpu_count(), "native_iterations_64MB_sha256": sum(burner.iters[:burner.native_threads]),
-                                        "python_iterations": sum(burner.iters[burner.native_threads:]),
+            res[mode]["host_stress"] = {"burner_processes": burner.native, "python_threads_holding_the_gil": burner.python_threads,
+                                        "host_cores": os.cpu_count(), "python_thread_iterations": sum(burner.iters),
                                         "cut_after_s": burner.max_seconds if burner.cut else None}
         progress(f"video -> first token, {name} {mode}{' under host stress' if burner else ''}: {res[mode]['ttft_ms']} ms")
     if not lead:
@@ -987,7 +987,7 @@ def attach_hbm_kernels(res, name, world):
 def host_contention_leg(eng, device):
     """Does the overlap survive a host that is actually busy?  (the costed source mostly sleeps.)  The 6-minute video
     (cfg4s: 45 groups of 2240 tokens — short groups, so the launch thread matters MORE than on the 1-hour video), un-padded frame
-    source, overlapped plugin, four times: (a) idle host; (b) one GIL-free native burner per host core for the whole leg; (c) the same
+    source, overlapped plugin, four times: (a) idle host; (b) one burner PROCESS per host core for the whole leg; (c) the same
     plus ONE pure-Python thread holding the interpreter lock; (d) as (b) with the frames coming from 720 JPEG files (1080x1920, written
     once to /tmp) through ImageFolderVideoReader — a real decode (libjpeg) + LANCZOS resize per frame.  Reported: prefill tokens/s incl. ViT, TTFT, the GPU's
     wait for frames and the idle-gap distribution of the LLM stream; `gpu_loss_frac` = 1 - tok/s(stressed) / tok/s(idle)."""
@@ -1022,8 +1022,8 @@ def host_contention_leg(eng, device):
         shutil.rmtree(tmp, ignore_errors=True)
     a = out["idle_host"]["prefill_tokens_per_s_with_vit"]
     out["gpu_loss_frac"] = {k: round(1 - out[k]["prefill_tokens_per_s_with_vit"] / a, 4) for k in out if isinstance(out[k], dict) and k != "idle_host"}
-    out["what"] = ("cfg4s (6-minute video, 45 groups), un-padded frame source, overlapped plugin; cores_saturated = one GIL-free native burner per "
-                   "host core (sha-256 over 64 MB: what a decoder pool does to the machine) for the whole leg; ...and_one_python_thread = the same "
+    out["what"] = ("cfg4s (6-minute video, 45 groups), un-padded frame source, overlapped plugin; cores_saturated = one burner process per "
+                   "host core (a busy loop in its own interpreter: what a decoder pool or another job does to the machine) for the whole leg; ...and_one_python_thread = the same "
                    "plus ONE pure-Python spinner that holds the interpreter lock between switch intervals (what the reference's HF-processor "
                    "thread does); jpeg_folder = frames decoded from 720 JPEG files by ImageFolderVideoReader under the saturated host.  The "
                    "product's own producer is a Python thread whose only work is next(reader) + a GIL-free memcpy + three stream-ordered "
@@ -1232,6 +1232,21 @@ def main():
                                  "note": "backend 'nccl' is RCCL over xGMI on ROCm; 'gloo' only under QP_BENCH_SINGLE_DEVICE=1"}
             if eff_sp is not None:
                 out["sp_efficiency_probe"] = {str(k): v for k, v in eff_sp.items()}
+                # the cost model --parallel auto chose the grid with (quickvideo_amd/parallel.py): fill/drain x heaviest stage x sp efficiency,
+                # for every factorisation of the world, and the predicted time of each pipeline stage for a mid-video group
+                L_, lm = spec.n_layers, getattr(probe_sp_efficiency, "layer_ms_mid_video", None)
+                cand, pp_ = {}, 1
+                while pp_ <= world:
+                    if world % pp_ == 0 and (world // pp_) in eff_sp and pp_ <= L_:
+                        cand[f"pp{pp_}xsp{world // pp_}"] = round(qp_parallel.layout_efficiency(len(plan.tokens), pp_, world // pp_, eff_sp, L_), 4)
+                    pp_ *= 2
+                stages = [pp_layer_split(L_, layout[0], s_) for s_ in range(layout[0])]
+                out["layout_cost_model"] = {"predicted_efficiency": cand, "chosen": f"pp{layout[0]}xsp{layout[1]}",
+                                            "layers_per_stage": [b - a for a, b in stages],
+                                            "predicted_stage_ms_per_mid_video_group": None if lm is None else
+                                            [round((b - a) * lm / max(layout[1] * eff_sp.get(layout[1], 1.0), 1e-9), 2) for a, b in stages],
+                                            "not_in_the_stage_model": "ViT (data-parallel over ALL ranks in every layout: an equal share per rank), "
+                                                                      "embedding gather and the prompt tail's lm_head (a few rows, once per video)"}
             if tp_block is not None and parallel != "tp":
                 out["tp"] = tp_block
         for k, v in legs.items():

@@ -83,6 +83,12 @@ class QuickPrefillEngine:
         self.tp_group = tp_group
         self.tp_size = weights.tp_size
         self.tp_rank = weights.tp_rank
+        # tensor parallel: the two row-parallel projections of a layer (o_proj, down_proj) are cut into `tp_chunks` row blocks and block i's
+        # all-reduce is issued asynchronously while block i+1's GEMM runs (rows are independent in a GEMM and an all-reduce is
+        # element-wise, so the result is the unsplit one — bit for bit on 1 and 2 ranks; on more ranks a ring all-reduce adds the ranks'
+        # partials in an order that depends on where an element sits in the buffer, like any change of message size would).
+        # QP_TP_CHUNKS=1 is the unsplit form (both all-reduces fully exposed on the compute stream) for A/B timing.
+        self.tp_chunks = max(1, int(os.environ.get("QP_TP_CHUNKS", "2")))
         # group-token parallelism ("sp"): weights and the KV arena are replicated (288 GB of HBM per GPU), every rank takes a
         # contiguous slice of each group's tokens through all layers and the ranks exchange only the group's new K/V rows
         # (+ key sums) once per layer — ~14x fewer bytes on xGMI than the two [n, d] all-reduces of tensor parallelism.
@@ -332,6 +338,29 @@ class QuickPrefillEngine:
         if self.tp_on:
             torch.distributed.all_reduce(t, group=self.tp_group)
 
+    def _linear_reduced(self, key: str, x: torch.Tensor, w: torch.Tensor, out: torch.Tensor) -> list:
+        """Row-parallel projection + tensor-parallel all-reduce of `out` [n, d], overlapped: -> outstanding all-reduce handles (wait on them
+        before `out` is read: _wait).  RCCL runs a collective on its own stream behind an event of the issuing stream, so all-reduce(block i)
+        proceeds beside GEMM(block i+1); only the LAST block's all-reduce is exposed (1 / tp_chunks of the message)."""
+        n = x.shape[0]
+        chunks = self.tp_chunks if (self.tp_on and n >= 128 * self.tp_chunks) else 1
+        if chunks == 1:
+            self._linear(key, x, w, out)
+            self._all_reduce(out)
+            return []
+        step = (-(-n // chunks) + 63) // 64 * 64
+        works = []
+        for r0 in range(0, n, step):
+            r1 = min(n, r0 + step)
+            self._linear(key, x[r0:r1], w, out[r0:r1])
+            works.append(torch.distributed.all_reduce(out[r0:r1], group=self.tp_group, async_op=True))
+        return works
+
+    @staticmethod
+    def _wait(works: list):
+        for wk in works:
+            wk.wait()                                # RCCL: the compute stream waits for the collective's event (no host block)
+
     def _global_sumsq(self, n: int) -> (torch.Tensor, int):
         """[Hkv_total, n] per-head sums in ascending head order, identical on every rank (partials are
         all-gathered and added in fixed head order so the norm is bit-stable across TP degrees)."""
@@ -397,6 +426,9 @@ class QuickPrefillEngine:
                 new_stride = n * D
                 if self.norm_source == 1:                                    # vector_norms*: score the value rows (utils.py:117-126)
                     ops.key_sumsq(vn, n * D, 0, n, self.hkv, D, self.b_ss)
+                # tensor parallel: the key sums cross the ranks NOW (they only depend on the RoPE'd keys), so that this small all-gather
+                # is not queued behind the o_proj all-reduces on the collective stream and the prune can run beside them
+                ss_pre = self._global_sumsq(n) if not fuse else None
             else:                                                            # append in place                (:56-58)
                 kc, vc = self.arena.k(l), self.arena.v(l)
                 ops.rope_append(qkv, cos, sin, self.hq, self.hkv, D, q, kc, vc, self.arena.head_stride, past, None)
@@ -409,8 +441,7 @@ class QuickPrefillEngine:
             ops.prefill_attn(q, self.arena.k(l), self.arena.v(l), self.arena.head_stride, past_attn, kn, vn, new_stride, n, self.hq,
                              self.hkv, D, scale, att)                        # :61-62, :102-112
             o = self.b_o[:n]
-            self._linear("o", att.view(n, self.hq * D), lw.w_o, o)           # o_proj                        (:114-115)
-            self._all_reduce(o)
+            o_works = self._linear_reduced("o", att.view(n, self.hq * D), lw.w_o, o)   # o_proj + all-reduce    (:114-115)
             prune_hidden = (k_keep is not None and cfg.enable and isinstance(cfg.prefill_prune_starting_layer, int)
                             and cfg.prefill_prune_starting_layer >= 0 and self.l0 + l >= cfg.prefill_prune_starting_layer)   # GLOBAL layer index
             if k_keep is not None:                                           # post_process_kv_cache         (:183-192)
@@ -418,7 +449,7 @@ class QuickPrefillEngine:
                 if fuse:
                     self._prune(None, 0, n, k_keep, kn, vn, n * D, l, past, idx, keys_ready=True)
                 else:
-                    ss_all, heads_total = self._global_sumsq(n)
+                    ss_all, heads_total = ss_pre
                     self._prune(ss_all, heads_total, n, k_keep, kn, vn, n * D, l, past, idx)
                 self.arena.len[l] = past + k_keep
                 if self.kept_trace is not None:
@@ -427,6 +458,7 @@ class QuickPrefillEngine:
                 self.arena.len[l] = past + n
                 if self.kept_trace is not None:
                     self.kept_trace.append((l, None))
+            self._wait(o_works)                                              # (the prune above ran beside the last block's all-reduce)
             if prune_hidden:                                                 # utils.py:292-331, 344-372
                 ops.add_inplace(h, o)
                 hsel ^= 1
@@ -446,8 +478,7 @@ class QuickPrefillEngine:
             act = self.b_act[:n]
             self._gate_up_swiglu(x2, lw, act)                                # gate & up, act(gate) * up      (:197)
             dn = self.b_dn[:n]
-            self._linear("down", act, lw.w_down, dn)
-            self._all_reduce(dn)
+            self._wait(self._linear_reduced("down", act, lw.w_down, dn))
             delta = dn
             if self.hidden_trace is not None:                                # the layer's output = h + MLP (the add itself is deferred)
                 self.hidden_trace.append((l, h.float() + dn.float()))

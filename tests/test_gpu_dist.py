@@ -70,7 +70,18 @@ def _nccl_world1_worker(rank, port, ret):
         base = _run_engine(mk(), plan, pos, embeds)
         # tensor parallel layout on a 1-rank RCCL group: 2 x all_reduce bf16 [n, d] + all_gather_into_tensor fp32 [Hkv, n] per layer
         grp = dist.new_group(ranks=[0])                                                  # bench.py builds stage groups like this
+        os.environ["QP_TP_CHUNKS"] = "1"                                                   # unsplit: bit-comparable with the plain engine
         tp = _run_engine(mk(tp_group=grp), plan, pos, embeds)
+        # round 4: the projections in two row blocks, block 0's all-reduce ASYNCHRONOUS on RCCL's stream beside block 1's GEMM
+        os.environ["QP_TP_CHUNKS"] = "2"
+        calls, real = [], dist.all_reduce
+        dist.all_reduce = lambda t_, *a, **kw: (calls.append((tuple(t_.shape), bool(kw.get("async_op", False)))), real(t_, *a, **kw))[1]
+        try:
+            tp2 = _run_engine(mk(tp_group=grp), plan, pos, embeds)
+        finally:
+            dist.all_reduce = real
+            os.environ.pop("QP_TP_CHUNKS")
+        ret["tp2"], ret["tp2_calls"] = tp2, calls
         # group-token parallel layout: all_gather_into_tensor of the uint8 K|V|sums exchange block + qp_sp_unpack per layer
         sp = _run_engine(mk(sp_group=grp, sp_rank=0, sp_size=1), plan, pos, embeds)
         # the remaining calls bench.py makes around the engine
@@ -108,6 +119,13 @@ def test_every_engine_collective_on_nccl_world_size_1():
             assert len(set(a.tolist()) & set(c.tolist())) / len(a) >= 0.98                 # sp: other attention tiling -> rounding
     assert np.array_equal(l0, l1), float(np.max(np.abs(l0 - l1)))
     assert np.max(np.abs(l0 - l2)) <= 4e-2
+    # the row-block form with asynchronous all-reduces (the default under tensor parallelism): same tokens kept, logits to GEMM-tiling noise
+    l3, k3, n3 = ret["tp2"]
+    assert n3 == n0 and np.max(np.abs(l0 - l3)) <= 4e-2
+    for a, b in zip(k0, k3):
+        assert (a is None) == (b is None) and (a is None or len(set(a.tolist()) & set(b.tolist())) / len(a) >= 0.98)
+    blocks = [c for c in ret["tp2_calls"] if c[0][0] >= 128]
+    assert blocks and all(is_async for _, is_async in blocks) and len(blocks) == 3 * 3 * 2 * 2     # 3 groups x 3 layers x (o, down) x 2 blocks
     assert ret["tok"] == int(np.argmax(l0)) and ret["max"] == 1.5
 
 
