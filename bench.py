@@ -942,6 +942,59 @@ def measure(args, name, device, rank, world, parallel, layout, group, weights=No
     return res, eng, ctx
 
 
+def collect_attention_traffic(name, spec, plan, cfg):
+    """`roofline.traffic` measured IN THIS RUN when rocprofv3 is on PATH: two child runs of this script over a
+    two-group mid-video window from a fast-forwarded KV arena (`--window`), one per TCC counter — FETCH_SIZE and WRITE_SIZE need separate
+    passes (MI355X_MICROARCH.md, HBM section), collected with --kernel-trace only, no other trace domain.  gfx950 correction as that guide
+    prescribes: read bytes = 2 x FETCH_SIZE x 1024 (wide coalesced loads are counted at half), write bytes = WRITE_SIZE x 1024.
+    -> dict or None (no rocprofv3, QP_BENCH_NO_PMC=1, or a failed pass: the caller then falls back to the committed figures, labelled)."""
+    import csv
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if exe is None or os.environ.get("QP_BENCH_NO_PMC") == "1":
+        return None
+    G = len(plan.tokens)
+    if G < 8:
+        return None
+    g0 = G // 2
+    ks = [effective_k(n, cfg, 0, spec.n_layers) or n for n in plan.tokens]
+    P, n = sum(ks[:g0]), plan.tokens[g0]
+    alg = 2 * (n * spec.n_heads * spec.head_dim * 2) + 2 * ((P + ks[g0] // 2 + n) * spec.n_kv_heads * spec.head_dim * 2)   # Q + O rows, K + V rows (mean prefix of the 2 groups)
+    tmp = tempfile.mkdtemp(prefix="qp_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", QP_BENCH_NO_PMC="1")
+    vals, t0 = {}, time.perf_counter()
+    try:
+        for c in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = [exe, "--kernel-trace", "--pmc", c, "--output-format", "csv", "-d", tmp, "-o", f"pmc_{c}", "--", sys.executable,
+                   os.path.abspath(__file__), "--config", name, "--window", f"{g0}:{g0 + 2}", "--lean", "--no-kernel-timing", "--steps", "5", "--warmup", "1"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=600)
+            files = sorted(glob.glob(os.path.join(tmp, "**", f"pmc_{c}_counter_collection.csv"), recursive=True))
+            if r.returncode != 0 or not files:
+                progress(f"rocprofv3 --pmc {c} pass failed (rc {r.returncode}): {r.stderr[-300:]}")
+                return None
+            acc = []
+            for row in csv.DictReader(open(files[-1])):
+                if row["Counter_Name"] == c and "attn_fwd_kernel_s6" in row["Kernel_Name"]:
+                    acc.append(float(row["Counter_Value"]))
+            # the window's launches are the LAST 2 x L of the child run (its warm-up runs the first groups of the video)
+            acc = acc[-2 * spec.n_layers:]
+            if len(acc) < 2 * spec.n_layers:
+                return None
+            vals[c] = sum(acc) / len(acc)
+    except Exception as e:
+        progress(f"in-run PMC collection failed: {type(e).__name__}: {e}")
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    traffic = 2 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024
+    return {"traffic": traffic, "algorithmic_bytes_this_launch": alg, "traffic_over_algorithmic": round(traffic / alg, 3),
+            "fetch_size_kb": round(vals["FETCH_SIZE"], 1), "write_size_kb": round(vals["WRITE_SIZE"], 1),
+            "window": f"groups [{g0}, {g0 + 2}) of {G}: n = {n} new tokens over ~{P} pruned prefix rows, {2 * spec.n_layers} launches averaged",
+            "source": f"collected IN THIS RUN: two `rocprofv3 --kernel-trace --pmc <counter>` child runs of this script (`--window {g0}:{g0 + 2}`), "
+                      f"{time.perf_counter() - t0:.0f} s; read bytes = 2 x FETCH_SIZE x 1024 (gfx950 counts wide coalesced loads at half), write bytes = WRITE_SIZE x 1024"}
+
+
 def attach_traffic(roofline, name, world):
     """HBM bytes per attention launch come from separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; gfx950 correction as in
     MI355X_MICROARCH.md) of this same command, committed under profiles/ — labelled with their source."""
@@ -1178,6 +1231,14 @@ def main():
         return
     attach_traffic(res.get("roofline"), name, world)
     attach_hbm_kernels(res, name, world)
+    if world == 1 and res.get("roofline") and not args.lean and not args.no_secondary:
+        live = collect_attention_traffic(name, ctx["spec"], ctx["plan"], ctx["cfg"])
+        if live:
+            r_ = res["roofline"]
+            r_["traffic_committed_builder_box"] = {"traffic": r_.get("traffic"), "source": r_.get("traffic_source")}
+            r_["traffic"], r_["traffic_source"], r_["traffic_over_algorithmic"] = live["traffic"], live["source"], live["traffic_over_algorithmic"]
+            r_["traffic_window"] = {k: live[k] for k in ("window", "algorithmic_bytes_this_launch", "fetch_size_kb", "write_size_kb")}
+            progress("attention HBM traffic collected in-run (rocprofv3 --pmc)")
 
     legs = {"decode": None, "peaked": None, "video_to_first_token": None, "host_contention": None, "cfg4ref": None, "cfg2": None,
             "cpu_baseline": None}

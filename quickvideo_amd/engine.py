@@ -149,6 +149,10 @@ class QuickPrefillEngine:
         env = os.environ.get("QP_SPLIT_GATE_UP_ROWS")                                  # developer override, see _gate_up_swiglu
         self.split_gate_up_rows = tuple(int(v) for v in env.split(",")) if env else None
         self._tune_gemms = self.device.type == "cuda" and os.environ.get("QP_TUNE_GEMMS", "1") == "1"
+        # QP_GEMM_BACKEND=lt: EVERY projection goes through the library's own hipBLASLt path (qp_linear_act, bound without releasing the
+        # interpreter lock) instead of torch.mm — no torch call is left in the layer loop, so another Python thread that wants the lock
+        # gets it at the switch interval only, not at every one of the ~150 GEMM calls of a group (bench.py host_contention)
+        self._lt_only = (self.device.type == "cuda" and os.environ.get("QP_GEMM_BACKEND", "") == "lt" and hasattr(self.ops, "linear_tune"))
         # decisions are per (projection shape, rows, device) and shared by every engine of the process
         self._gemm_plans, self._gu_split, self._lt_tuned = (QuickPrefillEngine._SHARED.setdefault((str(self.device), self._tune_gemms, i), {}) for i in range(3))
         self.kept_trace: Optional[list] = None      # tests: set to [] to record kept indices per (group, layer)
@@ -253,8 +257,26 @@ class QuickPrefillEngine:
 
     _WKEY = {"qkv": "w_qkv", "o": "w_o", "gate_up": "w_gate_up", "down": "w_down"}
 
+    def _lt_linear(self, key: str, x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bias=None) -> bool:
+        """hipBLASLt through the library for ANY row count (QP_GEMM_BACKEND=lt); False when plan selection failed for this shape."""
+        lk = (key, x.shape[0], tuple(w.shape), bias is not None, "lt-only")
+        ok = self._lt_tuned.get(lk)
+        if ok is None:
+            try:
+                self.ops.linear_tune(x, [getattr(lw, self._WKEY[key]) for lw in self.w.layers], bias, out, self.ops.ACT_NONE)
+                ok = True
+            except Exception as e:
+                ok = False
+                _tune_failed(lk, e)
+            self._lt_tuned[lk] = ok
+        if ok:
+            self.ops.linear_act(x, w, bias, out, self.ops.ACT_NONE)
+        return ok
+
     def _linear(self, key: str, x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bias=None):
         n = x.shape[0]
+        if self._lt_only and x.is_contiguous() and w.is_contiguous() and out.is_contiguous() and self._lt_linear(key, x, w, out, bias):
+            return
         if n < 256 and self._small_linear(key, x, w, out, bias):
             return
         pk = (key, n, tuple(w.shape), bias is not None)
@@ -305,6 +327,9 @@ class QuickPrefillEngine:
                 else:
                     torch.mm(x2[r0:r1], lw.w_gate_up.t(), out=gu[r0:r1])
 
+        if self._lt_only and x2.is_contiguous() and self._lt_linear("gate_up", x2, lw.w_gate_up, gu):
+            self.ops.swiglu(gu, act)
+            return
         if n < 256 and self._small_linear("gate_up", x2, lw.w_gate_up, gu):
             self.ops.swiglu(gu, act)
             return
