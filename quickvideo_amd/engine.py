@@ -180,6 +180,7 @@ class QuickPrefillEngine:
             self.b_ss_all = torch.empty(self.tp_size, self.hkv, n, dtype=torch.float32, device=dev)
 
     def reset(self):
+        self.pp_flush()
         self.arena.reset()
         self.seq_pos = 0
 
@@ -750,13 +751,48 @@ class QuickPrefillEngine:
         return buf, idx
 
     def _pp_out(self, h: torch.Tensor):
-        if self.pp_size > 1 and self.pp_rank < self.pp_size - 1:
-            dst, grp = self._pp_peer(self.pp_rank + 1), self._pp_p2p_group()
-            torch.distributed.send(h.cpu() if self._pp_host_staged(h) else h, dst=dst, group=grp)
-            rows = getattr(self, "_seg_rows", None)
-            if rows is not None:
-                rows = rows.to(torch.int32).contiguous()
-                torch.distributed.send(rows.cpu() if self._pp_host_staged(rows) else rows, dst=dst, group=grp)
+        """Hand the segment's hidden rows (+ the survivors' original row indices after a hidden-state prune) to the next stage WITHOUT
+        stalling this stage's compute stream: the rows are copied into one of two send slots and sent asynchronously (`isend`: RCCL
+        runs point-to-point on its own stream behind an event of this one), so the stage goes straight on to its next segment while
+        the transfer waits for the receiver to post its recv.  A slot is reused only after ITS send has completed (`wait()` = a stream
+        wait under RCCL): a receiver that falls two segments behind holds the sender there — back-pressure, not a clobbered buffer.
+        (The blocking `send` of rounds 1-3 made every stage wait for its successor to reach the matching recv before it could
+        start its own next segment: lock-step instead of a pipeline whenever stage times jitter.)"""
+        if not (self.pp_size > 1 and self.pp_rank < self.pp_size - 1):
+            return
+        dist = torch.distributed
+        dst, grp = self._pp_peer(self.pp_rank + 1), self._pp_p2p_group()
+        if not hasattr(self, "_pp_slots"):
+            self._pp_slots, self._pp_turn = [None, None], 0
+            self._pp_sendbuf = torch.empty(2, self.n_max, self.spec.hidden, dtype=self.dtype, device=self.device)
+            self._pp_sendidx = torch.empty(2, self.n_max, dtype=torch.int32, device=self.device)
+        slot = self._pp_turn & 1
+        self._pp_turn += 1
+        self._pp_wait_slot(slot)
+        m = h.shape[0]
+        buf = self._pp_sendbuf[slot, :m]
+        buf.copy_(h)
+        payload = [buf.cpu() if self._pp_host_staged(buf) else buf]
+        rows = getattr(self, "_seg_rows", None)
+        if rows is not None:
+            ib = self._pp_sendidx[slot, :rows.shape[0]]
+            ib.copy_(rows.to(torch.int32))
+            payload.append(ib.cpu() if self._pp_host_staged(ib) else ib)
+        works = [dist.isend(t, dst=dst, group=grp) for t in payload]           # same order as the receiver's recv calls
+        self._pp_slots[slot] = (works, payload)                                # (payload kept alive until the send has completed)
+
+    def _pp_wait_slot(self, slot: int):
+        pending = self._pp_slots[slot]
+        if pending is not None:
+            for wk in pending[0]:
+                wk.wait()
+            self._pp_slots[slot] = None
+
+    def pp_flush(self):
+        """Wait for every outstanding hand-off of this stage (end of a video; before the process group goes away)."""
+        if hasattr(self, "_pp_slots"):
+            self._pp_wait_slot(0)
+            self._pp_wait_slot(1)
 
     @property
     def is_last_stage(self) -> bool:
@@ -791,6 +827,7 @@ class QuickPrefillEngine:
         x, rows = self._pp_in(embeds, pos.shape[1], prune=pr)
         h = self.forward_segment(x, pos, prune=pr, row_idx=rows)
         self._pp_out(h)
+        self.pp_flush()                              # the caller is about to read a result: nothing of this stage stays in flight
         self.seq_pos += embeds.shape[0]
         return self.logits_last(h) if self.is_last_stage else None
 
@@ -812,6 +849,7 @@ class QuickPrefillEngine:
         x, rows = self._pp_in(token_embed.view(1, -1), 1, prune=bool(self.cfg.do_top_k_for_query))
         h = self.forward_segment(x, pos, prune=bool(self.cfg.do_top_k_for_query), row_idx=rows)
         self._pp_out(h)
+        self.pp_flush()
         self.seq_pos += 1
         return self.logits_last(h) if self.is_last_stage else None
 

@@ -572,6 +572,7 @@ class PrefillPipeline:
                     logits = eng.decode_step(eng.embed_tokens(torch.tensor([tok], device=dev)), P["delta"])
                 tok = choose(logits)
                 out.append(tok)
+        eng.pp_flush()                                                        # layer pipeline: no hand-off left in flight
         sync()
         tm.decode = time.perf_counter() - t_dec
         tm.e2e = time.perf_counter() - t_e2e

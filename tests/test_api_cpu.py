@@ -514,6 +514,57 @@ def test_layer_pipeline_with_query_score_pruning_gloo():
             assert (a is None) == (b is None) and (a is None or np.array_equal(a, b))
 
 
+def _pp_order_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import time
+    from quickvideo_amd.engine import QuickPrefillEngine
+    from quickvideo_amd.lvu_config import LVUConfig
+    from quickvideo_amd.spec import TextSpec
+    from quickvideo_amd.weights import DecoderWeights, pp_layer_split
+    L = 2
+    so = O.TextSpec(hidden=256, n_heads=2, n_kv_heads=1, head_dim=128, intermediate=256, n_layers=L, vocab=64)
+    spec = TextSpec(hidden=256, n_heads=2, n_kv_heads=1, head_dim=128, intermediate=256, n_layers=L, vocab=64)
+    w = {k: v.to(torch.bfloat16) for k, v in O.synthetic_text_weights(so, seed=3).items()}
+    eng = QuickPrefillEngine(DecoderWeights.from_named(spec, w, "cpu", layer_range=pp_layer_split(L, 2, rank)), LVUConfig("x", top_p=0.5, video_group_size=4),
+                             capacity=64, max_group_tokens=16, device="cpu", ops=OracleOps(), pp_rank=rank, pp_size=2)
+    segs = [torch.full((9 + i, 256), float(i + 1), dtype=torch.bfloat16) for i in range(4)]
+    if rank == 0:
+        t = []
+        for i, h in enumerate(segs):
+            t0 = time.perf_counter()
+            hh = h.clone()
+            eng._seg_rows = None
+            eng._pp_out(hh)
+            hh.zero_()                                        # the caller's buffer is reused at once (b_h is): the slot must hold a COPY
+            t.append(time.perf_counter() - t0)
+        eng.pp_flush()
+        ret["send_s"] = t
+    else:
+        time.sleep(1.0)                                       # the receiver is late: the first TWO hand-offs must not wait for it
+        got = []
+        for h in segs:
+            x, rows = eng._pp_in(torch.empty(0), h.shape[0], prune=False)
+            got.append(x.clone())
+            time.sleep(0.05)
+        ret["ok"] = all(torch.equal(a, b) for a, b in zip(got, segs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_layer_pipeline_handoff_is_asynchronous_ordered_and_double_buffered():
+    """VERDICT r3 #5c: the stage-to-stage hand-off as RCCL will run it — `isend` from one of two send slots, no host staging for CPU/RCCL
+    tensors, a blocking wait only when a slot is reused.  A receiver that shows up a second late: the sender's first two hand-offs return
+    immediately (its compute would go on), the third waits for slot 0 to drain; all four segments (different row counts) arrive in order
+    with the bytes they had when handed off, although the sender overwrote its source buffer right after each call."""
+    ret = mp.Manager().dict()
+    mp.spawn(_pp_order_worker, args=(2, 33100 + os.getpid() % 2000, ret), nprocs=2, join=True)
+    assert ret["ok"]
+    s0, s1, s2, s3 = ret["send_s"]
+    assert s0 < 0.3 and s1 < 0.3, ret["send_s"]               # not held back by the late receiver
+    assert s2 > 0.5, ret["send_s"]                            # slot 0 is reused only after its send has completed
+
+
 # ---------------------------------------------------------------- layer pipeline of group-token parallel stages (pp2 x sp2)
 def _ppsp_worker(rank, world, port, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
