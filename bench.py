@@ -70,6 +70,32 @@ QUESTION = "Describe what happens in this video in detail."
 _T0 = time.perf_counter()
 
 
+def effective_cpus():
+    """CPUs this process may actually use: min(os.cpu_count(), scheduler affinity, the container's cgroup CPU quota).  The GPU boxes
+    report 256 hardware threads but run the job under `cpu.max = 1600000 100000` — 16 CPUs' worth of time: 256 busy threads there are
+    16x oversubscription and the whole cgroup is throttled every period (found in round 4 when a 256-burner stress leg froze the run)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != "max":
+                n = min(n, max(1, int(int(quota) / int(period))))
+        except Exception:
+            pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if q > 0:
+            n = min(n, max(1, q // per))
+    except Exception:
+        pass
+    return n
+
+
 def progress(msg):
     """Leg-by-leg progress on stderr of rank 0 (stdout carries exactly one JSON line)."""
     if int(os.environ.get("RANK", "0")) == 0:
@@ -415,7 +441,7 @@ def cpu_baseline_full(name):
     from oracle import qp_oracle as O
     model, frames, fh, fw, gs, rho, prefix, tail = CONFIGS[name]
     ps = PRESETS[model]
-    cores = min(os.cpu_count() or 1, 32)
+    cores = min(effective_cpus(), 32)
     torch.set_num_threads(cores)
     spec = O.TextSpec(hidden=ps.hidden, n_heads=ps.n_heads, n_kv_heads=ps.n_kv_heads, head_dim=ps.head_dim, intermediate=ps.intermediate,
                       n_layers=ps.n_layers, vocab=1024)          # lm_head of ONE row: the vocabulary size is irrelevant to the timing
@@ -466,7 +492,7 @@ def cpu_baseline_check(name, group=None, layers=4):
     from oracle import qp_oracle as O
     model, frames, fh, fw, gs, rho, prefix, tail = CONFIGS[name]
     ps = PRESETS[model]
-    cores = min(os.cpu_count() or 1, 32)
+    cores = min(effective_cpus(), 32)
     torch.set_num_threads(cores)
     gh, gw = fh // 14, fw // 14
     plan = planner.plan_groups(frames, gs, gh, gw, prefix, prefix + (frames // 2) * (gh // 2) * (gw // 2) + tail)
@@ -517,8 +543,9 @@ def cpu_baseline(name, sample_layers=2):
     model, frames, fh, fw, gs, rho, prefix, tail = CONFIGS[name]
     ps = PRESETS[model]
     # torch-CPU on the GPU box's 256-thread EPYC host slows down past ~32 threads for these op sizes (measured in round 1:
-    # tools/probe/cpu_diag.py), so the baseline uses min(host cores, 32) threads and reports that count.
-    cores = min(os.cpu_count() or 1, 32)
+    # tools/probe/cpu_diag.py) — round 4 found out why: the job's cgroup grants 16 CPUs of time (cpu.max), so the baseline uses
+    # min(usable CPUs, 32) threads and reports that count.
+    cores = min(effective_cpus(), 32)
     torch.set_num_threads(cores)
     gh, gw = fh // 14, fw // 14
     n_video = (frames // 2) * (gh // 2) * (gw // 2)
@@ -670,7 +697,7 @@ def pipeline_leg(name, eng, device, modes=("overlapped", "sequential"), warm_vid
     pipe.measure_vit_alone = vit_alone
     if reader_threads is not None:
         os.environ["QUICKCODEC_CORES"] = str(reader_threads)
-    threads = int(os.environ.setdefault("QUICKCODEC_CORES", str(min(16, os.cpu_count() or 16))))   # the reference's timing scripts use 16
+    threads = int(os.environ.setdefault("QUICKCODEC_CORES", str(min(16, effective_cpus()))))   # the reference's timing scripts use 16
     dec = "&decode_h=1080&decode_w=1920"
     pad = lambda secs: f"&decode_s={decode_s_per_hour * secs / 3600:.4f}" if decode_s_per_hour > 0 else ""
     if name in ("cfg4", "cfg4s", "cfg4x2"):     # a 1-hour (or 6-minute) video at 8 fps sampled at 2 fps; planned at the model's frame size
@@ -719,7 +746,7 @@ def pipeline_leg(name, eng, device, modes=("overlapped", "sequential"), warm_vid
         res[mode]["producer"]["real_work_thread_seconds"] = round(getattr(rd, "work_seconds", 0.0), 2)
         if burner:
             res[mode]["host_stress"] = {"burner_processes": burner.native, "python_threads_holding_the_gil": burner.python_threads,
-                                        "host_cores": os.cpu_count(), "python_thread_iterations": sum(burner.iters),
+                                        "host_cpus_usable": effective_cpus(), "python_thread_iterations": sum(burner.iters),
                                         "cut_after_s": burner.max_seconds if burner.cut else None}
         progress(f"video -> first token, {name} {mode}{' under host stress' if burner else ''}: {res[mode]['ttft_ms']} ms")
     if not lead:
@@ -1047,8 +1074,9 @@ def host_contention_leg(eng, device):
     import shutil
     import tempfile
     from concurrent.futures import ThreadPoolExecutor
-    cores = os.cpu_count() or 16
-    out = {"host_cores": cores}
+    cores = effective_cpus()
+    out = {"host_cpus_usable": cores, "host_hardware_threads": os.cpu_count(),
+           "note_on_cpus": "usable = min(hardware threads, affinity, cgroup cpu.max quota): the stress saturates what the job may use"}
     leg = lambda **kw: pipeline_leg("cfg4s", eng, device, modes=("overlapped",), decode_s_per_hour=0, vit_alone=False, **kw)["overlapped"]
     out["idle_host"] = leg()
     out["cores_saturated"] = leg(stress=(cores, 0))
@@ -1222,7 +1250,8 @@ def main():
 
     progress(f"{name}: build + warm-up + timed pass")
     res, eng, ctx = measure(args, name, device, rank, world, parallel, layout, group, timing=timing, telemetry=(world == 1), tp_group_1rank=preflight)
-    progress(f"timed pass done: {res['value']} tok/s, {res['full_prefill_ms']} ms per pass")
+    if not args.window:
+        progress(f"timed pass done: {res['value']} tok/s, {res['full_prefill_ms']} ms per pass")
     if args.window:
         if rank == 0:
             emit_line(json.dumps({"config": describe(name), **res}))

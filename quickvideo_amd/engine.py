@@ -73,7 +73,7 @@ class QuickPrefillEngine:
     _SHARED: dict = {}
     def __init__(self, weights: DecoderWeights, cfg: LVUConfig, capacity: int, max_group_tokens: int, device=None, ops=None,
                  tp_group=None, sp_group=None, sp_rank: int = 0, sp_size: int = 1, pp_group=None, pp_rank: int = 0, pp_size: int = 1,
-                 pp_peers: Optional[List[int]] = None):
+                 pp_peers: Optional[List[int]] = None, pp_send_group=None, pp_recv_group=None):
         self.w, self.spec, self.cfg = weights, weights.spec, cfg
         self.device = torch.device(device if device is not None else weights.embed.device)
         if ops is None:
@@ -107,6 +107,9 @@ class QuickPrefillEngine:
         # pp_peers[s] = global rank of this rank's counterpart in stage s.  A stage may itself be a group-token parallel ("sp") group:
         # its ranks own the same zigzag rows in every stage, so each hands its own rows to its counterpart (no re-shuffle).
         self.pp_peers = pp_peers
+        # optional 2-rank process groups towards the next / from the previous stage (parallel.ParallelContext.pair_groups): one
+        # communicator per direction, so a recv never queues behind this stage's own unmatched send
+        self.pp_send_group, self.pp_recv_group = pp_send_group, pp_recv_group
         assert not (self.pp_size > 1 and self.tp_size > 1), "layer pipeline is not combined with tensor parallelism"
         self.l0, self.n_layers_total = weights.layer0, weights.n_layers_total
         s = self.spec
@@ -696,7 +699,10 @@ class QuickPrefillEngine:
         (a0, a1), (b0, b1) = sp_row_ranges(n, self.sp_size, self.sp_rank)
         return (a1 - a0) + (b1 - b0)
 
-    def _pp_p2p_group(self):
+    def _pp_p2p_group(self, sending: Optional[bool] = None):
+        pair = self.pp_send_group if sending else (self.pp_recv_group if sending is False else None)
+        if pair is not None:
+            return pair
         return None if self.pp_peers is not None else self.pp_group      # explicit peers are global ranks of the default group
 
     def _pp_peer(self, r: int) -> int:
@@ -727,7 +733,7 @@ class QuickPrefillEngine:
         return cur, pruned
 
     def _pp_recv(self, buf: torch.Tensor):
-        src, grp = self._pp_peer(self.pp_rank - 1), self._pp_p2p_group()
+        src, grp = self._pp_peer(self.pp_rank - 1), self._pp_p2p_group(sending=False)
         if self._pp_host_staged(buf):
             host = torch.empty(buf.shape, dtype=buf.dtype)
             torch.distributed.recv(host, src=src, group=grp)
@@ -761,7 +767,7 @@ class QuickPrefillEngine:
         if not (self.pp_size > 1 and self.pp_rank < self.pp_size - 1):
             return
         dist = torch.distributed
-        dst, grp = self._pp_peer(self.pp_rank + 1), self._pp_p2p_group()
+        dst, grp = self._pp_peer(self.pp_rank + 1), self._pp_p2p_group(sending=True)
         if not hasattr(self, "_pp_slots"):
             self._pp_slots, self._pp_turn = [None, None], 0
             self._pp_sendbuf = torch.empty(2, self.n_max, self.spec.hidden, dtype=self.dtype, device=self.device)

@@ -125,6 +125,22 @@ class ParallelContext:
             self._subgroups[key] = gs
         return self._subgroups[key][self.rank // sp]
 
+    def pair_groups(self, pp: int, sp: int):
+        """(group towards the next stage, group from the previous stage) of this rank in a pp x sp grid: one 2-rank process group per
+        adjacent pair of pipeline counterparts = one RCCL communicator and stream per DIRECTION of a stage.  On a communicator that was
+        created eagerly (init_process_group(device_id=...)) torch treats unbatched send/recv as collectives of that communicator and
+        serialises them with everything else on it (its own warning, seen on the GPU box: profiles/r4_rccl_self_p2p_probe.txt) — a stage's
+        recv of segment g+1 would queue behind its still unmatched send of segment g.  Collective creation: every rank creates every
+        pair's group in the same order, once per grid shape."""
+        if pp == 1:
+            return None, None
+        key = ("pairs", pp, sp)
+        if key not in self._subgroups:
+            self._subgroups[key] = {(s, i): torch.distributed.new_group(ranks=[self.global_rank(s * sp + i), self.global_rank((s + 1) * sp + i)])
+                                    for s in range(pp - 1) for i in range(sp)}
+        g, (stage, i) = self._subgroups[key], (self.rank // sp, self.rank % sp)
+        return g.get((stage, i)), g.get((stage - 1, i))
+
     def engine_kwargs(self, pp: int, sp: int) -> dict:
         """Constructor arguments of QuickPrefillEngine for this rank in a pp x sp grid (the wiring bench.py::measure used to do by hand)."""
         if not self.on:
@@ -136,7 +152,8 @@ class ParallelContext:
         if sp > 1:
             kw.update(sp_group=self.stage_group(pp, sp), sp_rank=sp_rank, sp_size=sp)
         if pp > 1:
-            kw.update(pp_rank=stage, pp_size=pp, pp_peers=[self.global_rank(s * sp + sp_rank) for s in range(pp)])
+            nxt, prv = self.pair_groups(pp, sp)
+            kw.update(pp_rank=stage, pp_size=pp, pp_peers=[self.global_rank(s * sp + sp_rank) for s in range(pp)], pp_send_group=nxt, pp_recv_group=prv)
         return kw
 
     def describe(self, pp: int = 1, sp: int = 1) -> str:
