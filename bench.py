@@ -743,6 +743,7 @@ def pipeline_leg(name, eng, device, modes=("overlapped", "sequential"), warm_vid
         if not lead:
             continue
         res[mode] = _leg_record(pipe.last_timings, overlap, threads)
+        res[mode]["side_streams"] = pipe.stream_report
         res[mode]["producer"]["real_work_thread_seconds"] = round(getattr(rd, "work_seconds", 0.0), 2)
         if burner:
             res[mode]["host_stress"] = {"burner_processes": burner.native, "python_threads_holding_the_gil": burner.python_threads,

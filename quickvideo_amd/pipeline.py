@@ -132,7 +132,7 @@ def _video_meta(reader):
 class _Producer(threading.Thread):
     """Frame groups -> pinned ring -> async H2D on `copy_stream`; bounded like the reference's Queue(maxsize=3)."""
 
-    def __init__(self, reader, n_groups, frames_per_group, device, depth=3, ring_cache=None):
+    def __init__(self, reader, n_groups, frames_per_group, device, depth=3, ring_cache=None, copy_stream=None):
         super().__init__(daemon=True)
         self.reader, self.n_groups, self.device, self.depth = reader, n_groups, device, depth
         # pinned host slots + device slots are kept across videos by the owner of `ring_cache` (page-locking ~80 MB costs tens
@@ -141,7 +141,9 @@ class _Producer(threading.Thread):
         self.q: "queue.Queue" = queue.Queue(maxsize=depth)
         self.exc = None
         self.use_gpu = device.type == "cuda"
-        self.copy_stream = torch.cuda.Stream(device) if self.use_gpu else None
+        # a stream on a hardware queue of its own (streams.side_streams): a copy stream that shares a queue with the ViT or the LLM stream
+        # uploads group g+1's frames only after that stream's earlier work has finished
+        self.copy_stream = (copy_stream if copy_stream is not None else torch.cuda.Stream(device, priority=-1)) if self.use_gpu else None
         self.slots_free = threading.Semaphore(depth)
         self.ring = None
         self.fpg = frames_per_group
@@ -236,7 +238,11 @@ class PrefillPipeline:
         self._vit_pg = None                       # dedicated process group (own RCCL communicator) of the front end's collectives
         self.last_layout = "single"
         self._tower = None
-        self.vit_stream = torch.cuda.Stream(model.device) if self.use_gpu else None
+        self.vit_stream = self.copy_stream = None
+        self.stream_report = None
+        if self.use_gpu:
+            from .streams import side_streams
+            self.vit_stream, self.copy_stream, self.stream_report = side_streams(model.device)
         self.last_timings: Optional[Timings] = None
         self.measure_vit_alone = False            # bench.py: replay one group's ViT pass after the run, GPU otherwise idle (3 extra passes)
 
@@ -446,7 +452,7 @@ class PrefillPipeline:
             self._ring_cache = {}
         prod = None
         if lead:
-            prod = _Producer(reader, G, gs, dev, depth=3, ring_cache=self._ring_cache)     # bounded like the reference's Queue(maxsize=3)
+            prod = _Producer(reader, G, gs, dev, depth=3, ring_cache=self._ring_cache, copy_stream=self.copy_stream)   # bounded like the reference's Queue(maxsize=3)
             prod.start()
         sync = (lambda: torch.cuda.synchronize(dev)) if self.use_gpu else (lambda: None)
         ev_t = (lambda: torch.cuda.Event(enable_timing=True)) if self.use_gpu else (lambda: None)
