@@ -765,7 +765,7 @@ def pipeline_leg(name, eng, device, modes=("overlapped", "sequential"), warm_vid
                           "definition": "producer_cost = wall time of fetching every frame group before the GPU starts (sequential plugin); "
                                         "hidden = ttft(sequential) - ttft(overlapped); hideable = min(producer_cost, GPU time of all groups but "
                                         "the last): a producer-bound video (GPU time < producer cost, e.g. cfg2) cannot hide more than its GPU time; "
-                                        "both plugins run the ViT exactly one group ahead of the LLM (round 4), so their GPU sides are the same schedule"}
+                                        "both plugins let the ViT run at most two groups ahead of the LLM on hardware queues of their own (round 4), so their GPU sides are the same schedule"}
     res["frame_source"] = (f"synthetic, costed: each of the {frames} sampled frames is produced at 1080x1920 and LANCZOS-resized (PIL) to {fh}x{fw} on "
                            f"{threads} threads (QUICKCODEC_CORES), " +
                            (f"padded to {decode_s_per_hour} s per hour of video at that thread count (the reference's QuickCodec figure; no codec in "
