@@ -393,11 +393,27 @@ class PrefillPipeline:
         return int(t.item())
 
     # ------------------------------------------------------------------ video -> tokens
+    def generate(self, *args, **kwargs) -> List[int]:
+        """video -> tokens (see _generate).  While the group loop runs, the interpreter's thread switch interval is lowered to 20 us:
+        every torch call of the launching thread (a few hundred per frame group) drops the interpreter lock, and a Python thread that is
+        busy beside it — the reference's own processor thread is one, qwen25_lvu_interleaved.py:303-340 — then keeps the lock for a whole
+        switch interval (5 ms by default) before the launcher gets it back: measured on cfg4s with ONE such thread, 9x slower
+        (bench.py host_contention).  The other thread loses nothing but a little switching overhead; the setting is restored on return."""
+        import sys
+        old = sys.getswitchinterval()
+        want = float(os.environ.get("QP_SWITCH_INTERVAL_S", "2e-5"))
+        if want > 0:
+            sys.setswitchinterval(min(old, want))
+        try:
+            return self._generate(*args, **kwargs)
+        finally:
+            sys.setswitchinterval(old)
+
     @torch.no_grad()
-    def generate(self, question, video, max_new_tokens: int = 16, overlap: bool = True, eos_token_id=None,
-                 do_sample: Optional[bool] = None, temperature: Optional[float] = None, top_k: Optional[int] = None,
-                 top_p: Optional[float] = None, repetition_penalty: Optional[float] = None, seed: Optional[int] = None,
-                 num_beams: int = 1, **unused) -> List[int]:
+    def _generate(self, question, video, max_new_tokens: int = 16, overlap: bool = True, eos_token_id=None,
+                  do_sample: Optional[bool] = None, temperature: Optional[float] = None, top_k: Optional[int] = None,
+                  top_p: Optional[float] = None, repetition_penalty: Optional[float] = None, seed: Optional[int] = None,
+                  num_beams: int = 1, **unused) -> List[int]:
         """generation kwargs as the reference hands them to HF `generate` (qwen25_lvu.py:744-761); unset ones fall back to the
         checkpoint's generation_config.json (`model.generation_defaults`), then to greedy.  Beam search is refused, not ignored.
         `question`: the user's text, or the reference's `messages` list (chat(); qwen25_lvu.py:546-548) when the processor can
