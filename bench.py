@@ -1388,6 +1388,19 @@ def main():
         # frame pair, ViT data-parallel + all-gather, the layout's engine, the deciding rank's token broadcast).  The measured engines
         # are dropped first: the pipeline builds its own from a model loaded the way `LVU(model_init_kwargs={"parallel": ...})` does.
         from quickvideo_amd.lvu import load_native_model
+        # This leg is the part of the N > 1 run that RCCL has never executed (frame scatter, front-end group, pipeline hand-off groups): a
+        # rank that throws or stalls must not cost the line — every rank carries the same watchdog, rank 0 prints what was measured.
+        budget_s = float(os.environ.get("QP_BENCH_AUX_BUDGET_S", "900"))
+        aux_done = threading.Event()
+
+        def watchdog_n():
+            if not aux_done.wait(budget_s):
+                progress(f"N>1 video -> first token leg exceeded {budget_s:.0f} s: printing the line without it")
+                emit(note=f"the N>1 video -> first token leg was cut off after {budget_s:.0f} s (not measured in this run)")
+                sys.stdout.flush()
+                os._exit(0)
+
+        threading.Thread(target=watchdog_n, daemon=True).start()
         del eng
         ctx.pop("embeds", None)
         torch.cuda.empty_cache()
@@ -1404,6 +1417,7 @@ def main():
             if rank == 0:
                 tp_block["video_to_first_token"] = v
             progress("video -> first token leg (tp) done")
+        aux_done.set()
     emit()
     if world > 1 or preflight is not None:
         torch.distributed.destroy_process_group()

@@ -30,7 +30,7 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 extern "C" {
 
 const char* qp_last_error(void) { return g_err; }
-const char* qp_version(void) { return "quickprefill-mi355x 0.3 (gfx950)"; }
+const char* qp_version(void) { return "quickprefill-mi355x 0.4 (gfx950)"; }
 
 int qp_create(qp_ctx** out, int device) {
   QP_REQUIRE(out != nullptr, QP_ERR_INVALID, "qp_create: out is NULL");

@@ -182,6 +182,22 @@ class VisionTower:
         (qp_vit_rope, qp_vit_attn, qp_quick_gelu; head_dim 80 only); None -> the same math in plain torch ops."""
         self.w, self.spec = weights, weights.spec
         self.ops = ops if (ops is not None and weights.spec.head_dim == 80 and hasattr(ops, "vit_attn")) else None
+        self._lt_shapes: dict = {}             # (name, rows) -> True once hipBLASLt's candidates were timed for this GEMM shape
+
+    def _lt(self, name: str, x: torch.Tensor, w: torch.Tensor, bias, act: int = 0, alpha: float = 1.0, peers=None) -> torch.Tensor:
+        """out = act(alpha x w^T + bias) through the library's hipBLASLt path with the candidate that is FASTEST for this shape: the first
+        time a (projection, row count) shows up, qp_linear_tune times every heuristic candidate over the same projection of all blocks
+        (`peers`, cold weights) and keeps the best — torch's F.linear takes the library's first candidate, which for these K = 1280 shapes
+        is up to 1.3x slower (tools/bench_vit.py: QP_VIT_LT=0 / 1).  Also one call that keeps the interpreter lock instead of three torch
+        calls that drop it (bench.py host_contention)."""
+        x = x if x.is_contiguous() else x.contiguous()
+        out = torch.empty(x.shape[0], w.shape[0], dtype=x.dtype, device=x.device)
+        key = (name, x.shape[0], act, bias is not None)
+        if key not in self._lt_shapes:
+            self.ops.linear_tune(x, [pw for pw in (peers or [w])], bias, out, act, alpha)
+            self._lt_shapes[key] = True
+        self.ops.linear_act(x, w, bias, out, act, alpha)
+        return out
 
     @torch.no_grad()
     def forward(self, pixel_rows: torch.Tensor, grid_thw: Tuple[int, int, int]) -> torch.Tensor:
@@ -208,6 +224,9 @@ class VisionTower:
         ybuf = torch.empty_like(x) if fused_ln else None
         fused_act = (ops is not None and hasattr(ops, "linear_act") and os.environ.get("QP_VIT_FUSED_ACT", "1") == "1"
                      and x.is_cuda and b_contig(w))
+        # every GEMM of the tower through the tuned hipBLASLt path (QP_VIT_LT=0: torch's F.linear / addmm, the round-3 form, for A/B)
+        use_lt = fused_act and hasattr(ops, "linear_tune") and os.environ.get("QP_VIT_LT", "1") == "1"
+        blocks = w.blocks
 
         def norm(wt, bs):
             """x += pending residual; LayerNorm(x)  (Qwen2VLVisionBlock: x = x + attn(norm1(x)); x = x + mlp(norm2(x)))"""
@@ -224,7 +243,8 @@ class VisionTower:
             x = x.contiguous()
         for b in w.blocks:
             y = norm(b.ln1_w, b.ln1_b)
-            qkv = F.linear(y, b.qkv_w, b.qkv_b)                                          # [n, 3*H*hd]
+            qkv = (self._lt("qkv", y, b.qkv_w, b.qkv_b, peers=[bb.qkv_w for bb in blocks]) if use_lt
+                   else F.linear(y, b.qkv_w, b.qkv_b))                                   # [n, 3*H*hd]
             if ops is not None:
                 ops.vit_rope(qkv, cos_h, sin_h, H, hd)                                   # q, k rotated in place
                 a = torch.empty(n, H * hd, dtype=x.dtype, device=x.device)
@@ -238,8 +258,14 @@ class VisionTower:
                 q4, k4, v4 = (z.reshape(t, seq, H, hd).transpose(1, 2) for z in (q, k, v))   # [t, H, seq, hd]
                 a = F.scaled_dot_product_attention(q4, k4, v4, is_causal=False)
                 a = a.transpose(1, 2).reshape(n, H * hd)
-            pend = F.linear(a, b.proj_w, b.proj_b)
+            pend = self._lt("proj", a, b.proj_w, b.proj_b, peers=[bb.proj_w for bb in blocks]) if use_lt else F.linear(a, b.proj_w, b.proj_b)
             y = norm(b.ln2_w, b.ln2_b)
+            if use_lt:
+                if getattr(b, "_fc1_b_scaled", None) is None:
+                    b._fc1_b_scaled = (b.fc1_b.float() * 1.702).contiguous()
+                z = self._lt("fc1", y, b.fc1_w, b._fc1_b_scaled, act=ops.ACT_SWISH, alpha=1.702, peers=[bb.fc1_w for bb in blocks])
+                pend = self._lt("fc2", z, b.fc2_w, b.fc2_b, alpha=1.0 / 1.702, peers=[bb.fc2_w for bb in blocks])
+                continue
             if fused_act:
                 # fc1 + quick-GELU in ONE GEMM: Swish epilogue on 1.702 (y W1^T + b1) = 1.702 quick_gelu(.), the 1/1.702 rides on fc2's alpha
                 if getattr(b, "_fc1_b_scaled", None) is None:
