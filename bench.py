@@ -149,6 +149,46 @@ class TimedOps:
         return {n: (sum(s.elapsed_time(e) for s, e in ev), len(ev)) for n, ev in self.events.items()}
 
 
+class HipEventTimer:
+    """HIP events for the one-call segment path (qp_prefill_segment records them around each layer's attention / prune launch, on the
+    launch stream, INSIDE the timed region): raw hipEvent_t handles made through the HIP runtime torch has loaded."""
+
+    def __init__(self):
+        import ctypes
+        self.c, self.hip = ctypes, ctypes.CDLL("libamdhip64.so")
+        self.records = {"attn": [], "prune": []}
+
+    def pairs(self, n_layers, what, used=None):
+        c = self.c
+        arr = (c.c_void_p * (2 * n_layers))()
+        for i in range(2 * n_layers):
+            ev = c.c_void_p()
+            if self.hip.hipEventCreate(c.byref(ev)) != 0:
+                raise RuntimeError("hipEventCreate failed")
+            arr[i] = ev
+        self.records[what].append((arr, used if used is not None else [True] * n_layers))
+        return arr
+
+    def totals_ms(self):
+        """{what: (sum of the bracketed intervals in ms, number of launches)}; destroys the events."""
+        torch.cuda.synchronize()
+        c, out = self.c, {}
+        for what, recs in self.records.items():
+            tot, cnt = 0.0, 0
+            for arr, used in recs:
+                for l, u in enumerate(used):
+                    if u:
+                        ms = c.c_float()
+                        if self.hip.hipEventElapsedTime(c.byref(ms), c.c_void_p(arr[2 * l]), c.c_void_p(arr[2 * l + 1])) == 0:
+                            tot += ms.value
+                            cnt += 1
+                for i in range(len(arr)):
+                    self.hip.hipEventDestroy(c.c_void_p(arr[i]))
+            out[what] = (tot, cnt)
+            recs.clear()
+        return out
+
+
 class Telemetry(threading.Thread):
     """Samples the GPU's average socket power and shader clock from sysfs (hwmon) while the timed region runs, so that
     'the MFMA kernels run power-limited' is a measurement in the bench line, not an inference."""
@@ -730,7 +770,10 @@ def pipeline_leg(name, eng, device, modes=("overlapped", "sequential"), warm_vid
         wm = video_messages(name, warm, 64 if warm != video else None)
         if name == "cfg4ref":
             wm[0]["content"][0].update(resized_height=fh, resized_width=fw)
+        if pipe.par.on and pipe.par.mode != "tp":               # warm up on the grid the MAIN video will get (its GEMM shapes, its groups)
+            pipe.par.grid_override = pipe.par.grid(-(-frames // gs), m.spec.n_layers)
         pipe.generate(wm, warm, max_new_tokens=1, overlap=overlap)
+        pipe.par.grid_override = None
         rd = open_video(video) if lead else video
         burner = HostStress(*stress) if (stress and lead) else None
         if burner:
@@ -891,9 +934,11 @@ def measure(args, name, device, rank, world, parallel, layout, group, weights=No
         wtok = sum(plan.tokens[g0:g1])
         return ({"window": args.window, "prefix_rows_at_start": P0, "ms_per_group": round(dt / (g1 - g0) * 1e3, 3),
                  "tokens_per_s": round(wtok / dt, 1)}, eng, None)
+    native_timer = HipEventTimer() if (timed is not None and getattr(eng, "_native", False)) else None
     if fraction:
         if timed is not None:
             eng.ops = timed                                       # attention + prune bracketed with HIP events INSIDE the timed pass
+            eng.attn_timer = native_timer                         # (one-call segment path: the library records them around its launches)
         eng.reset()
         barrier()
         if tele:
@@ -905,7 +950,7 @@ def measure(args, name, device, rank, world, parallel, layout, group, weights=No
         barrier()
         dt = time.perf_counter() - t0
         first = int(tok.item())
-        eng.ops = real_ops
+        eng.ops, eng.attn_timer = real_ops, None
     else:
         barrier()
         if tele:
@@ -917,9 +962,13 @@ def measure(args, name, device, rank, world, parallel, layout, group, weights=No
         dt = time.perf_counter() - t0
         first = int(tok.item())
         if timed is not None:                                     # short video: one extra, separately bracketed pass
-            eng.ops = timed
+            eng.ops, eng.attn_timer = timed, native_timer
             run_video(eng, plan, starts, embeds, pos)
-            eng.ops = real_ops
+            if native_timer is not None:                          # ... and one through the per-operator loop for the small kernels' brackets
+                was, eng._native, eng.attn_timer = eng._native, False, None
+                run_video(eng, plan, starts, embeds, pos)
+                eng._native = was
+            eng.ops, eng.attn_timer = real_ops, None
     tele_sum = tele.summary() if tele else None
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -936,6 +985,17 @@ def measure(args, name, device, rank, world, parallel, layout, group, weights=No
         res["telemetry"] = tele_sum
     if timed is not None:
         tot = timed.totals_ms()
+        if native_timer is not None:
+            nat = native_timer.totals_ms()
+            if not fraction:                                      # the per-operator extra pass bracketed the same launches once more: keep the native pass's
+                tot["prefill_attn"] = (0.0, 0)
+                for t_ in ("prune_keys", "norm_keys", "prune_staged"):
+                    if t_ in tot:
+                        tot[t_] = (0.0, 0)
+            tot["prefill_attn"] = (tot["prefill_attn"][0] + nat["attn"][0], tot["prefill_attn"][1] + nat["attn"][1])
+            if "prune_keys" in tot:
+                tot["prune_keys"] = (tot["prune_keys"][0] + nat["prune"][0], tot["prune_keys"][1] + nat["prune"][1])
+            res["segment_path"] = "qp_prefill_segment: one library call per segment (all layers); attention / prune bracketed by events the library records"
         att_ms, att_n = tot["prefill_attn"]
         att_local = local_attn_flops(spec, cfg, plan, world, rank, parallel, layout, att)
         ach = att_local / (att_ms * 1e-3) / 1e12

@@ -296,6 +296,59 @@ int qp_linear_tune(qp_ctx* ctx, const void* x, const void* const* weights, int n
 /* out = y * sigmoid(1.702 y) with torch's bf16 rounding steps (hidden_act = quick_gelu). */
 int qp_quick_gelu(qp_ctx* ctx, const void* x, void* out, int64_t n_elems, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------------------------
+ * One segment (a video group, or the prompt tail) through ALL decoder layers in one call: the reference's patched decoder layer
+ * (lvu/models/qwen25_lvu.py:122-212) with its attention (:29-120) and prune hook (lvu/utils.py:197-376), looped over the layers the way
+ * the group loop does (:671-717) — on the host side this replaces ~13 calls per layer from the caller's language with one call per
+ * segment.  It issues exactly the launches the per-operator entry points above issue, in the same order, on `stream`:
+ *   x = RMSNorm(h += delta) -> qkv = x Wqkv^T + b -> M-RoPE + K/V append (staging rows + 16-bit norm keys when the layer prunes, the cache
+ *   tail otherwise) -> MFMA attention over (cache prefix, new rows) -> o = att Wo^T -> [k smallest norm keys kept: rows staging -> cache tail]
+ *   -> x = RMSNorm(h += o) -> act = SiLU(x Wg^T) * (x Wu^T) -> delta = act Wd^T;  after the last layer h += delta.
+ * Single-device key-norm path only (prune modes QP_PRUNE_KEY_NORMS_SMALL / QP_PRUNE_KEY_NORMS with a head layout qp_rope_append_keys can
+ * fuse); tensor / group-token parallel layers, value-norm and query-score modes and hidden-state pruning stay with the per-operator calls.
+ * GEMMs go through qp_linear_act's plans (tune the shapes with qp_linear_tune first); `split_*` cut a projection's rows into two GEMMs
+ * ([0, split) and [split, n); 0 = one GEMM), `gate_up_two_gemms` runs gate and up as two [n, I] GEMMs — the decompositions the caller's
+ * tuner found fastest for this row count (hipBLASLt's pick is erratic in M).
+ * cache_len (HOST, n_layers, in/out): rows in use per layer.  k_keep (HOST, n_layers): tokens the layer keeps, or -1 = append all n.
+ * kept_idx (device int32, n_layers rows of kept_idx_stride): layer l's ascending kept list.  attn_events / prune_events: NULL, or
+ * 2*n_layers hipEvent_t recorded right before / after each layer's attention / prune launch (measurement).  Nothing is allocated,
+ * nothing synchronises. */
+typedef struct qp_layer {
+  const void* ln1;        /* bf16 [hidden] */
+  const void* w_qkv;      /* bf16 [(n_q + 2 n_kv) * 128][hidden], rows: q heads, k heads, v heads */
+  const void* b_qkv;      /* bf16 [(n_q + 2 n_kv) * 128] */
+  const void* w_o;        /* bf16 [hidden][n_q * 128] */
+  const void* ln2;        /* bf16 [hidden] */
+  const void* w_gate_up;  /* bf16 [2 * intermediate][hidden], rows: gate then up */
+  const void* w_down;     /* bf16 [hidden][intermediate] */
+  void* k_cache;          /* bf16 [n_kv][capacity][128] of this layer */
+  void* v_cache;
+} qp_layer;
+
+typedef struct qp_segment {
+  int32_t n_layers, hidden, n_q_heads, n_kv_heads, head_dim, intermediate;
+  float rms_eps, attn_scale;
+  int64_t n;                    /* rows of this segment */
+  int64_t cache_capacity;       /* rows per head of every layer's cache (head stride = capacity * head_dim) */
+  int32_t prune_mode;           /* enum qp_prune_mode (key-row modes only) */
+  int32_t attend_prefix;        /* 0: a video group under adaptive_local_attention = False (qwen25_lvu.py:700-714): no cache prefix */
+  int64_t split_qkv, split_o, split_gate_up, split_down;
+  int32_t gate_up_two_gemms, reserved_;
+  void *h, *x, *qkv, *q, *att, *o, *gate_up, *act, *down;     /* bf16 [n][...] activations, caller-owned */
+  void *k_stage, *v_stage;      /* bf16 [n_kv][n][128]: the segment's new K/V while the layer prunes */
+  uint16_t* norm_keys;          /* [n] */
+  int32_t* kept_idx;
+  int64_t kept_idx_stride;
+  const void *cos, *sin;        /* M-RoPE table of the segment (qp_mrope_table) */
+  void* attn_ws;  size_t attn_ws_bytes;
+  void* gemm_ws;  size_t gemm_ws_bytes;
+  void** attn_events;
+  void** prune_events;          /* same, around each pruning layer's qp_prune_keys launch (entries of non-pruning layers are not recorded) */
+} qp_segment;
+
+int qp_prefill_segment(qp_ctx* ctx, const qp_segment* seg, const qp_layer* layers, int64_t* cache_len, const int64_t* k_keep,
+                       void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -158,6 +158,12 @@ class QuickPrefillEngine:
         self._lt_only = (self.device.type == "cuda" and os.environ.get("QP_GEMM_BACKEND", "") == "lt" and hasattr(self.ops, "linear_tune"))
         # decisions are per (projection shape, rows, device) and shared by every engine of the process
         self._gemm_plans, self._gu_split, self._lt_tuned = (QuickPrefillEngine._SHARED.setdefault((str(self.device), self._tune_gemms, i), {}) for i in range(3))
+        # One call per segment instead of ~13 per layer: qp_prefill_segment sequences the same launches inside the library (single-device
+        # key-norm path; everything else keeps the per-operator loop below).  QP_NATIVE_SEGMENT=0: the per-operator loop, for A/B.
+        self._native = (self.device.type == "cuda" and hasattr(self.ops, "prefill_segment") and hasattr(self.ops, "linear_tune")
+                        and os.environ.get("QP_NATIVE_SEGMENT", "1") == "1")
+        self._native_state = None
+        self.attn_timer = None                      # bench.py: .pairs(n_layers, what[, used]) -> (c_void_p * 2L) of hipEvent_t recorded around each attention / prune launch
         self.kept_trace: Optional[list] = None      # tests: set to [] to record kept indices per (group, layer)
         self.hidden_trace: Optional[list] = None    # tests: set to [] to record the residual stream after every layer (fp32 copy)
         self.seq_pos = 0                            # tokens of the original sequence consumed so far
@@ -263,7 +269,7 @@ class QuickPrefillEngine:
 
     def _lt_linear(self, key: str, x: torch.Tensor, w: torch.Tensor, out: torch.Tensor, bias=None) -> bool:
         """hipBLASLt through the library for ANY row count (QP_GEMM_BACKEND=lt); False when plan selection failed for this shape."""
-        lk = (key, x.shape[0], tuple(w.shape), bias is not None, "lt-only")
+        lk = ("lt", x.shape[0], w.shape[0], w.shape[1], bias is not None)     # = the library's plan key: tuned once, whoever asks first
         ok = self._lt_tuned.get(lk)
         if ok is None:
             try:
@@ -422,6 +428,8 @@ class QuickPrefillEngine:
             pos = pos.index_select(1, row_idx.long())
             n = pos.shape[1]
         assert embeds.shape[0] == n
+        if self._native_segment_ok(n, prune, row_idx):
+            return self._forward_segment_native(embeds, pos, prune, video_group)
         L = self.n_layers_total                      # effective_k's decay uses the GLOBAL layer index / count
         cos, sin = ops.mrope_table(pos.contiguous(), s.mrope_section, s.rope_theta, D)
         hbufs, hsel = (self.b_h, self.b_h2), 0
@@ -512,6 +520,114 @@ class QuickPrefillEngine:
             if self.hidden_trace is not None:                                # the layer's output = h + MLP (the add itself is deferred)
                 self.hidden_trace.append((l, h.float() + dn.float()))
         ops.add_inplace(h, delta)                                            # last residual                  (:198)
+        return h
+
+    # ------------------------------------------------------------------ one call per segment (qp_prefill_segment)
+    def _native_segment_ok(self, n: int, prune: bool, row_idx) -> bool:
+        if not self._native or self.tp_on or row_idx is not None or self.hidden_trace is not None or n < 1 or self._prune_probe:
+            return False
+        if not prune:
+            return True
+        if self.query_mode or self._hidden_prune_on(True) or self.norm_source != 0:
+            return False
+        return bool(self._keys_path and n <= self.ops.PRUNE_KEYS_MAX_N and self.ops.can_fuse_keys(self.hq, self.hkv))
+
+    def _native_gemm_plan(self, n: int):
+        """Row decomposition of the four projections for the one-call path, from timings of the library's OWN GEMM path (qp_linear_act
+        after qp_linear_tune) at this row count: whole, or rows [0, q*floor(n/q)) + the remainder (hipBLASLt's pick is erratic in M, see
+        _linear), gate/up fused or as two GEMMs.  -> (split_qkv, split_o, split_gate_up, split_down, gate_up_two)."""
+        key = ("native", n, self.hq, self.hkv, self.li, self.spec.hidden)
+        plan = self._gemm_plans.get(key)
+        if plan is not None:
+            return plan
+        lws, li, d = self.w.layers, self.li, self.spec.hidden
+        x, act, att = self.b_x[:n], self.b_act[:n], self.b_att[:n].view(n, self.hq * self.D)
+
+        def run(name, xin, wsel, out, bias, split):
+            blocks = [(0, n)] if not split else [(0, split), (split, n)]
+            for r0, r1 in blocks:
+                xb, ob = xin[r0:r1], out[r0:r1]
+                w0 = wsel(lws[0])
+                lk = ("lt", r1 - r0, w0.shape[0], w0.shape[1], bias is not None)  # shared with _lt_linear: one tuning per GEMM shape
+                if lk not in self._lt_tuned:
+                    self.ops.linear_tune(xb, [wsel(lw) for lw in lws], bias, ob, self.ops.ACT_NONE)
+                    self._lt_tuned[lk] = True
+                self.ops.linear_act(xb, wsel(lws[0]), bias, ob, self.ops.ACT_NONE)
+
+        def best_split(name, xin, wsel, out, bias):
+            if not (self._tune_gemms and n >= 256):
+                run(name, xin, wsel, out, bias, 0)
+                return 0, 0.0
+            cands = [0] + [m for (_, m), *rest in [p for p in self._row_plans(n) if len(p) == 2]]
+            times = [(self._time(lambda c=c: run(name, xin, wsel, out, bias, c)), c) for c in cands]
+            whole = times[0][0]
+            t, c = min(times)
+            return (c, t) if t < 0.97 * whole else (0, whole)
+
+        s_qkv, _ = best_split("qkv", x, lambda lw: lw.w_qkv, self.b_qkv[:n], lws[0].b_qkv)
+        s_o, _ = best_split("o", att, lambda lw: lw.w_o, self.b_o[:n], None)
+        s_dn, _ = best_split("down", act, lambda lw: lw.w_down, self.b_dn[:n], None)
+        flat = self.b_gu.view(-1)
+        gbuf, ubuf = flat[: n * li].view(n, li), flat[n * li: 2 * n * li].view(n, li)
+        s_gu, t_f = best_split("gate_up", x, lambda lw: lw.w_gate_up, self.b_gu[:n], None)
+        two = 0
+        if self._tune_gemms and n >= 256:
+            s_g, t_g = best_split("gate", x, lambda lw: lw.w_gate_up[:li], gbuf, None)
+            if t_f > 0 and 2 * t_g < 0.97 * t_f:
+                run("up", x, lambda lw: lw.w_gate_up[li:], ubuf, None, s_g)          # same shape as "gate": plans exist
+                two, s_gu = 1, s_g
+        plan = (s_qkv, s_o, s_gu, s_dn, two)
+        if os.environ.get("QP_ENGINE_DEBUG"):
+            print(f"[engine] one-call segment path, n={n}: row splits qkv/o/gate_up/down = {s_qkv}/{s_o}/{s_gu}/{s_dn}, gate_up as "
+                  f"{'two GEMMs' if two else 'one GEMM'}", flush=True)
+        self._gemm_plans[key] = plan
+        return plan
+
+    def _forward_segment_native(self, embeds: torch.Tensor, pos: torch.Tensor, prune: bool, video_group: bool) -> torch.Tensor:
+        """forward_segment through qp_prefill_segment: the same launches in the same order, sequenced inside the library."""
+        import ctypes
+        from .native import QpLayer, QpSegment
+        s, ops, cfg, D = self.spec, self.ops, self.cfg, self.D
+        n, L, Lt = pos.shape[1], len(self.w.layers), self.n_layers_total
+        st = self._native_state
+        if st is None:
+            layers = (QpLayer * L)()
+            for l, lw in enumerate(self.w.layers):
+                for f, t in (("ln1", lw.ln1), ("w_qkv", lw.w_qkv), ("b_qkv", lw.b_qkv), ("w_o", lw.w_o), ("ln2", lw.ln2), ("w_gate_up", lw.w_gate_up),
+                             ("w_down", lw.w_down), ("k_cache", self.arena.k(l)), ("v_cache", self.arena.v(l))):
+                    assert t.is_contiguous() or f in ("k_cache", "v_cache")
+                    setattr(layers[l], f, t.data_ptr())
+            seg = QpSegment()
+            seg.n_layers, seg.hidden, seg.n_q_heads, seg.n_kv_heads, seg.head_dim, seg.intermediate = L, s.hidden, self.hq, self.hkv, D, self.li
+            seg.rms_eps, seg.attn_scale, seg.cache_capacity = s.rms_eps, D ** -0.5, self.arena.capacity
+            self.b_idx_all = torch.empty(L, self.n_max, dtype=torch.int32, device=self.device)
+            for f, t in (("h", self.b_h), ("x", self.b_x), ("qkv", self.b_qkv), ("q", self.b_q), ("att", self.b_att), ("o", self.b_o), ("gate_up", self.b_gu),
+                         ("act", self.b_act), ("down", self.b_dn), ("k_stage", self.b_stage[0]), ("v_stage", self.b_stage[1]),
+                         ("norm_keys", getattr(self, "b_keys", None)), ("kept_idx", self.b_idx_all)):
+                setattr(seg, f, None if t is None else t.data_ptr())
+            seg.kept_idx_stride = self.n_max
+            st = self._native_state = (seg, layers, (ctypes.c_int64 * L)(), (ctypes.c_int64 * L)())
+        seg, layers, cache_len, k_keep = st
+        cos, sin = ops.mrope_table(pos.contiguous(), s.mrope_section, s.rope_theta, D)
+        keeps = [effective_k(n, cfg, self.l0 + l, Lt) if prune else None for l in range(L)]
+        for l in range(L):
+            cache_len[l], k_keep[l] = self.arena.len[l], (-1 if keeps[l] is None else keeps[l])
+        seg.split_qkv, seg.split_o, seg.split_gate_up, seg.split_down, seg.gate_up_two_gemms = self._native_gemm_plan(n)
+        h = self.b_h[:n]                             # (plan selection used x / att / act and the projection outputs as scratch, not h)
+        h.copy_(embeds)
+        seg.n, seg.prune_mode = n, self.prune_mode
+        seg.attend_prefix = 0 if (video_group and not cfg.adaptive_local_attention) else 1
+        seg.cos, seg.sin = cos.data_ptr(), sin.data_ptr()
+        ws = ops.attn_workspace(n, self.arena.len if seg.attend_prefix else [0], self.hq, self.hkv)
+        seg.attn_ws, seg.attn_ws_bytes = ws.data_ptr(), ws.numel()
+        seg.attn_events = self.attn_timer.pairs(L, "attn") if self.attn_timer is not None else None
+        seg.prune_events = self.attn_timer.pairs(L, "prune", [k is not None for k in keeps]) if self.attn_timer is not None else None
+        ops.prefill_segment(seg, layers, cache_len, k_keep)
+        for l in range(L):
+            self.arena.len[l] = int(cache_len[l])
+            if self.kept_trace is not None:
+                self.kept_trace.append((l, None if keeps[l] is None else self.b_idx_all[l, :keeps[l]].clone()))
+        self._seg_rows = None
         return h
 
     # ------------------------------------------------------------------ query-attention-score groups (SURVEY 8 f4)

@@ -31,8 +31,25 @@ class QuickPrefillError(RuntimeError):
 _c = ctypes
 _vp, _i64, _i32, _f32, _sz = _c.c_void_p, _c.c_int64, _c.c_int, _c.c_float, _c.c_size_t
 
+class QpLayer(_c.Structure):
+    """struct qp_layer (include/quickprefill.h): one decoder layer's weight and cache pointers."""
+    _fields_ = [(n, _vp) for n in ("ln1", "w_qkv", "b_qkv", "w_o", "ln2", "w_gate_up", "w_down", "k_cache", "v_cache")]
+
+
+class QpSegment(_c.Structure):
+    """struct qp_segment (include/quickprefill.h)."""
+    _fields_ = ([(n, _c.c_int32) for n in ("n_layers", "hidden", "n_q_heads", "n_kv_heads", "head_dim", "intermediate")] +
+                [("rms_eps", _f32), ("attn_scale", _f32), ("n", _i64), ("cache_capacity", _i64), ("prune_mode", _c.c_int32),
+                 ("attend_prefix", _c.c_int32), ("split_qkv", _i64), ("split_o", _i64), ("split_gate_up", _i64), ("split_down", _i64),
+                 ("gate_up_two_gemms", _c.c_int32), ("reserved_", _c.c_int32)] +
+                [(n, _vp) for n in ("h", "x", "qkv", "q", "att", "o", "gate_up", "act", "down", "k_stage", "v_stage", "norm_keys", "kept_idx")] +
+                [("kept_idx_stride", _i64), ("cos", _vp), ("sin", _vp), ("attn_ws", _vp), ("attn_ws_bytes", _sz), ("gemm_ws", _vp),
+                 ("gemm_ws_bytes", _sz), ("attn_events", _c.POINTER(_vp)), ("prune_events", _c.POINTER(_vp))])
+
+
 # name -> (restype, argtypes): exactly the declarations of include/quickprefill.h
 SIGNATURES = {
+    "qp_prefill_segment": (_i32, [_vp, _c.POINTER(QpSegment), _c.POINTER(QpLayer), _c.POINTER(_i64), _c.POINTER(_i64), _vp]),
     "qp_create": (_i32, [_c.POINTER(_vp), _i32]),
     "qp_destroy": (None, [_vp]),
     "qp_last_error": (_c.c_char_p, []),
@@ -270,6 +287,22 @@ class QuickPrefillOps:
         self._check(self.lib.qp_prune_tail(self.ctx, k_cache.data_ptr(), v_cache.data_ptr(), head_stride, past_len, n, k, n_kv,
                                            head_dim, kept_idx.data_ptr(), int(mode), workspace.data_ptr(),
                                            workspace.numel() * workspace.element_size(), self._stream()))
+
+    # -- one segment through all layers in one call (qp_prefill_segment)
+    def attn_workspace(self, n: int, prefix_lens, n_q: int, n_kv: int) -> torch.Tensor:
+        """Scratch large enough for the attention launch of n new rows over ANY of the given prefix lengths (the launch plan, and with it the
+        size, is chosen per shape)."""
+        need = max(int(self.lib.qp_attn_workspace_bytes(self.ctx, n, int(p), n_q, n_kv)) for p in set(prefix_lens))
+        if self._attn_ws is None or self._attn_ws.numel() < need:
+            self._attn_ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=self.device)
+        return self._attn_ws
+
+    def prefill_segment(self, seg: "QpSegment", layers, cache_len, k_keep):
+        """seg: a filled QpSegment; layers: (QpLayer * L) array; cache_len / k_keep: (c_int64 * L) arrays (cache_len is updated in place).
+        The hipBLASLt scratch of the current stream and the stream itself are filled in here."""
+        ws = self._lt_workspace()
+        seg.gemm_ws, seg.gemm_ws_bytes = ws.data_ptr(), ws.numel()
+        self._check(self.lib.qp_prefill_segment(self.ctx, ctypes.byref(seg), layers, cache_len, k_keep, self._stream()))
 
     def sp_unpack(self, gathered, world, n_kv, m2, head_dim, n, k_stage, v_stage, stage_head_stride, sumsq_out):
         self._check(self.lib.qp_sp_unpack(self.ctx, gathered.data_ptr(), world, n_kv, m2, head_dim, n, k_stage.data_ptr(), v_stage.data_ptr(),

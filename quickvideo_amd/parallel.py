@@ -91,6 +91,7 @@ class ParallelContext:
     rank: int = 0
     group: object = None                     # None = the default group
     sp_efficiency: Optional[Dict[int, float]] = None
+    grid_override: Optional[Tuple[int, int]] = None   # (pp, sp) forced for the next videos (bench.py: warm-up clip on the main video's grid)
     _subgroups: dict = field(default_factory=dict)
 
     @property
@@ -101,6 +102,8 @@ class ParallelContext:
         """(pp, sp) for a video of n_groups groups under this context's mode (tp / single: (1, 1))."""
         if not self.on or self.mode == "tp":
             return 1, 1
+        if self.grid_override is not None:
+            return self.grid_override
         if self.mode == "sp":
             return 1, self.world
         if self.mode == "pp":

@@ -450,3 +450,31 @@ def test_gemm_tuning_does_not_change_results(monkeypatch):
         outs.append((list(eng.arena.len), logits.numpy()))
     assert outs[0][0] == outs[1][0]
     check_logits(outs[1][1], outs[0][1])
+
+
+def test_one_call_segment_path_equals_the_per_operator_loop(monkeypatch):
+    """qp_prefill_segment (round 4): one library call per segment sequencing the SAME launches the per-operator loop issues.  With the same
+    GEMM path on both sides (QP_GEMM_BACKEND=lt: every projection through qp_linear_act's plan for its shape, no row splits on either
+    side because QP_TUNE_GEMMS=0) the two must agree BIT FOR BIT: kept lists of every (group, layer), cache lengths, the cache rows
+    themselves and the first-token logits; also under adaptive_local_attention=False, decay (different k per layer) and with layers that do
+    not prune (rho = 1).  And the default configuration (its own tuned decompositions) stays within the engine's stated tolerance of the
+    oracle (that is what every other test of this file now exercises)."""
+    monkeypatch.setenv("QP_GEMM_BACKEND", "lt")
+    monkeypatch.setenv("QP_TUNE_GEMMS", "0")
+    spec_o, w, plan, pos, delta, embeds = make_case(24, 16, 24, 8, 15, 20)                  # 3 groups x 384 tokens
+    for kw in (dict(top_p=0.5), dict(top_p=0.5, adaptive_local_attention=False), dict(top_p=0.5, top_k_decay_type="linear", top_k_decay_factor=0.5),
+               dict(top_p=None)):
+        cfg = LVUConfig("x", video_group_size=8, **kw)
+        runs = []
+        for native in ("1", "0"):
+            monkeypatch.setenv("QP_NATIVE_SEGMENT", native)
+            eng, logits = run_gpu(TINY, w, plan, pos, embeds, cfg)
+            assert (eng._native_state is not None) == (native == "1")
+            kept = [None if k is None else k.cpu().numpy() for _, k in eng.kept_trace]
+            rows = [eng.arena.k(l)[:, :eng.arena.len[l]].cpu().view(torch.int16).numpy().copy() for l in range(3)]
+            runs.append((list(eng.arena.len), kept, rows, logits.numpy().copy()))
+        (l1, k1, r1, g1), (l0, k0, r0, g0) = runs
+        assert l1 == l0, kw
+        assert len(k1) == len(k0) and all((a is None) == (b is None) and (a is None or np.array_equal(a, b)) for a, b in zip(k1, k0)), kw
+        assert all(np.array_equal(a, b) for a, b in zip(r1, r0)), kw
+        assert np.array_equal(g1, g0), (kw, float(np.max(np.abs(g1 - g0))))
