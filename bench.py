@@ -1375,7 +1375,7 @@ def main():
             out["nccl_preflight"] = {"backend": torch.distributed.get_backend(), "world_size": 1,
                                      "what": "the timed pass ran in the tensor-parallel layout on a 1-rank RCCL group: per layer 2 x all_reduce of "
                                              "[n, d] bf16 + 1 x all_gather_into_tensor of the fp32 key sums, norm keys through qp_norm_keys"}
-        for k in ("roofline_prune", "hbm_kernels", "kernel_ms_per_pass", "telemetry"):
+        for k in ("roofline_prune", "hbm_kernels", "kernel_ms_per_pass", "telemetry", "segment_path"):
             if k in res:
                 out[k] = res[k]
         if world > 1:
