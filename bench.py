@@ -1051,7 +1051,7 @@ def collect_attention_traffic(name, spec, plan, cfg):
     alg = 2 * (n * spec.n_heads * spec.head_dim * 2) + 2 * ((P + ks[g0] // 2 + n) * spec.n_kv_heads * spec.head_dim * 2)   # Q + O rows, K + V rows (mean prefix of the 2 groups)
     tmp = tempfile.mkdtemp(prefix="qp_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp", QP_BENCH_NO_PMC="1")
-    vals, t0 = {}, time.perf_counter()
+    vals, vals_p, t0 = {}, {}, time.perf_counter()
     try:
         for c in ("FETCH_SIZE", "WRITE_SIZE"):
             cmd = [exe, "--kernel-trace", "--pmc", c, "--output-format", "csv", "-d", tmp, "-o", f"pmc_{c}", "--", sys.executable,
@@ -1061,22 +1061,32 @@ def collect_attention_traffic(name, spec, plan, cfg):
             if r.returncode != 0 or not files:
                 progress(f"rocprofv3 --pmc {c} pass failed (rc {r.returncode}): {r.stderr[-300:]}")
                 return None
-            acc = []
+            acc, acc_p = [], []
             for row in csv.DictReader(open(files[-1])):
                 if row["Counter_Name"] == c and "attn_fwd_kernel_s6" in row["Kernel_Name"]:
                     acc.append(float(row["Counter_Value"]))
+                elif row["Counter_Name"] == c and "prune_keys_kernel" in row["Kernel_Name"]:
+                    acc_p.append(float(row["Counter_Value"]))
             # the window's launches are the LAST 2 x L of the child run (its warm-up runs the first groups of the video)
-            acc = acc[-2 * spec.n_layers:]
+            acc, acc_p = acc[-2 * spec.n_layers:], acc_p[-2 * spec.n_layers:]
             if len(acc) < 2 * spec.n_layers:
                 return None
             vals[c] = sum(acc) / len(acc)
+            if len(acc_p) == 2 * spec.n_layers:
+                vals_p[c] = sum(acc_p) / len(acc_p)
     except Exception as e:
         progress(f"in-run PMC collection failed: {type(e).__name__}: {e}")
         return None
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     traffic = 2 * vals["FETCH_SIZE"] * 1024 + vals["WRITE_SIZE"] * 1024
-    return {"traffic": traffic, "algorithmic_bytes_this_launch": alg, "traffic_over_algorithmic": round(traffic / alg, 3),
+    prune = None
+    if len(vals_p) == 2:                                        # the prune launch of the same window, from the same two passes
+        kq = ks[g0]
+        moved = 2 * n + 2 * (kq * spec.n_kv_heads * spec.head_dim * 2 * 2) + 4 * kq     # 2-byte keys in, kept K/V rows in and out, indices out
+        pt = 2 * vals_p["FETCH_SIZE"] * 1024 + vals_p["WRITE_SIZE"] * 1024
+        prune = {"traffic": pt, "bytes_this_launch_moves": moved, "traffic_over_bytes_this_launch_moves": round(pt / moved, 3)}
+    return {"traffic": traffic, "prune": prune, "algorithmic_bytes_this_launch": alg, "traffic_over_algorithmic": round(traffic / alg, 3),
             "fetch_size_kb": round(vals["FETCH_SIZE"], 1), "write_size_kb": round(vals["WRITE_SIZE"], 1),
             "window": f"groups [{g0}, {g0 + 2}) of {G}: n = {n} new tokens over ~{P} pruned prefix rows, {2 * spec.n_layers} launches averaged",
             "source": f"collected IN THIS RUN: two `rocprofv3 --kernel-trace --pmc <counter>` child runs of this script (`--window {g0}:{g0 + 2}`), "
@@ -1328,6 +1338,11 @@ def main():
             r_["traffic_committed_builder_box"] = {"traffic": r_.get("traffic"), "source": r_.get("traffic_source")}
             r_["traffic"], r_["traffic_source"], r_["traffic_over_algorithmic"] = live["traffic"], live["source"], live["traffic_over_algorithmic"]
             r_["traffic_window"] = {k: live[k] for k in ("window", "algorithmic_bytes_this_launch", "fetch_size_kb", "write_size_kb")}
+            if live.get("prune") and res.get("roofline_prune"):
+                rp = res["roofline_prune"]
+                rp["traffic_committed_builder_box"] = {"traffic": rp.get("traffic"), "source": rp.get("traffic_source")}
+                rp.update(live["prune"])
+                rp["traffic_source"] = live["source"]
             progress("attention HBM traffic collected in-run (rocprofv3 --pmc)")
 
     legs = {"decode": None, "peaked": None, "video_to_first_token": None, "host_contention": None, "cfg4ref": None, "cfg2": None,

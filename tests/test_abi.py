@@ -93,12 +93,12 @@ def test_pipelined_attention_kernel_does_not_spill(src_name, kernel, min_kernels
 C_CALLER = os.path.join(ROOT, "tests", "c", "abi_prune_attn.c")
 
 
-def build_c_caller(out):
+def build_c_caller(out, source=None):
     """gcc, plain C99: the boundary is a C ABI (no C++ types, no torch types), and a C program links against the library."""
     import subprocess
     from quickvideo_amd import native
     lib_dir = os.path.dirname(native.LIB_PATH)
-    cmd = ["gcc", "-std=c99", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"), C_CALLER, "-o", out,
+    cmd = ["gcc", "-std=c99", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"), source or C_CALLER, "-o", out,
            "-L" + lib_dir, "-lquickprefill", "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib"]
     p = subprocess.run(cmd, capture_output=True, text=True)
     assert p.returncode == 0, p.stderr[-2000:]
@@ -114,6 +114,7 @@ def test_header_is_plain_c_and_library_has_no_torch_dependency(tmp_path):
     libs = re.findall(r"NEEDED.*\[(.*?)\]", needed)
     assert libs and not [l for l in libs if re.search(r"torch|c10|python", l)], libs
     build_c_caller(str(tmp_path / "abi_c"))                     # compiles and links here; runs on the GPU box (tests/test_gpu_ops.py)
+    build_c_caller(str(tmp_path / "abi_seg"), os.path.join(ROOT, "tests", "c", "abi_segment.c"))
 
 
 def test_hbm_bound_kernels_use_no_scratch(tmp_path):
@@ -139,3 +140,29 @@ def test_hbm_bound_kernels_use_no_scratch(tmp_path):
             assert private == 0 and spills == 0, f"{name}: {kernel} uses {private} B of scratch per lane ({spills} spilled VGPRs)"
             seen += 1
     assert seen >= 15
+
+
+def test_segment_structs_have_the_same_layout_in_c_and_in_the_ctypes_mirror(tmp_path):
+    """struct qp_layer / struct qp_segment cross the boundary BY LAYOUT (qp_prefill_segment): a field added on one side only would shift
+    every pointer behind it.  gcc prints sizeof / offsetof of every field from include/quickprefill.h; the ctypes mirror in
+    quickvideo_amd/native.py must agree field by field."""
+    import subprocess
+    from quickvideo_amd.native import QpLayer, QpSegment
+    src = tmp_path / "layout.c"
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "quickprefill.h"', 'int main(void) {']
+    for cname, cls in (("qp_layer", QpLayer), ("qp_segment", QpSegment)):
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for f, _t in cls._fields_:
+            lines.append(f'  printf("{cname}.{f} %zu\\n", offsetof({cname}, {f}));')
+    lines += ['  return 0;', '}']
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    p = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(ROOT, "include"),
+                        str(src), "-o", str(exe)], capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    got = dict(l.split() for l in subprocess.run([str(exe)], capture_output=True, text=True).stdout.splitlines())
+    import ctypes
+    for cname, cls in (("qp_layer", QpLayer), ("qp_segment", QpSegment)):
+        assert int(got[cname]) == ctypes.sizeof(cls), (cname, got[cname], ctypes.sizeof(cls))
+        for f, _t in cls._fields_:
+            assert int(got[f"{cname}.{f}"]) == getattr(cls, f).offset, (cname, f)

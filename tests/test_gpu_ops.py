@@ -1092,3 +1092,16 @@ def test_c_abi_from_a_plain_c_program(tmp_path):
     p = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert p.returncode == 0, (p.stdout, p.stderr[-1000:])
     assert "kept indices and compacted rows exact" in p.stdout and "output row equals the value row" in p.stdout
+
+
+def test_c_abi_segment_from_a_plain_c_program(tmp_path):
+    """tests/c/abi_segment.c: a C99 host (no torch, no Python) runs the whole decoder-layer loop — a pruning group and a prompt tail through two
+    layers — once with ONE qp_prefill_segment call and once operator by operator; hidden rows, kept lists, cache lengths and cache rows
+    must be bit-identical."""
+    import subprocess
+    from tests.test_abi import build_c_caller
+    exe = str(tmp_path / "abi_seg")
+    build_c_caller(exe, os.path.join(os.path.dirname(os.path.abspath(__file__)), "c", "abi_segment.c"))
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=180)
+    assert p.returncode == 0, (p.stdout, p.stderr[-1000:])
+    assert "bit-identical" in p.stdout and "cache_len 184 184" in p.stdout
