@@ -319,6 +319,9 @@ def video_messages(name, video, nframes=None):
     return [{"role": "user", "content": [entry, {"type": "text", "text": QUESTION}]}]
 
 
+_PAR_CTX: dict = {}          # world -> ParallelContext (its sub-groups are created once per grid shape)
+
+
 def build_workload(name, device, rank, world, seed=0, parallel="single", layout=(1, 1), weights=None):
     model, frames, fh, fw, gs, rho, prefix, tail = CONFIGS[name]
     spec = PRESETS[model]
@@ -336,9 +339,12 @@ def build_workload(name, device, rank, world, seed=0, parallel="single", layout=
                                            layer_range=pp_layer_split(spec.n_layers, pp_n, stage) if pp_n > 1 else None)
     kept = sum(effective_k(n, cfg, 0, spec.n_layers) or n for n in plan.tokens)
     cap = kept + plan.tail_len + 384                             # room for the pipeline leg's prompt + decoded tokens
-    eng = QuickPrefillEngine(weights, cfg, capacity=cap, max_group_tokens=max(plan.tokens + [plan.tail_len]) + 16, device=device,
-                             sp_rank=sp_rank, sp_size=sp_n, pp_rank=stage, pp_size=pp_n,
-                             pp_peers=[s * sp_n + sp_rank for s in range(pp_n)] if pp_n > 1 else None)
+    # the engine's process groups come from the PRODUCT's wiring (parallel.ParallelContext.engine_kwargs: stage groups, one 2-rank group per
+    # direction of every pipeline hand-off) — the same objects LVU(model_init_kwargs={"parallel": ...}) builds
+    par_kw = {}
+    if world > 1 and not tp:
+        par_kw = _PAR_CTX.setdefault(world, qp_parallel.ParallelContext("auto", world, rank)).engine_kwargs(pp_n, sp_n)
+    eng = QuickPrefillEngine(weights, cfg, capacity=cap, max_group_tokens=max(plan.tokens + [plan.tail_len]) + 16, device=device, **par_kw)
     eng.rope_delta = int(delta)                                  # decode positions continue at sequence index + delta
     g = torch.Generator(device=device); g.manual_seed(1234)      # same embeddings on every rank
     # synthetic ViT output / text embeddings: N(0, 1) scaled like embedding rows (the ViT front end is timed in video_to_first_token)
@@ -874,13 +880,6 @@ def measure(args, name, device, rank, world, parallel, layout, group, weights=No
         eng.tp_group = tp_group_1rank          # --nccl-preflight: every layer's collectives run on the 1-rank RCCL group
     if parallel == "tp":
         eng.tp_group = group
-    elif world > 1:
-        pp_n, sp_n = layout
-        if sp_n == world:
-            eng.sp_group = group
-        elif sp_n > 1:                        # every rank creates every stage's group, in the same order
-            stage_groups = [torch.distributed.new_group(ranks=list(range(s * sp_n, (s + 1) * sp_n))) for s in range(pp_n)]
-            eng.sp_group = stage_groups[rank // sp_n]
     G, K = len(plan.tokens), args.steps
     starts = group_starts(plan)
     tokens = sum(plan.tokens)                 # tokens prefilled in the group loop (the reference's total_prefill span)

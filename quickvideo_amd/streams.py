@@ -9,7 +9,7 @@ group g+1's frames waited for ViT(g) to finish) or, once a hipGraph capture had 
 VERDICT r3 Weak #7's "ViT-scheduling artefact").  High-priority streams (priority -1) live on queues of their own.
 
 So the pipeline does not take "a stream" and hope: `side_streams` hands out a high-priority copy stream and a ViT stream and VERIFIES on
-the device that work on each overtakes a kernel train submitted earlier on the main stream and on the other one (a ~3 ms test per
+the device that work on each overtakes a kernel train submitted earlier on the main stream and on the other one (a ~10 ms test per
 candidate, once per (device, main stream) and cached)."""
 from __future__ import annotations
 
@@ -21,13 +21,38 @@ import torch
 _CACHE: Dict[Tuple[int, int], Tuple[torch.cuda.Stream, torch.cuda.Stream, dict]] = {}
 
 
+_TRAIN_REPS: Dict[int, int] = {}
+
+
+def _train_reps(a: torch.Tensor, stream: torch.cuda.Stream) -> int:
+    """GEMM repetitions that keep a stream busy for ~8 ms on this device (calibrated once): long against launch latencies and event
+    granularity, so that "finished in under half the train's time" is unambiguous."""
+    key = a.device.index or 0
+    if key not in _TRAIN_REPS:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        with torch.cuda.stream(stream):
+            for _ in range(4):
+                torch.mm(a, a)
+            e0.record(stream)
+            for _ in range(32):
+                torch.mm(a, a)
+            e1.record(stream)
+        e1.synchronize()
+        per = max(e0.elapsed_time(e1) / 32, 1e-3)
+        _TRAIN_REPS[key] = int(min(4000, max(16, 8.0 / per)))
+    return _TRAIN_REPS[key]
+
+
 def _overtakes(first: torch.cuda.Stream, second: torch.cuda.Stream, a: torch.Tensor, probe: torch.Tensor) -> bool:
     """True iff a tiny kernel on `second` finishes well before a kernel train submitted EARLIER on `first` (= separate hardware queues)."""
-    e0, ea, eb = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    with torch.cuda.stream(second):                                     # first use of a stream sets up its queue: not part of the test
+        probe.add_(1)
+    reps = _train_reps(a, first)
     torch.cuda.synchronize(a.device)
+    e0, ea, eb = (torch.cuda.Event(enable_timing=True) for _ in range(3))
     e0.record(first)
     with torch.cuda.stream(first):
-        for _ in range(24):
+        for _ in range(reps):
             torch.mm(a, a)
         ea.record(first)
     with torch.cuda.stream(second):
