@@ -67,6 +67,7 @@ def _nccl_world1_worker(rank, port, ret):
         cfg = LVUConfig("x", top_p=0.5, video_group_size=8)
         mk = lambda **kw: QuickPrefillEngine(DecoderWeights.from_named(spec, w, dev), cfg, capacity=T + 8,          # noqa: E731
                                              max_group_tokens=max(plan.tokens + [plan.tail_len]), device=dev, **kw)
+        os.environ["QP_NATIVE_SEGMENT"] = "0"       # the bit-for-bit comparison below is between two runs of the per-operator loop (same GEMM calls)
         base = _run_engine(mk(), plan, pos, embeds)
         # tensor parallel layout on a 1-rank RCCL group: 2 x all_reduce bf16 [n, d] + all_gather_into_tensor fp32 [Hkv, n] per layer
         grp = dist.new_group(ranks=[0])                                                  # bench.py builds stage groups like this
