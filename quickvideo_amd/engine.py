@@ -558,7 +558,7 @@ class QuickPrefillEngine:
             if not (self._tune_gemms and n >= 256):
                 run(name, xin, wsel, out, bias, 0)
                 return 0, 0.0
-            cands = [0] + [m for (_, m), *rest in [p for p in self._row_plans(n) if len(p) == 2]]
+            cands = [0] + [p[0][1] for p in self._row_plans(n) if len(p) == 2]        # 0 = one GEMM; m = rows [0, m) + [m, n)
             times = [(self._time(lambda c=c: run(name, xin, wsel, out, bias, c)), c) for c in cands]
             whole = times[0][0]
             t, c = min(times)
