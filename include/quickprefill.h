@@ -174,6 +174,14 @@ int qp_prune_keys(qp_ctx* ctx, const uint16_t* norm_keys, int64_t n, int64_t k, 
  * (uint16 [n], may be NULL); norm_keys_out[t] = ~pattern(score) — or ~pattern(bf16(score * ||v_t||)) when value_sumsq (fp32
  * [n_kv][n], from qp_key_sumsq over the value rows) is given — ready for qp_prune_keys: k largest scores, ties -> lowest index. */
 size_t qp_query_scores_workspace_bytes(int64_t n, int64_t m, int n_q_heads);
+/* The same scoring in two steps, for hosts that shard the heads (tensor parallelism): (1) per-head sums s1[h][t] = bf16(sum over the prompt
+ * queries of the bf16 softmax probabilities) for the LOCAL heads (same workspace as qp_query_scores); (2) after the ranks' blocks were
+ * gathered in ascending head order: mean over all heads, optional value-norm weighting (value_sumsq fp32 [n_kv_heads_total][n]),
+ * complemented sort keys.  qp_query_scores == (1) then (2) on one device, bit for bit (it IS the composition). */
+int qp_query_head_sums(qp_ctx* ctx, const void* q_prompt, const void* k_group, int64_t k_head_stride, int64_t n, int64_t m, int n_q_heads,
+                       int n_kv_heads, int head_dim, uint16_t* head_sums_out, void* workspace, size_t workspace_bytes, void* stream);
+int qp_query_scores_from_head_sums(qp_ctx* ctx, const uint16_t* head_sums, int n_heads_total, int64_t n, const float* value_sumsq,
+                                   int n_kv_heads_total, uint16_t* norm_keys_out, uint16_t* scores_out, void* stream);
 int qp_query_scores(qp_ctx* ctx, const void* q_prompt, const void* k_group, int64_t k_head_stride, int64_t n, int64_t m,
                     int n_q_heads, int n_kv_heads, int head_dim, const float* value_sumsq, uint16_t* norm_keys_out,
                     uint16_t* scores_out, void* workspace, size_t workspace_bytes, void* stream);

@@ -140,7 +140,29 @@ int qp_rope_append_keys(qp_ctx* ctx, const void* qkv, const void* cos, const voi
 
 size_t qp_query_scores_workspace_bytes(int64_t n, int64_t m, int n_q_heads) {
   if (n <= 0 || m <= 0 || n_q_heads <= 0) return 0;
-  return (size_t)n * (size_t)m * (size_t)n_q_heads * 2 + 256;
+  return (((size_t)n_q_heads * m * n * 2 + 255) & ~(size_t)255) + (size_t)n_q_heads * n * 2 + 256;      // probabilities + per-head sums
+}
+
+int qp_query_head_sums(qp_ctx* ctx, const void* q_prompt, const void* k_group, int64_t k_head_stride, int64_t n, int64_t m, int n_q_heads,
+                       int n_kv_heads, int head_dim, uint16_t* head_sums_out, void* workspace, size_t workspace_bytes, void* stream) {
+  QP_REQUIRE(ctx && q_prompt && k_group && head_sums_out && workspace, QP_ERR_INVALID, "qp_query_head_sums: NULL argument");
+  QP_REQUIRE(head_dim == 128, QP_ERR_UNSUPPORTED, "qp_query_head_sums: head_dim=%d (only 128)", head_dim);
+  QP_REQUIRE(n > 0 && m > 0 && n_q_heads > 0 && n_kv_heads > 0 && n_q_heads % n_kv_heads == 0, QP_ERR_INVALID, "qp_query_head_sums: bad sizes");
+  QP_REQUIRE(n <= 32768 && m <= 65535 && n_q_heads <= 65535, QP_ERR_UNSUPPORTED, "qp_query_head_sums: n=%lld > 32768 (one softmax row lives in LDS)",
+             (long long)n);
+  QP_REQUIRE(k_head_stride % 8 == 0 && k_head_stride >= n * head_dim, QP_ERR_INVALID, "qp_query_head_sums: bad key stride");
+  QP_REQUIRE(workspace_bytes >= qp_query_scores_workspace_bytes(n, m, n_q_heads), QP_ERR_WORKSPACE, "qp_query_head_sums: workspace %zu < %zu bytes",
+             workspace_bytes, qp_query_scores_workspace_bytes(n, m, n_q_heads));
+  QP_REQUIRE(aligned16(q_prompt) && aligned16(k_group) && aligned16(workspace), QP_ERR_INVALID, "qp_query_head_sums: alignment");
+  return qp_launch_query_head_sums(q_prompt, k_group, k_head_stride, n, m, n_q_heads, n_kv_heads, head_sums_out, workspace, (hipStream_t)stream);
+}
+
+int qp_query_scores_from_head_sums(qp_ctx* ctx, const uint16_t* head_sums, int n_heads_total, int64_t n, const float* value_sumsq,
+                                   int n_kv_heads_total, uint16_t* norm_keys_out, uint16_t* scores_out, void* stream) {
+  QP_REQUIRE(ctx && head_sums && norm_keys_out, QP_ERR_INVALID, "qp_query_scores_from_head_sums: NULL argument");
+  QP_REQUIRE(n_heads_total > 0 && n > 0 && n < (1ll << 31) && (!value_sumsq || n_kv_heads_total > 0), QP_ERR_INVALID,
+             "qp_query_scores_from_head_sums: bad sizes");
+  return qp_launch_query_scores_final(head_sums, n_heads_total, n, value_sumsq, n_kv_heads_total, norm_keys_out, scores_out, (hipStream_t)stream);
 }
 
 int qp_query_scores(qp_ctx* ctx, const void* q_prompt, const void* k_group, int64_t k_head_stride, int64_t n, int64_t m, int n_q_heads,

@@ -83,6 +83,10 @@ bool qp_rope_can_fuse_keys(int hq, int hkv);
 int qp_launch_norm_keys(const float* head_sumsq, int n_heads, int64_t n, uint16_t* norm_keys, int largest, hipStream_t s);
 int qp_launch_query_scores(const void* q_prompt, const void* k_group, int64_t k_head_stride, int64_t n, int64_t m, int hq, int hkv,
                            const float* value_sumsq, uint16_t* keys_out, uint16_t* scores_out, void* workspace, hipStream_t s);
+int qp_launch_query_head_sums(const void* q_prompt, const void* k_group, int64_t k_head_stride, int64_t n, int64_t m, int hq, int hkv,
+                              uint16_t* head_sums_out, void* workspace, hipStream_t s);
+int qp_launch_query_scores_final(const uint16_t* head_sums, int hq_total, int64_t n, const float* value_sumsq, int hkv_total, uint16_t* keys_out,
+                                 uint16_t* scores_out, hipStream_t s);
 int qp_launch_prune_keys(const uint16_t* norm_keys, int64_t n, int64_t k, const void* k_src, const void* v_src, int64_t src_head_stride,
                          int hkv, void* k_dst, void* v_dst, int64_t dst_head_stride, int64_t dst_row0, int32_t* kept, hipStream_t s);
 int qp_launch_key_sumsq(const void* k, int64_t head_stride, int64_t row0, int64_t n, int hkv, float* head_sumsq,

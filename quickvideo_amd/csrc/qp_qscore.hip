@@ -60,19 +60,24 @@ __global__ __launch_bounds__(256) void qscore_prob_kernel(const uint4* __restric
   for (int t = threadIdx.x; t < n; t += 256) out[t] = f32_to_bf16_bits(row[t] / sum);
 }
 
-// thread per key t: sum over queries (bf16), mean over heads (bf16), optional value-norm weighting, complemented key out
-__global__ __launch_bounds__(256) void qscore_reduce_kernel(const uint16_t* __restrict__ P, int n, int m, int hq,
-                                                            const float* __restrict__ value_sumsq, int hkv,
-                                                            uint16_t* __restrict__ keys_out, uint16_t* __restrict__ scores_out) {
+// thread per (head, key): s1[h][t] = bf16(sum over the m prompt queries of the bf16 probabilities)
+__global__ __launch_bounds__(256) void qscore_headsum_kernel(const uint16_t* __restrict__ P, int n, int m, int hq, uint16_t* __restrict__ s1) {
+  const int t = blockIdx.x * 256 + threadIdx.x, h = blockIdx.y;
+  if (t >= n) return;
+  float acc = 0.f;
+  const uint16_t* p = P + (int64_t)h * m * n + t;
+  for (int qi = 0; qi < m; ++qi) acc += bf16_bits_to_f32(p[(int64_t)qi * n]);
+  s1[(int64_t)h * n + t] = f32_to_bf16_bits(acc);
+}
+
+// thread per key t: mean over ALL heads of the per-head sums (ascending head order, bf16 result), optional value-norm weighting,
+// complemented key out.  Tensor parallelism all-gathers the ranks' s1 blocks (rank-major = ascending head order) in front of this.
+__global__ __launch_bounds__(256) void qscore_final_kernel(const uint16_t* __restrict__ s1, int n, int hq, const float* __restrict__ value_sumsq,
+                                                           int hkv, uint16_t* __restrict__ keys_out, uint16_t* __restrict__ scores_out) {
   const int t = blockIdx.x * 256 + threadIdx.x;
   if (t >= n) return;
   float acc = 0.f;
-  for (int h = 0; h < hq; ++h) {
-    float s1 = 0.f;
-    const uint16_t* p = P + (int64_t)h * m * n + t;
-    for (int qi = 0; qi < m; ++qi) s1 += bf16_bits_to_f32(p[(int64_t)qi * n]);
-    acc += round_bf16(s1);
-  }
+  for (int h = 0; h < hq; ++h) acc += bf16_bits_to_f32(s1[(int64_t)h * n + t]);
   float sc = round_bf16(acc / (float)hq);
   if (scores_out) scores_out[t] = f32_to_bf16_bits(sc);
   if (value_sumsq) {                                   // * ||v_t|| over all kv heads (bf16 norm, heads added in ascending order)
@@ -83,17 +88,36 @@ __global__ __launch_bounds__(256) void qscore_reduce_kernel(const uint16_t* __re
   keys_out[t] = (uint16_t)~f32_to_bf16_bits(sc);
 }
 
-int qp_launch_query_scores(const void* q_prompt, const void* k_group, int64_t k_head_stride, int64_t n, int64_t m, int hq, int hkv,
-                           const float* value_sumsq, uint16_t* keys_out, uint16_t* scores_out, void* workspace, hipStream_t s) {
+static int launch_probs(const void* q_prompt, const void* k_group, int64_t k_head_stride, int64_t n, int64_t m, int hq, int hkv, void* workspace,
+                        hipStream_t s) {
   static std::atomic<unsigned long long> lds_ok{0};
   const size_t smem = (size_t)n * 4;
   if (smem > 48 * 1024)
     if (int rc = qp_opt_in_lds(lds_ok, (const void*)qscore_prob_kernel, 160 * 1024 - 256, "qscore_prob")) return rc;
   qscore_prob_kernel<<<dim3((unsigned)m, (unsigned)hq), 256, smem, s>>>((const uint4*)q_prompt, (const uint4*)k_group, k_head_stride / 8,
                                                                         (int)n, (int)m, hq, hkv, sqrtf(128.0f), (uint16_t*)workspace);
-  int rc = qp_check_launch("qscore_prob");
-  if (rc) return rc;
-  qscore_reduce_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>((const uint16_t*)workspace, (int)n, (int)m, hq, value_sumsq, hkv,
-                                                                   keys_out, scores_out);
-  return qp_check_launch("qscore_reduce");
+  return qp_check_launch("qscore_prob");
+}
+
+// workspace = [P: hq*m*n bf16 | pad to 256 B | s1: hq*n bf16]
+static size_t probs_bytes(int64_t n, int64_t m, int hq) { return ((size_t)hq * m * n * 2 + 255) & ~(size_t)255; }
+
+int qp_launch_query_head_sums(const void* q_prompt, const void* k_group, int64_t k_head_stride, int64_t n, int64_t m, int hq, int hkv,
+                              uint16_t* head_sums_out, void* workspace, hipStream_t s) {
+  if (int rc = launch_probs(q_prompt, k_group, k_head_stride, n, m, hq, hkv, workspace, s)) return rc;
+  qscore_headsum_kernel<<<dim3((unsigned)((n + 255) / 256), (unsigned)hq), 256, 0, s>>>((const uint16_t*)workspace, (int)n, (int)m, hq, head_sums_out);
+  return qp_check_launch("qscore_headsum");
+}
+
+int qp_launch_query_scores_final(const uint16_t* head_sums, int hq_total, int64_t n, const float* value_sumsq, int hkv_total, uint16_t* keys_out,
+                                 uint16_t* scores_out, hipStream_t s) {
+  qscore_final_kernel<<<(unsigned)((n + 255) / 256), 256, 0, s>>>(head_sums, (int)n, hq_total, value_sumsq, hkv_total, keys_out, scores_out);
+  return qp_check_launch("qscore_final");
+}
+
+int qp_launch_query_scores(const void* q_prompt, const void* k_group, int64_t k_head_stride, int64_t n, int64_t m, int hq, int hkv,
+                           const float* value_sumsq, uint16_t* keys_out, uint16_t* scores_out, void* workspace, hipStream_t s) {
+  uint16_t* s1 = (uint16_t*)((char*)workspace + probs_bytes(n, m, hq));
+  if (int rc = qp_launch_query_head_sums(q_prompt, k_group, k_head_stride, n, m, hq, hkv, s1, workspace, s)) return rc;
+  return qp_launch_query_scores_final(s1, hq, n, value_sumsq, hkv, keys_out, scores_out, s);
 }

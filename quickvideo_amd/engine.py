@@ -642,9 +642,11 @@ class QuickPrefillEngine:
         nt = pos.shape[1]
         n = nt - m
         assert embeds.shape[0] == nt and n > 0 and nt <= self.n_max, f"group of {n}+{m} tokens exceeds max_group_tokens={self.n_max}"
-        if self.tp_on or self.sp_on:
-            raise NotImplementedError("query-attention-score pruning has no tensor / group-token parallel form (per-head bf16 score sums would "
-                                      "have to cross ranks in head order); the layer pipeline is supported")
+        if self.sp_on:
+            raise NotImplementedError("query-attention-score pruning has no group-token parallel form; tensor parallelism and the layer pipeline are supported")
+        if self.tp_on and (s.n_kv_heads % self.tp_size != 0 or not hasattr(ops, "query_head_sums")):
+            raise NotImplementedError("query-attention-score pruning under tensor parallelism needs the kv heads to divide over the ranks "
+                                      "(replicated kv heads carry zero pad q heads, which would enter the mean over heads)")
         if cfg.enable and isinstance(cfg.prefill_prune_starting_layer, int) and cfg.prefill_prune_starting_layer >= 0:
             raise NotImplementedError("query-attention-score pruning + hidden-state pruning: the reference drops the prompt rows there")
         if n > 32768:
@@ -686,13 +688,27 @@ class QuickPrefillEngine:
                 ops.prefill_attn(q[z:m], None, None, hs, 0, self.arena.k(l), self.arena.v(l), hs, pa, self.hq, self.hkv, D, scale, att[z:m],
                                  q_row0=pa - (m - z), nq=m - z)
             o = self.b_o[:nt]
-            self._linear("o", att.view(nt, self.hq * D), lw.w_o, o)
+            o_works = self._linear_reduced("o", att.view(nt, self.hq * D), lw.w_o, o)
             if k_keep is not None:
                 vss = None
                 if by_vnorm:
                     ops.key_sumsq(vn, stride, 0, n, self.hkv, D, self.b_ss)
                     vss = self.b_ss
-                ops.query_scores(q[n:], kn, stride, n, self.hq, self.hkv, D, self.b_keys, value_sumsq=vss)
+                if self.tp_on:
+                    # heads are sharded: every rank sums its heads' probabilities over the prompt queries (bf16 [hq_local, n]); the blocks
+                    # are all-gathered in rank = ascending head order and every rank takes the SAME mean over all heads (the single-device
+                    # kernel is this composition), so the kept list is identical everywhere and each rank compacts its own kv heads
+                    if getattr(self, "b_hs", None) is None:
+                        self.b_hs = torch.empty(self.hq, self.n_max, dtype=torch.int16, device=self.device)
+                        self.b_hs_all = torch.empty(self.tp_size * self.hq, self.n_max, dtype=torch.int16, device=self.device)
+                    hs_loc = self.b_hs.view(-1)[: self.hq * n].view(self.hq, n)
+                    hs_all = self.b_hs_all.view(-1)[: self.tp_size * self.hq * n].view(self.tp_size * self.hq, n)
+                    ops.query_head_sums(q[n:], kn, stride, n, self.hq, self.hkv, D, hs_loc)
+                    torch.distributed.all_gather_into_tensor(hs_all.view(torch.bfloat16), hs_loc.view(torch.bfloat16), group=self.tp_group)   # (16-bit patterns)
+                    vss_all, kv_total = self._global_sumsq(n) if by_vnorm else (None, 0)
+                    ops.query_scores_from_head_sums(hs_all, self.tp_size * self.hq, n, self.b_keys, value_sumsq=vss_all, n_kv_total=kv_total)
+                else:
+                    ops.query_scores(q[n:], kn, stride, n, self.hq, self.hkv, D, self.b_keys, value_sumsq=vss)
                 idx = self.b_idx[:k_keep]
                 if n <= ops.PRUNE_KEYS_MAX_N:
                     ops.prune_keys(self.b_keys, n, k_keep, kn, vn, stride, self.hkv, D, self.arena.k(l), self.arena.v(l), hs, past, idx)
@@ -706,12 +722,13 @@ class QuickPrefillEngine:
                 self.arena.len[l] = past + n
                 if self.kept_trace is not None:
                     self.kept_trace.append((l, None))
+            self._wait(o_works)
             x2 = self.b_x[:nt]
             ops.add_rmsnorm(h, o, lw.ln2, x2, s.rms_eps)
             act = self.b_act[:nt]
             self._gate_up_swiglu(x2, lw, act)
             dn = self.b_dn[:nt]
-            self._linear("down", act, lw.w_down, dn)
+            self._wait(self._linear_reduced("down", act, lw.w_down, dn))
             delta = dn
         ops.add_inplace(h, delta)
         return h

@@ -60,6 +60,8 @@ SIGNATURES = {
     "qp_rope_append": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _vp, _vp]),
     "qp_rope_append_keys": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i32, _vp]),
     "qp_query_scores_workspace_bytes": (_sz, [_i64, _i64, _i32]),
+    "qp_query_head_sums": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
+    "qp_query_scores_from_head_sums": (_i32, [_vp, _vp, _i32, _i64, _vp, _i32, _vp, _vp, _vp]),
     "qp_query_scores": (_i32, [_vp, _vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _sz, _vp]),
     "qp_norm_keys": (_i32, [_vp, _vp, _i32, _i64, _vp, _i32, _vp]),
     "qp_prune_keys": (_i32, [_vp, _vp, _i64, _i64, _vp, _vp, _i64, _i32, _i32, _vp, _vp, _i64, _i64, _vp, _vp]),
@@ -225,6 +227,20 @@ class QuickPrefillOps:
         self._check(self.lib.qp_query_scores(self.ctx, q_prompt.data_ptr(), k_group.data_ptr(), k_head_stride, n, m, n_q, n_kv, head_dim,
                                              _ptr(value_sumsq), norm_keys.data_ptr(), _ptr(scores), self._qs_ws.data_ptr(), self._qs_ws.numel(),
                                              self._stream()))
+
+    def query_head_sums(self, q_prompt, k_group, k_head_stride, n, n_q, n_kv, head_dim, head_sums):
+        """Step 1 of the query-based scoring for sharded heads: bf16 per-head sums [n_q, n] of the LOCAL heads (int16 tensor)."""
+        m = q_prompt.shape[0]
+        need = int(self.lib.qp_query_scores_workspace_bytes(n, m, n_q))
+        if getattr(self, "_qs_ws", None) is None or self._qs_ws.numel() < need:
+            self._qs_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        self._check(self.lib.qp_query_head_sums(self.ctx, q_prompt.data_ptr(), k_group.data_ptr(), k_head_stride, n, m, n_q, n_kv, head_dim,
+                                                head_sums.data_ptr(), self._qs_ws.data_ptr(), self._qs_ws.numel(), self._stream()))
+
+    def query_scores_from_head_sums(self, head_sums, n_heads_total, n, norm_keys, value_sumsq=None, n_kv_total=0, scores=None):
+        """Step 2: mean over ALL heads (rows of head_sums in ascending head order) -> complemented score keys for prune_keys."""
+        self._check(self.lib.qp_query_scores_from_head_sums(self.ctx, head_sums.data_ptr(), n_heads_total, n, _ptr(value_sumsq), n_kv_total,
+                                                            norm_keys.data_ptr(), _ptr(scores), self._stream()))
 
     def norm_keys(self, head_sumsq, n_heads_total, n, norm_keys, mode: int = 0):
         self._check(self.lib.qp_norm_keys(self.ctx, head_sumsq.data_ptr(), n_heads_total, n, norm_keys.data_ptr(), int(mode), self._stream()))

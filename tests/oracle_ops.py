@@ -95,6 +95,22 @@ class OracleOps:
         bits = O.torch_bf16_to_bits(sc)
         norm_keys[:n].copy_(torch.from_numpy((~bits).astype(np.uint16).view(np.int16)))
 
+    def query_head_sums(self, q_prompt, k_group, k_head_stride, n, n_q, n_kv, D, head_sums):
+        kg = torch.stack([self._rows(k_group, h, k_head_stride, 0, n, D) for h in range(n_kv)])
+        qp = q_prompt.transpose(0, 1).contiguous()                                   # [Hq_local, m, D]
+        kr = kg.repeat_interleave(n_q // n_kv, dim=0)
+        a = torch.einsum("hqd,hkd->hqk", qp, kr) / (D ** 0.5)
+        p = torch.softmax(a, dim=-1, dtype=torch.float32).to(qp.dtype)
+        head_sums.view(-1)[: n_q * n].copy_(torch.from_numpy(O.torch_bf16_to_bits(p.sum(-2)).view(np.int16)).view(-1))
+
+    def query_scores_from_head_sums(self, head_sums, n_heads_total, n, norm_keys, value_sumsq=None, n_kv_total=0, scores=None):
+        s1 = O.bits_to_torch_bf16(head_sums.view(-1)[: n_heads_total * n].view(n_heads_total, n).numpy().view(np.uint16))
+        sc = s1.mean(0)
+        if value_sumsq is not None:
+            vn = O.bits_to_torch_bf16(O.key_norms_bf16(value_sumsq.reshape(-1)[: n_kv_total * n].view(n_kv_total, n).numpy()))
+            sc = sc * vn
+        norm_keys[:n].copy_(torch.from_numpy((~O.torch_bf16_to_bits(sc)).astype(np.uint16).view(np.int16)))
+
     def prune_keys(self, norm_keys, n, k, k_src, v_src, src_head_stride, n_kv, D, k_dst, v_dst, dst_head_stride, dst_row0, kept_idx):
         keys = norm_keys[:n].numpy().view(np.uint16)
         kept_idx[:k].copy_(torch.from_numpy(O.select_k_smallest(keys, k)))

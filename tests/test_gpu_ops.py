@@ -1105,3 +1105,35 @@ def test_c_abi_segment_from_a_plain_c_program(tmp_path):
     p = subprocess.run([exe], capture_output=True, text=True, timeout=180)
     assert p.returncode == 0, (p.stdout, p.stderr[-1000:])
     assert "bit-identical" in p.stdout and "cache_len 184 184" in p.stdout
+
+
+def test_query_scores_two_step_form_for_sharded_heads(ops):
+    """qp_query_head_sums + qp_query_scores_from_head_sums (round 4: query-score pruning under tensor parallelism): the heads cut into two
+    "ranks" (each with its kv heads and their q heads), per-rank head sums concatenated in head order, then ONE mean over all heads — the
+    sort keys must be bit-identical to the single-device qp_query_scores (which is the same two kernels back to back), with and without
+    the value-norm weighting."""
+    from oracle.make_golden import QUERY_CASES, make_query_case
+    hq, hkv, n, m, k = QUERY_CASES[0]
+    q, kk, vv = make_query_case(0)
+    qp = q[0, :, n:].transpose(0, 1).contiguous().cuda()                   # [m, Hq, D]
+    kg, vg = kk[0, :, :n].contiguous().cuda(), vv[0, :, :n].contiguous().cuda()
+    grp = hq // hkv
+    for by_v in (False, True):
+        vss = None
+        if by_v:
+            vss = torch.empty(hkv, n, dtype=torch.float32, device="cuda")
+            ops.key_sumsq(vg, n * D, 0, n, hkv, D, vss)
+        want = torch.zeros(n, dtype=torch.int16, device="cuda")
+        ops.query_scores(qp, kg, n * D, n, hq, hkv, D, want, value_sumsq=vss)
+        parts = []
+        half = hkv // 2
+        for r in range(2):                                                  # rank r: kv heads [r*half, (r+1)*half) and their q heads
+            qh = qp[:, r * half * grp:(r + 1) * half * grp].contiguous()
+            kh = kg[r * half:(r + 1) * half].contiguous()
+            hs = torch.zeros(half * grp, n, dtype=torch.int16, device="cuda")
+            ops.query_head_sums(qh, kh, n * D, n, half * grp, half, D, hs)
+            parts.append(hs)
+        got = torch.zeros(n, dtype=torch.int16, device="cuda")
+        ops.query_scores_from_head_sums(torch.cat(parts, 0).contiguous(), hq, n, got, value_sumsq=vss, n_kv_total=hkv)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), by_v
