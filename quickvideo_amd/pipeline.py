@@ -413,13 +413,17 @@ class PrefillPipeline:
     def _generate(self, question, video, max_new_tokens: int = 16, overlap: bool = True, eos_token_id=None,
                   do_sample: Optional[bool] = None, temperature: Optional[float] = None, top_k: Optional[int] = None,
                   top_p: Optional[float] = None, repetition_penalty: Optional[float] = None, seed: Optional[int] = None,
-                  num_beams: int = 1, **unused) -> List[int]:
+                  num_beams: int = 1, length_penalty: float = 1.0, early_stopping=False, **unused) -> List[int]:
         """generation kwargs as the reference hands them to HF `generate` (qwen25_lvu.py:744-761); unset ones fall back to the
-        checkpoint's generation_config.json (`model.generation_defaults`), then to greedy.  Beam search is refused, not ignored.
+        checkpoint's generation_config.json (`model.generation_defaults`), then to greedy.  `num_beams > 1`: deterministic beam search
+        with HF's semantics (`length_penalty`, `early_stopping`; beam.py) on one GPU.
         `question`: the user's text, or the reference's `messages` list (chat(); qwen25_lvu.py:546-548) when the processor can
         template it.  eos_token_id: an id or a list of ids (HF stops on ANY of generation_config.eos_token_id)."""
-        if num_beams != 1:
-            raise NotImplementedError("beam search is not implemented (greedy and sampling with temperature / top-k / top-p / repetition penalty are)")
+        num_beams = int(num_beams)
+        if num_beams > 1 and (do_sample or (do_sample is None and (getattr(self.model, "generation_defaults", None) or {}).get("do_sample"))):
+            raise NotImplementedError("beam-search multinomial sampling (num_beams > 1 with do_sample=True) is not implemented; deterministic beam search is")
+        if num_beams > 1 and self.par.on:
+            raise NotImplementedError("beam search runs on one GPU (the multi-GPU layouts decode greedily or by sampling)")
         gd = getattr(self.model, "generation_defaults", None) or {}
         pick = lambda v, k: gd.get(k) if v is None else v
         selector = TokenSelector(pick(do_sample, "do_sample") or False, pick(temperature, "temperature"), pick(top_k, "top_k"),
@@ -579,6 +583,27 @@ class PrefillPipeline:
                 t = selector.select(lg) if not selector.trivial else int(torch.argmax(lg).item())
             return self._share_token(t, decider) if par.on else t
 
+        if num_beams > 1:
+            # beam search (HF generate semantics, beam.py): all beams share the prefilled video + prompt rows of the arena; the clock for
+            # "first token" stops when the first step's distribution is on the host (the final first token is only known at the end)
+            from .beam import EngineBeams, beam_search
+            first = logits.float()
+            _ = float(first[0].item())
+            tm.ttft = time.perf_counter() - t_e2e
+            beams = EngineBeams(eng, P["delta"], num_beams, max_new_tokens)
+            out = beam_search(first, beams.advance, num_beams, max_new_tokens, eos_ids=sorted(eos_set), length_penalty=float(length_penalty),
+                              early_stopping=early_stopping, repetition_penalty=selector.penalty, prompt_ids=list(P["prompt"].tail_ids))
+            beams.finish(len(out))
+            sync()
+            tm.decode = time.perf_counter() - t_dec
+            tm.e2e = time.perf_counter() - t_e2e
+            if prod is not None:
+                tm.producer_busy, tm.producer_blocked, tm.producer_copy = prod.t_busy, prod.t_blocked + prod.t_put, prod.t_copy
+            if self.use_gpu and trace and lead:
+                self._device_breakdown(tm, origin, trace)
+            tm.layout = self.last_layout
+            self.last_timings = tm
+            return out
         tok = choose(logits)                                                  # first token on the host = TTFT point
         tm.ttft = time.perf_counter() - t_e2e
         out = [tok]

@@ -5,7 +5,7 @@ greedy after a repetition penalty — so the penalty matters even for "greedy" u
 
 Order as in HF: processors (repetition penalty) -> [sampling only] warpers (temperature, top-k, top-p) -> softmax -> multinomial;
 without `do_sample` the argmax of the processed scores.  Pure torch on the 152k-entry logits vector of one step (device-agnostic;
-pinned against the installed transformers classes in tests/test_api_cpu.py).  Beam search is not offered.
+pinned against the installed transformers classes in tests/test_api_cpu.py).  Beam search: quickvideo_amd/beam.py.
 """
 from __future__ import annotations
 

@@ -311,8 +311,10 @@ def test_load_hf_checkpoint_directory(tmp_path):
     obj = lvu.LVU(lvu.LVUConfig(str(tmp_path), top_p=0.5, video_group_size=4, num_frames=8), model=m)
     obj._ops = OracleOps()
     out = obj.generate("hi", "synthetic://?frames=16&h=56&w=84&seed=1", max_new_tokens=2)
-    with pytest.raises(NotImplementedError):                       # beam search is refused, not ignored
-        obj.generate("hi", "synthetic://?frames=16&h=56&w=84&seed=1", max_new_tokens=2, num_beams=2)
+    assert obj.generate("hi", "synthetic://?frames=16&h=56&w=84&seed=1", max_new_tokens=2, num_beams=1) == out
+    assert obj.generate("hi", "synthetic://?frames=16&h=56&w=84&seed=1", max_new_tokens=2, num_beams=2)[0].count("<tok_") == 2   # beam search (round 4)
+    with pytest.raises(NotImplementedError):                       # beam SAMPLING is refused, not ignored
+        obj.generate("hi", "synthetic://?frames=16&h=56&w=84&seed=1", max_new_tokens=2, num_beams=2, do_sample=True)
     assert obj.generate("hi", "synthetic://?frames=16&h=56&w=84&seed=1", max_new_tokens=2, do_sample=True, temperature=0.7,
                         seed=1)[0].count("<tok_") == 2
     assert obj.generate("hi", "synthetic://?frames=16&h=56&w=84&seed=1", max_new_tokens=2, do_sample=True, top_k=1) == out
@@ -910,8 +912,9 @@ def test_generation_kwargs_like_hf_generate():
     pen = run(repetition_penalty=1e6)
     toks = pen.split()
     assert len(set(toks)) == len(toks)
+    assert run(num_beams=4).count("<tok_") >= 1                                            # deterministic beam search (tests/test_beam_search.py)
     with pytest.raises(NotImplementedError):
-        run(num_beams=4)
+        run(num_beams=4, do_sample=True)
     m.generation_defaults = {"do_sample": True, "temperature": 5.0}                      # generation_config.json of a checkpoint
     assert len({run(seed=s) for s in range(4)}) > 1 and run(do_sample=False) == greedy   # explicit kwargs win
 
