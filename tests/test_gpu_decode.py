@@ -331,3 +331,38 @@ def test_decode_full_size_properties(ops):
     ref = torch.softmax(s, -1) @ v[0].float()
     err = (a[:7] - ref).abs()
     assert (err <= 1.5e-2 + 1.5e-2 * ref.abs()).all(), err.max().item()
+
+
+def test_beam_search_on_the_hip_path_shares_the_prefilled_cache():
+    """Beam search (round 4) on the HIP kernels through the plugin: `LVU.generate(num_beams=...)` on a tiny model.  num_beams=1 through the
+    beam code equals the greedy answer; a 3-beam search returns a sequence whose summed log-probability (re-scored token by token with the
+    eager decode step over the same prefilled cache) is at least the greedy sequence's; the prefilled rows of the arena are left untouched
+    and the engine is back at the prefill state afterwards."""
+    import lvu
+    from quickvideo_amd.beam import EngineBeams, beam_search
+    video = "synthetic://?frames=16&h=56&w=84&seed=3"
+    obj = lvu.LVU(lvu.LVUConfig("synthetic:tiny", top_p=0.5, video_group_size=4, num_frames=8), model_init_kwargs={"device": "cuda:0", "seed": 5})
+    greedy = obj.generate("What happens?", video, max_new_tokens=5, eos_token_id=-1)
+    one = obj.generate("What happens?", video, max_new_tokens=5, eos_token_id=-1, num_beams=1)
+    assert one == greedy
+    three = obj.generate("What happens?", video, max_new_tokens=5, eos_token_id=-1, num_beams=3)
+    assert three[0].count("<tok_") == 5
+    eng = obj._pipeline.model.engine
+    # re-score both answers over the SAME prefilled cache: prefill once more through the pipeline, then teacher-force the tokens
+    def score(text):
+        ids = [int(t[5:-1]) for t in text.split()]
+        obj.generate("What happens?", video, max_new_tokens=1, eos_token_id=-1)            # prefill + tail (leaves the first-token logits' state)
+        lens, pos0 = list(eng.arena.len), eng.seq_pos
+        # the tail's last logits are gone; recompute them from a beam object's first step: advance needs a first token, so score from token 2 on
+        b = EngineBeams(eng, obj._pipeline.model.rope_deltas, 1, len(ids))
+        total, lg = 0.0, None
+        for i, tok in enumerate(ids[:-1]):
+            lg = b.advance([0], [tok])[0]
+            total += float(torch.log_softmax(lg.float(), -1)[ids[i + 1]])
+        b.finish(len(ids))
+        assert list(eng.arena.len) == lens and eng.seq_pos == pos0
+        return total, ids[0]
+    s_g, f_g = score(greedy[0])
+    s_b, f_b = score(three[0])
+    if f_g == f_b:                                       # same first token: the remaining 4 tokens of the beam answer must score at least as well
+        assert s_b >= s_g - 1e-3, (s_b, s_g, three, greedy)
