@@ -18,10 +18,13 @@ steps (untimed) run the first groups + the prompt tail of the same video (GEMM p
 which the KV arena is reset.  Videos with fewer groups than K (cfg2, cfg3) keep the step = one full pass over the video.
 
 Prints ONE JSON line (rank 0): the driver's contract fields, `roofline` (dominant hand-written kernel = the MFMA prefill
-attention, HIP events on the launch stream inside the timed region), `roofline_prune`, `cpu_baseline` (the CPU oracle on
-the host cores over a bounded sample, extrapolated over the groups as BASELINE.md §3 prescribes), `video_to_first_token`
-(the real front end: frame producer -> pinned ring -> copy stream -> GPU patchify + ViT -> group prefill -> first token)
-and, as a secondary block, the cfg2 numbers of round 1.
+attention, HIP events on the launch stream inside the timed region — recorded by the library around its launches on the one-call
+segment path; `traffic` from two `rocprofv3 --pmc` child passes of this script when rocprofv3 is on PATH), `roofline_prune`,
+`cpu_baseline` (the CPU oracle on the host cores over a bounded sample, extrapolated over the groups as BASELINE.md §3 prescribes),
+`video_to_first_token` (the real front end: frame producer -> pinned ring -> copy stream -> GPU patchify + ViT -> group prefill ->
+first token; also for N > 1, through the plugin's distributed pipeline), `value_with_vit` / `ttft_ms` (the metric as the reference
+defines it), `host_contention` (the overlap under a saturated host / a lock-holding Python thread), `cfg4ref` (the reference's own
+operating point: 432 k tokens) and, as a secondary block, the cfg2 numbers of round 1.
 """
 from __future__ import annotations
 
