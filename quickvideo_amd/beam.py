@@ -130,13 +130,14 @@ class EngineBeams:
         for i, (par, tok) in enumerate(zip(parents, tokens)):
             self._load(self.tails[par])
             lg = eng.decode_step(eng.embed_tokens(torch.tensor([tok], device=eng.device)), self.delta)
-            out.append(lg.float())
+            if lg is not None:                                          # (layer-pipeline stages other than the last hold no logits)
+                out.append(lg.float())
             if t:
                 new_tails[i][:, :, :, :t].copy_(self.tails[par][:, :, :, :t])
             for l, p in enumerate(self.base_len):                       # the row this step appended
                 new_tails[i][l, :, :, t].copy_(eng.arena.buf[l, :, :, p + t])
         self.tails, self.t = new_tails, t + 1
-        return torch.stack(out)
+        return torch.stack(out) if out else None
 
     def finish(self, generated: int):
         """Leave the engine with the winner's length bookkeeping (its rows beyond the shared prefix are not restored)."""

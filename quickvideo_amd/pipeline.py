@@ -422,8 +422,6 @@ class PrefillPipeline:
         num_beams = int(num_beams)
         if num_beams > 1 and (do_sample or (do_sample is None and (getattr(self.model, "generation_defaults", None) or {}).get("do_sample"))):
             raise NotImplementedError("beam-search multinomial sampling (num_beams > 1 with do_sample=True) is not implemented; deterministic beam search is")
-        if num_beams > 1 and self.par.on:
-            raise NotImplementedError("beam search runs on one GPU (the multi-GPU layouts decode greedily or by sampling)")
         gd = getattr(self.model, "generation_defaults", None) or {}
         pick = lambda v, k: gd.get(k) if v is None else v
         selector = TokenSelector(pick(do_sample, "do_sample") or False, pick(temperature, "temperature"), pick(top_k, "top_k"),
@@ -587,13 +585,45 @@ class PrefillPipeline:
             # beam search (HF generate semantics, beam.py): all beams share the prefilled video + prompt rows of the arena; the clock for
             # "first token" stops when the first step's distribution is on the host (the final first token is only known at the end)
             from .beam import EngineBeams, beam_search
-            first = logits.float()
-            _ = float(first[0].item())
+            first = logits.float() if logits is not None else None
+            if first is not None:
+                _ = float(first[0].item())
             tm.ttft = time.perf_counter() - t_e2e
             beams = EngineBeams(eng, P["delta"], num_beams, max_new_tokens)
-            out = beam_search(first, beams.advance, num_beams, max_new_tokens, eos_ids=sorted(eos_set), length_penalty=float(length_penalty),
-                              early_stopping=early_stopping, repetition_penalty=selector.penalty, prompt_ids=list(P["prompt"].tail_ids))
+            search = lambda adv: beam_search(first, adv, num_beams, max_new_tokens, eos_ids=sorted(eos_set), length_penalty=float(length_penalty),   # noqa: E731
+                                             early_stopping=early_stopping, repetition_penalty=selector.penalty, prompt_ids=list(P["prompt"].tail_ids))
+            if not par.on:
+                out = search(beams.advance)
+            else:
+                # multi-GPU: ONE rank (the one that holds logits) runs the search; before every step it tells the others which beams to extend
+                # by which tokens, and every rank advances its share of the model (its layers / its heads) in lock-step
+                dist, grp, B = torch.distributed, self._front_group(), num_beams
+                src = par.global_rank(decider)
+                msg = torch.zeros(1 + 2 * B + max_new_tokens + 1, dtype=torch.int64, device=dev)
+
+                def leader_advance(parents, tokens):
+                    msg.zero_()
+                    msg[0] = 1
+                    msg[1:1 + B] = torch.tensor(parents, device=dev); msg[1 + B:1 + 2 * B] = torch.tensor(tokens, device=dev)
+                    dist.broadcast(msg, src=src, group=grp)
+                    return beams.advance(parents, tokens)
+
+                if par.rank == decider:
+                    out = search(leader_advance)
+                    msg.zero_()
+                    msg[1 + 2 * B] = len(out)
+                    msg[2 + 2 * B:2 + 2 * B + len(out)] = torch.tensor(out, device=dev)
+                    dist.broadcast(msg, src=src, group=grp)
+                else:
+                    while True:
+                        dist.broadcast(msg, src=src, group=grp)
+                        m_ = msg.tolist()
+                        if m_[0] == 0:
+                            out = m_[2 + 2 * B:2 + 2 * B + m_[1 + 2 * B]]
+                            break
+                        beams.advance(m_[1:1 + B], m_[1 + B:1 + 2 * B])
             beams.finish(len(out))
+            eng.pp_flush()
             sync()
             tm.decode = time.perf_counter() - t_dec
             tm.e2e = time.perf_counter() - t_e2e

@@ -127,6 +127,39 @@ def test_hidden_state_pruning_and_sampling_through_the_pipeline_stages():
     assert ret["r0"][0] == out and ret["r1"][0] == out
 
 
+def _beam_worker(rank, world, port, mode, ret):
+    try:
+        os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        torch.set_num_threads(2)
+        import lvu
+        obj = lvu.LVU(_cfg(lvu, 12, 48), model_init_kwargs={"device": "cpu", "seed": 3, "parallel": mode})
+        obj._ops = OracleOps()
+        ret[f"r{rank}"] = obj.generate(QUESTION, VIDEO, max_new_tokens=4, num_beams=3, eos_token_id=-1)
+        dist.barrier()
+        dist.destroy_process_group()
+    except BaseException as e:
+        import traceback
+        ret[f"error{rank}"] = "".join(traceback.format_exception(type(e), e, e.__traceback__))
+        raise
+
+
+@pytest.mark.parametrize("mode", ["pp", "sp", "tp"])
+def test_beam_search_over_ranks_equals_single_process(mode):
+    """Beam search on the multi-GPU layouts: the rank that holds the logits runs the search and tells the others, step by step, which beams to
+    extend by which tokens; every rank advances its share of the model.  Same answer as the single-process beam search on every rank."""
+    import lvu
+    ret = mp.Manager().dict()
+    obj = lvu.LVU(_cfg(lvu, 12, 48), model_init_kwargs={"device": "cpu", "seed": 3})
+    obj._ops = OracleOps()
+    want = obj.generate(QUESTION, VIDEO, max_new_tokens=4, num_beams=3, eos_token_id=-1)
+    assert want[0].count("<tok_") == 4
+    mp.spawn(_beam_worker, args=(2, _free_port(), mode, ret), nprocs=2, join=True)
+    for r in range(2):
+        assert f"error{r}" not in ret, ret.get(f"error{r}")
+        assert ret[f"r{r}"] == want, (mode, r, ret[f"r{r}"], want)
+
+
 def test_layout_cost_model():
     from quickvideo_amd.parallel import choose_layout, layout_efficiency, stage_balance
     assert stage_balance(28, 8) == pytest.approx(3.5 / 4) and stage_balance(28, 4) == 1.0 and stage_balance(80, 8) == 1.0
