@@ -182,3 +182,21 @@ def resolve(parallel: Optional[str] = None, group=None) -> ParallelContext:
     if world == 1:
         return ParallelContext("single")
     return ParallelContext(mode, world, rank, group)
+
+
+def init_distributed(backend: Optional[str] = None) -> ParallelContext:
+    """Convenience for a script launched with one process per GPU (`python -m torch.distributed.run --nproc-per-node N --master-addr
+    127.0.0.1 script.py`): binds this process to its GPU (LOCAL_RANK), initialises torch.distributed (backend "nccl" = RCCL over xGMI on a
+    GPU box; "gloo" on CPU) unless that has been done already, and returns the resolved context.  In a plain single-process run it does
+    nothing and returns the single context — the same script works on 1 and on 8 GPUs."""
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not torch.distributed.is_initialized():
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # the host driver only supports dmabuf IPC
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        cuda = torch.cuda.is_available()
+        kw = {}
+        if cuda:
+            dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+            torch.cuda.set_device(dev)
+            kw["device_id"] = dev
+        torch.distributed.init_process_group(backend or ("nccl" if cuda else "gloo"), **kw)
+    return resolve()
