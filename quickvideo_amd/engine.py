@@ -422,7 +422,7 @@ class QuickPrefillEngine:
         assert n <= self.n_max, f"group of {n} tokens exceeds max_group_tokens={self.n_max}"
         self._seg_rows = row_idx
         self._parallel_buffers()
-        if self._sp_active(n):
+        if self._sp_active(n, prune):
             return self._forward_segment_sp(embeds, pos, prune, video_group)
         if row_idx is not None:                      # positions of the surviving rows only (utils.py:344-372 gathers them the same way)
             pos = pos.index_select(1, row_idx.long())
@@ -743,8 +743,7 @@ class QuickPrefillEngine:
         Returns this rank's hidden rows (callers only need them for the replicated prompt tail)."""
         s, ops, cfg, D, N, r = self.spec, self.ops, self.cfg, self.D, self.sp_size, self.sp_rank
         n = pos.shape[1]
-        if cfg.enable and isinstance(cfg.prefill_prune_starting_layer, int) and cfg.prefill_prune_starting_layer >= 0 and prune:
-            raise NotImplementedError("hidden-state pruning (prefill_prune_starting_layer) is not combined with group-token parallelism")
+        assert not self._hidden_prune_on(prune), "segments with hidden-state pruning run replicated under group-token parallelism (_sp_active)"
         (a0, a1), (b0, b1) = sp_row_ranges(n, N, r)
         m2 = -(-n // (2 * N))
         m = 2 * m2                                   # rows per rank slot in the exchange buffers
@@ -822,12 +821,16 @@ class QuickPrefillEngine:
 
     # ------------------------------------------------------------------ public steps of the group loop
     # layer-pipeline hand-off: stage r > 0 receives the segment's hidden rows from stage r-1, the last stage keeps its output
-    def _sp_active(self, n: int) -> bool:
-        return self.sp_on and n >= 64 * self.sp_size
+    def _sp_active(self, n: int, prune: bool = False) -> bool:
+        """Is this segment's work split over the sp ranks?  Short segments (prompt tail, decode) and segments that prune the HIDDEN rows
+        (prefill_prune_starting_layer: the surviving rows of a layer are an irregular subset, which the fixed zigzag deal of the K/V
+        exchange cannot follow) run REPLICATED instead: every rank computes the whole segment on its replica of the weights and the
+        cache — same result on every rank, no exchange, no speed-up for that segment."""
+        return self.sp_on and n >= 64 * self.sp_size and not self._hidden_prune_on(prune)
 
-    def _pp_rows(self, n: int) -> int:
+    def _pp_rows(self, n: int, prune: bool = False) -> int:
         """Rows of an n-token segment that travel between this rank and its pipeline counterparts."""
-        if not self._sp_active(n):
+        if not self._sp_active(n, prune):
             return n
         (a0, a1), (b0, b1) = sp_row_ranges(n, self.sp_size, self.sp_rank)
         return (a1 - a0) + (b1 - b0)
@@ -881,7 +884,7 @@ class QuickPrefillEngine:
         n = embeds.shape[0] if n is None else n
         rows, pruned = self._rows_entering_stage(n, prune)
         if not pruned:
-            buf = self.b_h2[: self._pp_rows(n)]
+            buf = self.b_h2[: self._pp_rows(n, prune)]
             self._pp_recv(buf)
             return buf, None
         buf, idx = self.b_h2[:rows], self.b_idx_pp[:rows]           # a stage before this one pruned the hidden rows

@@ -125,6 +125,10 @@ def test_hidden_state_pruning_and_sampling_through_the_pipeline_stages():
     ret = _launch(2, "pp", 12, 48, prefill_prune_starting_layer=1)
     out = ret["single"][0]
     assert ret["r0"][0] == out and ret["r1"][0] == out
+    # ... and under group-token parallelism (round 4): segments that prune the hidden rows run replicated on every sp rank (the surviving
+    # rows are an irregular subset the zigzag K/V exchange cannot follow), the prompt tail as before — same answer, same cache lengths
+    ret = _launch(2, "sp", 12, 48, prefill_prune_starting_layer=1)
+    assert ret["r0"][0] == ret["r1"][0] == ret["single"][0] and ret["r0"][2] == ret["r1"][2] == ret["single"][2]
 
 
 def _beam_worker(rank, world, port, mode, ret):
