@@ -642,11 +642,11 @@ class QuickPrefillEngine:
         nt = pos.shape[1]
         n = nt - m
         assert embeds.shape[0] == nt and n > 0 and nt <= self.n_max, f"group of {n}+{m} tokens exceeds max_group_tokens={self.n_max}"
-        if self.sp_on:
-            raise NotImplementedError("query-attention-score pruning has no group-token parallel form; tensor parallelism and the layer pipeline are supported")
-        if self.tp_on and (s.n_kv_heads % self.tp_size != 0 or not hasattr(ops, "query_head_sums")):
-            raise NotImplementedError("query-attention-score pruning under tensor parallelism needs the kv heads to divide over the ranks "
-                                      "(replicated kv heads carry zero pad q heads, which would enter the mean over heads)")
+        # (group-token parallel engines run these segments REPLICATED — every rank the whole group on its replica, see _sp_active — so
+        # nothing of the sp exchange is involved here)
+        if self.tp_on and (self.tp_size * self.hq != s.n_heads or not hasattr(ops, "query_head_sums")):
+            raise NotImplementedError("query-attention-score pruning under tensor parallelism needs the q heads to divide over the ranks without "
+                                      "padding (zero pad heads of a replicated kv head would enter the mean over heads)")
         if cfg.enable and isinstance(cfg.prefill_prune_starting_layer, int) and cfg.prefill_prune_starting_layer >= 0:
             raise NotImplementedError("query-attention-score pruning + hidden-state pruning: the reference drops the prompt rows there")
         if n > 32768:
@@ -824,9 +824,10 @@ class QuickPrefillEngine:
     def _sp_active(self, n: int, prune: bool = False) -> bool:
         """Is this segment's work split over the sp ranks?  Short segments (prompt tail, decode) and segments that prune the HIDDEN rows
         (prefill_prune_starting_layer: the surviving rows of a layer are an irregular subset, which the fixed zigzag deal of the K/V
-        exchange cannot follow) run REPLICATED instead: every rank computes the whole segment on its replica of the weights and the
+        exchange cannot follow), and every segment of a query-attention-score engine (the appended prompt rows score ALL of the group's keys),
+        run REPLICATED instead: every rank computes the whole segment on its replica of the weights and the
         cache — same result on every rank, no exchange, no speed-up for that segment."""
-        return self.sp_on and n >= 64 * self.sp_size and not self._hidden_prune_on(prune)
+        return self.sp_on and n >= 64 * self.sp_size and not self._hidden_prune_on(prune) and not (self.query_mode and self.cfg.enable)
 
     def _pp_rows(self, n: int, prune: bool = False) -> int:
         """Rows of an n-token segment that travel between this rank and its pipeline counterparts."""

@@ -131,6 +131,18 @@ def test_hidden_state_pruning_and_sampling_through_the_pipeline_stages():
     assert ret["r0"][0] == ret["r1"][0] == ret["single"][0] and ret["r0"][2] == ret["r1"][2] == ret["single"][2]
 
 
+@pytest.mark.parametrize("world,mode", [(2, "sp"), (2, "tp"), (2, "pp"), (4, "auto")])
+def test_query_score_pruning_through_the_plugin_on_every_layout(world, mode):
+    """top_k_predict_type="query_attention_weights" (the prompt rows ride along with every group and score its keys) behind the plugin:
+    tensor parallel (per-head sums all-gathered), layer pipeline (n + m rows travel), group-token parallel (these segments run replicated)
+    and the auto grid — the single-process answer on every rank."""
+    gs, nf = (12, 48) if world == 2 else (24, 96)
+    ret = _launch(world, mode, gs, nf, top_k_predict_type="query_attention_weights")
+    out = ret["single"][0]
+    for r in range(world):
+        assert ret[f"r{r}"][0] == out, (r, ret[f"r{r}"][0], out)
+
+
 def _beam_worker(rank, world, port, mode, ret):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
