@@ -25,9 +25,12 @@ NEG = -1.0e9
 
 def beam_search(first_logits: torch.Tensor, advance: Callable[[List[int], List[int]], torch.Tensor], num_beams: int, max_new_tokens: int,
                 eos_ids: Sequence[int] = (), length_penalty: float = 1.0, early_stopping=False, repetition_penalty: float = 1.0,
-                prompt_ids: Sequence[int] = ()) -> List[int]:
+                prompt_ids: Sequence[int] = (), do_sample: bool = False, temperature: float = 1.0, top_k: int = 0, top_p: float = 1.0,
+                generator: Optional[torch.Generator] = None) -> List[int]:
     """-> generated token ids of the best hypothesis (eos included when it ended the sequence).  first_logits: fp32 [V] logits of the
-    prompt's last position (every beam starts from it: HF initialises the scores as [0, -1e9, ...] so that step 0 spreads ONE beam)."""
+    prompt's last position (every beam starts from it: HF initialises the scores as [0, -1e9, ...] so that step 0 spreads ONE beam).
+    do_sample: beam-search multinomial sampling — the warpers (temperature, top-k, top-p) act on each beam's log-probabilities and the K
+    continuations are DRAWN without replacement from softmax(accumulated scores) instead of taken by top-K (HF `_get_top_k_continuations`)."""
     B, V = int(num_beams), first_logits.numel()
     if B < 1 or max_new_tokens < 1:
         raise ValueError("num_beams and max_new_tokens must be >= 1")
@@ -58,8 +61,24 @@ def beam_search(first_logits: torch.Tensor, advance: Callable[[List[int], List[i
                     seen[torch.as_tensor(seqs[b], dtype=torch.long, device=dev)] = True
                 row = logp[b]
                 logp[b] = torch.where(seen, torch.where(row < 0, row * repetition_penalty, row / repetition_penalty), row)
+        if do_sample:                                               # TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper per beam
+            logp = logp.clone()
+            if temperature != 1.0:
+                logp = logp / temperature
+            if top_k > 0:
+                kth = torch.topk(logp, min(top_k, V), dim=-1).values[:, -1:]
+                logp = logp.masked_fill(logp < kth, float("-inf"))
+            if top_p < 1.0:
+                srt, order = torch.sort(logp, descending=False, dim=-1)
+                remove = srt.softmax(-1).cumsum(-1) <= (1.0 - top_p)
+                remove[:, -1:] = False
+                logp = logp.masked_fill(torch.zeros_like(remove).scatter(1, order, remove), float("-inf"))
         acc = (logp + run_scores[:, None]).reshape(-1)
-        top_v, top_i = torch.topk(acc, K)
+        if do_sample:
+            top_i = torch.multinomial(torch.softmax(acc, dim=-1), num_samples=K, generator=generator)
+            top_v = acc[top_i]
+        else:
+            top_v, top_i = torch.topk(acc, K)
         parents = (top_i // V).tolist()
         toks = (top_i % V).tolist()
         last = step + 1 >= max_new_tokens

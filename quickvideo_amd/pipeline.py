@@ -415,13 +415,11 @@ class PrefillPipeline:
                   top_p: Optional[float] = None, repetition_penalty: Optional[float] = None, seed: Optional[int] = None,
                   num_beams: int = 1, length_penalty: float = 1.0, early_stopping=False, **unused) -> List[int]:
         """generation kwargs as the reference hands them to HF `generate` (qwen25_lvu.py:744-761); unset ones fall back to the
-        checkpoint's generation_config.json (`model.generation_defaults`), then to greedy.  `num_beams > 1`: deterministic beam search
-        with HF's semantics (`length_penalty`, `early_stopping`; beam.py) on one GPU.
+        checkpoint's generation_config.json (`model.generation_defaults`), then to greedy.  `num_beams > 1`: beam search with HF's
+        semantics (`length_penalty`, `early_stopping`, with `do_sample` beam-search multinomial sampling; beam.py).
         `question`: the user's text, or the reference's `messages` list (chat(); qwen25_lvu.py:546-548) when the processor can
         template it.  eos_token_id: an id or a list of ids (HF stops on ANY of generation_config.eos_token_id)."""
         num_beams = int(num_beams)
-        if num_beams > 1 and (do_sample or (do_sample is None and (getattr(self.model, "generation_defaults", None) or {}).get("do_sample"))):
-            raise NotImplementedError("beam-search multinomial sampling (num_beams > 1 with do_sample=True) is not implemented; deterministic beam search is")
         gd = getattr(self.model, "generation_defaults", None) or {}
         pick = lambda v, k: gd.get(k) if v is None else v
         selector = TokenSelector(pick(do_sample, "do_sample") or False, pick(temperature, "temperature"), pick(top_k, "top_k"),
@@ -591,7 +589,9 @@ class PrefillPipeline:
             tm.ttft = time.perf_counter() - t_e2e
             beams = EngineBeams(eng, P["delta"], num_beams, max_new_tokens)
             search = lambda adv: beam_search(first, adv, num_beams, max_new_tokens, eos_ids=sorted(eos_set), length_penalty=float(length_penalty),   # noqa: E731
-                                             early_stopping=early_stopping, repetition_penalty=selector.penalty, prompt_ids=list(P["prompt"].tail_ids))
+                                             early_stopping=early_stopping, repetition_penalty=selector.penalty, prompt_ids=list(P["prompt"].tail_ids),
+                                             do_sample=selector.do_sample, temperature=selector.temperature, top_k=selector.top_k,
+                                             top_p=selector.top_p, generator=selector.gen)
             if not par.on:
                 out = search(beams.advance)
             else:

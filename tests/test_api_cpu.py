@@ -313,8 +313,8 @@ def test_load_hf_checkpoint_directory(tmp_path):
     out = obj.generate("hi", "synthetic://?frames=16&h=56&w=84&seed=1", max_new_tokens=2)
     assert obj.generate("hi", "synthetic://?frames=16&h=56&w=84&seed=1", max_new_tokens=2, num_beams=1) == out
     assert obj.generate("hi", "synthetic://?frames=16&h=56&w=84&seed=1", max_new_tokens=2, num_beams=2)[0].count("<tok_") == 2   # beam search (round 4)
-    with pytest.raises(NotImplementedError):                       # beam SAMPLING is refused, not ignored
-        obj.generate("hi", "synthetic://?frames=16&h=56&w=84&seed=1", max_new_tokens=2, num_beams=2, do_sample=True)
+    assert obj.generate("hi", "synthetic://?frames=16&h=56&w=84&seed=1", max_new_tokens=2, num_beams=2, do_sample=True,
+                        seed=3)[0].count("<tok_") >= 1               # beam-search multinomial sampling
     assert obj.generate("hi", "synthetic://?frames=16&h=56&w=84&seed=1", max_new_tokens=2, do_sample=True, temperature=0.7,
                         seed=1)[0].count("<tok_") == 2
     assert obj.generate("hi", "synthetic://?frames=16&h=56&w=84&seed=1", max_new_tokens=2, do_sample=True, top_k=1) == out
@@ -913,8 +913,7 @@ def test_generation_kwargs_like_hf_generate():
     toks = pen.split()
     assert len(set(toks)) == len(toks)
     assert run(num_beams=4).count("<tok_") >= 1                                            # deterministic beam search (tests/test_beam_search.py)
-    with pytest.raises(NotImplementedError):
-        run(num_beams=4, do_sample=True)
+    assert run(num_beams=4, do_sample=True, seed=5) == run(num_beams=4, do_sample=True, seed=5)    # beam sampling, reproducible by seed
     m.generation_defaults = {"do_sample": True, "temperature": 5.0}                      # generation_config.json of a checkpoint
     assert len({run(seed=s) for s in range(4)}) > 1 and run(do_sample=False) == greedy   # explicit kwargs win
 

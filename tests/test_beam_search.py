@@ -49,6 +49,34 @@ def test_beam_search_equals_hf_generate(B, lp, eos, es, rp, mnt):
         assert got == want, (seed, got, want)
 
 
+@pytest.mark.parametrize("B,kw", [(3, dict(temperature=1.3)), (4, dict(top_k=12)), (3, dict(top_p=0.8, temperature=0.9)), (2, dict())])
+def test_beam_sampling_equals_hf_generate(B, kw):
+    """num_beams > 1 with do_sample=True (beam-search multinomial sampling): the same draws from the same RNG state give HF's sequences."""
+    m = _tiny_model()
+    for seed in range(3):
+        g = torch.Generator().manual_seed(200 + seed)
+        prompt = torch.randint(13, 97, (1, 7), generator=g)
+        torch.manual_seed(77 + seed)
+        with torch.no_grad():
+            want = m.generate(prompt, num_beams=B, max_new_tokens=7, do_sample=True, eos_token_id=[5], pad_token_id=0, **kw)[0, 7:].tolist()
+        while want and want[-1] == 0:
+            want.pop()
+        seqs = [prompt[0].tolist() for _ in range(B)]
+
+        def advance(parents, tokens):
+            nonlocal seqs
+            seqs = [seqs[p] + [t] for p, t in zip(parents, tokens)]
+            with torch.no_grad():
+                return torch.stack([m(torch.tensor([s])).logits[0, -1].float() for s in seqs])
+
+        with torch.no_grad():
+            first = m(prompt).logits[0, -1].float()
+        torch.manual_seed(77 + seed)
+        got = beam_search(first, advance, B, 7, eos_ids=(5,), do_sample=True, temperature=kw.get("temperature", 1.0), top_k=kw.get("top_k", 0),
+                          top_p=kw.get("top_p", 1.0))
+        assert got == want, (seed, got, want)
+
+
 def test_beams_actually_differ_from_greedy_somewhere():
     """The comparison above must not be vacuous: on this model some prompt makes the 4-beam answer differ from the greedy one."""
     m = _tiny_model()
