@@ -62,29 +62,6 @@ def _overtakes(first: torch.cuda.Stream, second: torch.cuda.Stream, a: torch.Ten
     return e0.elapsed_time(eb) < 0.5 * e0.elapsed_time(ea)
 
 
-def _masked_stream(device: torch.device):
-    """QP_VIT_CU_STRIDE=k (developer experiment): a ViT stream restricted to every k-th CU (hipExtStreamCreateWithCUMask through
-    the HIP runtime torch loaded), so that the tower cannot take more than 1/k of the machine from the prefill.  None when unset."""
-    import ctypes
-    import os
-    k = int(os.environ.get("QP_VIT_CU_STRIDE", "0"))
-    if k < 2:
-        return None
-    cus = torch.cuda.get_device_properties(device).multi_processor_count
-    words = (cus + 31) // 32
-    mask = (ctypes.c_uint32 * words)()
-    for cu in range(0, cus, k):
-        mask[cu // 32] |= 1 << (cu % 32)
-    raw = ctypes.c_void_p()
-    hip = ctypes.CDLL("libamdhip64.so")
-    with torch.cuda.device(device):
-        if hip.hipExtStreamCreateWithCUMask(ctypes.byref(raw), words, mask) != 0:
-            return None
-    st = torch.cuda.ExternalStream(raw.value, device=device)
-    st._qp_mask_desc = f"every {k}th CU ({len(range(0, cus, k))} of {cus})"
-    return st
-
-
 def side_streams(device: torch.device, main: torch.cuda.Stream = None):
     """-> (vit_stream, copy_stream, report).  copy_stream: high priority (frame uploads go ahead of compute and use queues of their own);
     vit_stream: default priority.  Each is checked against the main stream and against the other; candidates that share a hardware
@@ -106,10 +83,8 @@ def side_streams(device: torch.device, main: torch.cuda.Stream = None):
             copy = s
             break
         report["copy_candidates_skipped"] += 1
-    vit = _masked_stream(device)                                        # experiment (QP_VIT_CU_STRIDE): a CU-masked ViT stream
-    if vit is not None:
-        report["vit_cu_mask"] = vit._qp_mask_desc
-    for _ in range(16 if vit is None else 0):
+    vit = None
+    for _ in range(16):
         s = torch.cuda.Stream(device)
         if _overtakes(main, s, a, probe) and (copy is None or (_overtakes(s, copy, a, probe) and _overtakes(copy, s, a, probe))):
             vit = s
