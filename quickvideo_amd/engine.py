@@ -13,7 +13,10 @@ Mirrors, per group, the reference's patched decoder layer (lvu/models/qwen25_lvu
   * GQA is native in the attention kernel (no repeat_kv materialisation, :61-62);
   * lm_head only for the last position of the prompt tail (HF 4.50 computes it for every video token).
 
-GEMMs go through torch (hipBLASLt); everything else is libquickprefill.so via quickvideo_amd.native.
+Two drivers of the same launches: `_forward_segment_native` hands a whole segment (all layers) to the library in ONE call
+(qp_prefill_segment: single-device key-norm path; GEMMs through the library's hipBLASLt plans), `forward_segment` issues them
+operator by operator (every other mode and layout; GEMMs through torch.mm or the library, whichever the warm-up tuner measured
+faster).  Everything that is not a GEMM is a hand-written kernel of libquickprefill.so via quickvideo_amd.native.
 """
 from __future__ import annotations
 
