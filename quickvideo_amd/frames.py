@@ -19,6 +19,8 @@ There is no FFmpeg / codec in this image, so real containers cannot be decoded; 
   * a DIRECTORY of image files (frame_000001.jpg ...; sorted by name; optional `fps.txt` holding the frame rate): every requested
     frame is DECODED (PIL: JPEG / PNG / ...) and LANCZOS-resized on the reader's worker threads — a real decode workload without
     FFmpeg (e.g. frames exported once with any tool; the reference keeps such a JPEG frame cache itself, lvu_cache.py:28-49)
+  * ONE multi-frame image file (animated GIF / WebP / APNG, multi-page TIFF): the containers PIL decodes by itself — a real file a user can
+    point `video_path` at without FFmpeg (AnimatedImageVideoReader)
 A real decoder plugs in by implementing the same five members.  Environment knobs QUICKCODEC_CORES /
 QUICKCODEC_INTERVALS are read like the reference does (interleaved:391-392) and passed to the reader."""
 from __future__ import annotations
@@ -197,6 +199,54 @@ class ImageFolderVideoReader(VideoReaderBase):
         return out
 
 
+class AnimatedImageVideoReader(VideoReaderBase):
+    """A video as ONE multi-frame image file — animated GIF / WebP / APNG, multi-page TIFF — decoded with PIL (no FFmpeg in the image, but
+    these containers PIL reads itself).  Frame rate from the file's per-frame duration (GIF / WebP / APNG `duration` in ms), else `fps`
+    in the query string of the path (`clip.gif?fps=12`), else 10.  Inter-frame coded formats are decoded sequentially up to the highest
+    requested index once (process()), then served from memory; every requested frame is resized with the reader's interpolation."""
+    EXT = (".gif", ".webp", ".apng", ".png", ".tif", ".tiff")
+
+    def __init__(self, path: str, num_threads: int = 8, num_intervals: int = 64):
+        super().__init__(path, num_threads, num_intervals)
+        from PIL import Image
+        base, _, query = path.partition("?")
+        self.file = base
+        q = dict(urllib.parse.parse_qsl(query))
+        with Image.open(base) as im:
+            self.total = int(getattr(im, "n_frames", 1))
+            self.src_w, self.src_h = im.size
+            dur = im.info.get("duration")
+        self.fps = float(q["fps"]) if "fps" in q else (1000.0 / dur if dur else 10.0)
+        self._decoded = {}
+
+    def __len__(self): return self.total
+    def get_fps(self): return self.fps
+
+    def process(self, idx):
+        super().process(idx)
+        from PIL import Image
+        want = set(int(i) for i in self._idx)
+        self._decoded = {}
+        with Image.open(self.file) as im:
+            for i in range(max(want) + 1 if want else 0):          # sequential: GIF / APNG frames are deltas of their predecessors
+                im.seek(i)
+                if i in want:
+                    self._decoded[i] = im.convert("RGB").copy()
+
+    def _frames(self, idx):
+        from PIL import Image
+        H, W = self.height or self.src_h, self.width or self.src_w
+        flt = {"LANCZOS": Image.LANCZOS, "BICUBIC": Image.BICUBIC, "BILINEAR": Image.BILINEAR, "NEAREST": Image.NEAREST}.get(
+            str(self.interpolation).upper(), Image.LANCZOS)
+        out = np.empty((len(idx), 3, H, W), dtype=np.uint8)
+        for j, i in enumerate(idx):
+            im = self._decoded[int(i)]
+            if im.size != (W, H):
+                im = im.resize((W, H), flt)
+            out[j] = np.asarray(im).transpose(2, 0, 1)
+        return out
+
+
 def open_video(path, num_threads: Optional[int] = None, num_intervals: Optional[int] = None) -> VideoReaderBase:
     if isinstance(path, VideoReaderBase):
         return path
@@ -217,9 +267,11 @@ def open_video(path, num_threads: Optional[int] = None, num_intervals: Optional[
         return ArrayVideoReader(p, nt, ni)
     if os.path.isdir(p):
         return ImageFolderVideoReader(p, nt, ni)
+    if p.partition("?")[0].lower().endswith(AnimatedImageVideoReader.EXT) and os.path.isfile(p.partition("?")[0]):
+        return AnimatedImageVideoReader(p, nt, ni)
     raise ValueError(f"cannot open {p!r}: this build has no video codec (no FFmpeg in the image); use synthetic://..., a "
-                     f".npy/.pt file of uint8 [F,3,H,W] frames, a directory of frame images, or pass a reader object with the "
-                     f"InterleavedVideoReader contract")
+                     f".npy/.pt file of uint8 [F,3,H,W] frames, a directory of frame images, an animated GIF / WebP / APNG / multi-page "
+                     f"TIFF, or pass a reader object with the InterleavedVideoReader contract")
 
 
 def smart_nframes(total_frames: int, video_fps: float, nframes: Optional[int] = None, fps: Optional[float] = None) -> int:

@@ -980,3 +980,31 @@ def test_image_folder_reader_decodes_and_runs_end_to_end(tmp_path):
     obj._ops = OracleOps()
     out = obj.generate("What moves?", str(tmp_path), max_new_tokens=2, eos_token_id=None)
     assert len(out) == 1 and obj._pipeline.last_timings.groups == 2
+
+
+def test_animated_gif_is_a_video(tmp_path):
+    """f3 (frame source): an animated GIF (the container PIL decodes by itself) as `video_path` — frame count, frame rate from the per-frame
+    duration, sequential decode of the delta-coded frames, LANCZOS resize to the planned size, end to end through LVU.generate."""
+    import lvu
+    from PIL import Image
+    from quickvideo_amd.frames import open_video
+    from quickvideo_amd.lvu import load_native_model
+    rs = np.random.RandomState(0)
+    frames = [Image.fromarray((rs.rand(60, 90, 3) * 255).astype(np.uint8)).convert("P", palette=Image.ADAPTIVE) for _ in range(24)]
+    path = str(tmp_path / "clip.gif")
+    frames[0].save(path, save_all=True, append_images=frames[1:], duration=100, loop=0)      # 10 fps
+    r = open_video(path)
+    assert len(r) == 24 and abs(r.get_fps() - 10.0) < 1e-6 and (r.src_h, r.src_w) == (60, 90)
+    r.height, r.width, r.frame_iter = 56, 84, 4
+    r.process(np.array([0, 5, 9, 23]))
+    got = next(r)
+    assert got.shape == (4, 3, 56, 84) and got.dtype == torch.uint8
+    with Image.open(path) as im:                                                              # frame 9 decoded independently
+        im.seek(9)
+        want = np.asarray(im.convert("RGB").resize((84, 56), Image.LANCZOS)).transpose(2, 0, 1)
+    assert np.array_equal(got[2].numpy(), want)
+    m = load_native_model("synthetic:tiny", device="cpu")
+    obj = lvu.LVU(lvu.LVUConfig("synthetic:tiny", top_p=0.5, video_group_size=4, num_frames=8), model=m)
+    obj._ops = OracleOps()
+    out = obj.generate("What is shown?", path, max_new_tokens=2)
+    assert out[0].count("<tok_") == 2 and obj._pipeline.last_timings.groups == 2
