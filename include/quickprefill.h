@@ -357,6 +357,21 @@ typedef struct qp_segment {
 int qp_prefill_segment(qp_ctx* ctx, const qp_segment* seg, const qp_layer* layers, int64_t* cache_len, const int64_t* k_keep,
                        void* stream);
 
+/* All blocks of the Qwen2-VL vision tower (transformers Qwen2VLVisionBlock [3P]) in one call — the tower's counterpart of
+ * qp_prefill_segment: per block  y = LayerNorm(x += pending) -> qkv = y Wqkv^T + b -> 2-D rotary -> full attention inside each temporal
+ * patch -> pending = a Wp^T + b -> y = LayerNorm(x += pending) -> z = Swish(1.702 (y W1^T + b1)) -> pending = z W2^T / 1.702 + b2
+ * (fc1 + quick-GELU as ONE GEMM, see qp_linear_act), the same launches quickvideo_amd/vit.py issues one by one.  On return x holds the
+ * residual stream WITHOUT the last block's MLP output, which is left in `pending` (the caller's final LayerNorm adds it: qp_add_layernorm).
+ * x, y, pending bf16 [n][dim]; qkv bf16 [n][3*dim]; att bf16 [n][dim]; z bf16 [n][mlp_dim]; cos/sin fp32 [n][head_dim/2];
+ * fc1_bias_scaled fp32 [mlp_dim] = 1.702 * b1.  n = n_seq * seq_len.  GEMM plans as for qp_linear_act (tune first). */
+typedef struct qp_vit_block {
+  const void *ln1_w, *ln1_b, *qkv_w, *qkv_b, *proj_w, *proj_b, *ln2_w, *ln2_b, *fc1_w, *fc1_bias_scaled, *fc2_w, *fc2_b;
+} qp_vit_block;
+
+int qp_vit_blocks(qp_ctx* ctx, const qp_vit_block* blocks, int n_blocks, int64_t n_seq, int64_t seq_len, int dim, int heads, int mlp_dim,
+                  void* x, void* y, void* qkv, void* att, void* pending, void* z, const float* cos, const float* sin, float ln_eps,
+                  void* gemm_ws, size_t gemm_ws_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

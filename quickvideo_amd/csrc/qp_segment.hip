@@ -3,6 +3,7 @@
 // them one by one — so a group costs one call from the caller's language instead of ~13 per layer (28 layers: 370 calls, 25-30 ms
 // of interpreter time per group, each torch call among them handing the interpreter lock to whoever waits for it).
 #include "qp_common.h"
+#include <math.h>
 
 namespace {
 
@@ -112,4 +113,31 @@ extern "C" int qp_prefill_segment(qp_ctx* ctx, const qp_segment* g, const qp_lay
     delta = g->down;
   }
   return qp_add_inplace(ctx, g->h, delta, n * d, stream);          // last residual                       (:198)
+}
+
+// The vision tower's blocks in one call (include/quickprefill.h: qp_vit_blocks) — same launches, same order as quickvideo_amd/vit.py.
+extern "C" int qp_vit_blocks(qp_ctx* ctx, const qp_vit_block* blocks, int n_blocks, int64_t n_seq, int64_t seq_len, int dim, int heads,
+                             int mlp_dim, void* x, void* y, void* qkv, void* att, void* pending, void* z, const float* cos, const float* sin,
+                             float ln_eps, void* gemm_ws, size_t gemm_ws_bytes, void* stream) {
+  QP_REQUIRE(ctx && blocks && x && y && qkv && att && pending && z && cos && sin && gemm_ws, QP_ERR_INVALID, "qp_vit_blocks: NULL argument");
+  QP_REQUIRE(n_blocks > 0 && n_seq > 0 && seq_len > 0 && dim > 0 && heads > 0 && dim % heads == 0 && mlp_dim > 0, QP_ERR_INVALID,
+             "qp_vit_blocks: bad sizes");
+  const int64_t n = n_seq * seq_len;
+  const int hd = dim / heads;
+  const float scale = (float)pow((double)hd, -0.5);          // the value the per-operator caller passes: float(head_dim ** -0.5)
+  const void* pend = nullptr;
+  int rc = QP_OK;
+  for (int b = 0; b < n_blocks; ++b) {
+    const qp_vit_block& w = blocks[b];
+    if ((rc = qp_add_layernorm(ctx, x, pend, w.ln1_w, w.ln1_b, y, n, dim, ln_eps, stream))) return rc;
+    if ((rc = qp_linear_act(ctx, y, w.qkv_w, w.qkv_b, 0, 1.0f, qkv, n, 3 * (int64_t)dim, dim, 0, gemm_ws, gemm_ws_bytes, stream))) return rc;
+    if ((rc = qp_vit_rope(ctx, qkv, cos, sin, n, heads, hd, stream))) return rc;
+    if ((rc = qp_vit_attn(ctx, qkv, n_seq, seq_len, heads, hd, scale, att, stream))) return rc;
+    if ((rc = qp_linear_act(ctx, att, w.proj_w, w.proj_b, 0, 1.0f, pending, n, dim, dim, 0, gemm_ws, gemm_ws_bytes, stream))) return rc;
+    if ((rc = qp_add_layernorm(ctx, x, pending, w.ln2_w, w.ln2_b, y, n, dim, ln_eps, stream))) return rc;
+    if ((rc = qp_linear_act(ctx, y, w.fc1_w, w.fc1_bias_scaled, 1, 1.702f, z, n, mlp_dim, dim, 1, gemm_ws, gemm_ws_bytes, stream))) return rc;
+    if ((rc = qp_linear_act(ctx, z, w.fc2_w, w.fc2_b, 0, 1.0f / 1.702f, pending, n, dim, mlp_dim, 0, gemm_ws, gemm_ws_bytes, stream))) return rc;
+    pend = pending;
+  }
+  return QP_OK;
 }

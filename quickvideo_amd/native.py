@@ -47,8 +47,14 @@ class QpSegment(_c.Structure):
                  ("gemm_ws_bytes", _sz), ("attn_events", _c.POINTER(_vp)), ("prune_events", _c.POINTER(_vp))])
 
 
+class QpVitBlock(_c.Structure):
+    """struct qp_vit_block (include/quickprefill.h)."""
+    _fields_ = [(n, _vp) for n in ("ln1_w", "ln1_b", "qkv_w", "qkv_b", "proj_w", "proj_b", "ln2_w", "ln2_b", "fc1_w", "fc1_bias_scaled", "fc2_w", "fc2_b")]
+
+
 # name -> (restype, argtypes): exactly the declarations of include/quickprefill.h
 SIGNATURES = {
+    "qp_vit_blocks": (_i32, [_vp, _c.POINTER(QpVitBlock), _i32, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f32, _vp, _sz, _vp]),
     "qp_prefill_segment": (_i32, [_vp, _c.POINTER(QpSegment), _c.POINTER(QpLayer), _c.POINTER(_i64), _c.POINTER(_i64), _vp]),
     "qp_create": (_i32, [_c.POINTER(_vp), _i32]),
     "qp_destroy": (None, [_vp]),
@@ -319,6 +325,13 @@ class QuickPrefillOps:
         ws = self._lt_workspace()
         seg.gemm_ws, seg.gemm_ws_bytes = ws.data_ptr(), ws.numel()
         self._check(self.lib.qp_prefill_segment(self.ctx, ctypes.byref(seg), layers, cache_len, k_keep, self._stream()))
+
+    def vit_blocks(self, blocks, n_blocks, n_seq, seq_len, dim, heads, mlp_dim, x, y, qkv, att, pending, z, cos, sin, eps):
+        """All blocks of the Qwen2-VL tower in one call (qp_vit_blocks); `blocks`: (QpVitBlock * n_blocks) array."""
+        ws = self._lt_workspace()
+        self._check(self.lib.qp_vit_blocks(self.ctx, blocks, n_blocks, n_seq, seq_len, dim, heads, mlp_dim, x.data_ptr(), y.data_ptr(), qkv.data_ptr(),
+                                           att.data_ptr(), pending.data_ptr(), z.data_ptr(), cos.data_ptr(), sin.data_ptr(), float(eps),
+                                           ws.data_ptr(), ws.numel(), self._stream()))
 
     def sp_unpack(self, gathered, world, n_kv, m2, head_dim, n, k_stage, v_stage, stage_head_stride, sumsq_out):
         self._check(self.lib.qp_sp_unpack(self.ctx, gathered.data_ptr(), world, n_kv, m2, head_dim, n, k_stage.data_ptr(), v_stage.data_ptr(),

@@ -241,7 +241,28 @@ class VisionTower:
 
         if fused_ln:
             x = x.contiguous()
-        for b in w.blocks:
+        # all blocks in ONE library call (qp_vit_blocks: the same launches, sequenced inside the library) once the GEMM plans of this row
+        # count exist — the first pass at a new row count goes block by block below and tunes them.  QP_VIT_ONE_CALL=0: always block by block.
+        one_call = (use_lt and fused_ln and hasattr(ops, "vit_blocks") and os.environ.get("QP_VIT_ONE_CALL", "1") == "1"
+                    and all(((nm, n, act, True) in self._lt_shapes) for nm, act in (("qkv", 0), ("proj", 0), ("fc1", ops.ACT_SWISH), ("fc2", 0))))
+        if one_call:
+            from .native import QpVitBlock
+            arr = self.__dict__.get("_blocks_arr")
+            if arr is None:
+                arr = (QpVitBlock * len(blocks))()
+                for i, b in enumerate(blocks):
+                    if getattr(b, "_fc1_b_scaled", None) is None:
+                        b._fc1_b_scaled = (b.fc1_b.float() * 1.702).contiguous()
+                    for f, tns in (("ln1_w", b.ln1_w), ("ln1_b", b.ln1_b), ("qkv_w", b.qkv_w), ("qkv_b", b.qkv_b), ("proj_w", b.proj_w), ("proj_b", b.proj_b),
+                                   ("ln2_w", b.ln2_w), ("ln2_b", b.ln2_b), ("fc1_w", b.fc1_w), ("fc1_bias_scaled", b._fc1_b_scaled), ("fc2_w", b.fc2_w),
+                                   ("fc2_b", b.fc2_b)):
+                        setattr(arr[i], f, tns.data_ptr())
+                self._blocks_arr = arr
+            e = lambda *shape: torch.empty(*shape, dtype=x.dtype, device=x.device)
+            mlp = blocks[0].fc1_w.shape[0]
+            qkv_b, att_b, pend, z_b = e(n, 3 * s.embed_dim), e(n, s.embed_dim), e(n, s.embed_dim), e(n, mlp)
+            ops.vit_blocks(arr, len(blocks), t, seq, s.embed_dim, H, mlp, x, ybuf, qkv_b, att_b, pend, z_b, cos_h, sin_h, 1e-6)
+        for b in (() if one_call else w.blocks):
             y = norm(b.ln1_w, b.ln1_b)
             qkv = (self._lt("qkv", y, b.qkv_w, b.qkv_b, peers=[bb.qkv_w for bb in blocks]) if use_lt
                    else F.linear(y, b.qkv_w, b.qkv_b))                                   # [n, 3*H*hd]
