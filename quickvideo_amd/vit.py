@@ -376,13 +376,9 @@ class VisionTower:
                 x, pend = x + pend, None
             return rms_t(x, g)
 
-        # the tower's GEMMs through the library's tuned hipBLASLt path, gate + SiLU as ONE GEMM with the Swish epilogue (QP_VIT_LT=0: torch)
-        use_lt = (fused and hasattr(ops, "linear_tune") and x.is_cuda and os.environ.get("QP_VIT_LT", "1") == "1"
-                  and all(bb.gate_w.is_contiguous() and bb.down_w.is_contiguous() for bb in w.blocks))
-        blocks = w.blocks
         for li, b in enumerate(w.blocks):
             y = rms(b.n1)
-            qkv = self._lt("qkv25", y, b.qkv_w, b.qkv_b, peers=[bb.qkv_w for bb in blocks]) if use_lt else F.linear(y, b.qkv_w, b.qkv_b)
+            qkv = F.linear(y, b.qkv_w, b.qkv_b)
             full = li in s.fullatt_blocks
             if ops is not None:
                 ops.vit_rope(qkv, cos_h, sin_h, H, hd)
@@ -409,13 +405,6 @@ class VisionTower:
                     a = torch.empty(n, H, hd, dtype=x.dtype, device=x.device)
                     a[wmap[wvalid]] = o.transpose(1, 2)[wvalid]
                     a = a.reshape(n, H * hd)
-            if use_lt:
-                pend = self._lt("proj25", a, b.proj_w, b.proj_b, peers=[bb.proj_w for bb in blocks])
-                y = rms(b.n2)
-                g = self._lt("gate25", y, b.gate_w, b.gate_b, act=ops.ACT_SWISH, peers=[bb.gate_w for bb in blocks])     # SiLU(y Wg^T + bg)
-                y = g * self._lt("up25", y, b.up_w, b.up_b, peers=[bb.up_w for bb in blocks])
-                pend = self._lt("down25", y, b.down_w, b.down_b, peers=[bb.down_w for bb in blocks])
-                continue
             pend = F.linear(a, b.proj_w, b.proj_b)
             y = rms(b.n2)
             y = F.silu(F.linear(y, b.gate_w, b.gate_b)) * F.linear(y, b.up_w, b.up_b)
