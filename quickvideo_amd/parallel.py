@@ -106,6 +106,12 @@ class ParallelContext:
             return self.grid_override
         if self.mode == "sp":
             return 1, self.world
+        forced = os.environ.get("QP_GRID")                              # "4x2": pp x sp forced for mode "auto" (A/B of the cost model's choice)
+        if forced and self.mode == "auto":
+            pp, sp = (int(v) for v in forced.lower().split("x"))
+            if pp * sp != self.world or pp > n_layers:
+                raise ValueError(f"QP_GRID={forced!r}: pp * sp must equal the {self.world} ranks of the job and pp <= {n_layers} layers")
+            return pp, sp
         if self.mode == "pp":
             if self.world > n_layers:
                 raise ValueError(f"layer pipeline over {self.world} ranks needs at least that many layers (model has {n_layers})")

@@ -176,6 +176,16 @@ def test_beam_search_over_ranks_equals_single_process(mode):
         assert ret[f"r{r}"] == want, (mode, r, ret[f"r{r}"], want)
 
 
+def test_forced_grid_env(monkeypatch):
+    from quickvideo_amd.parallel import ParallelContext
+    ctx = ParallelContext("auto", 8, 3)
+    monkeypatch.setenv("QP_GRID", "4x2")
+    assert ctx.grid(4, 28) == (4, 2) and ParallelContext("sp", 8, 0).grid(4, 28) == (1, 8)
+    monkeypatch.setenv("QP_GRID", "4x4")
+    with pytest.raises(ValueError):
+        ctx.grid(4, 28)
+
+
 def test_layout_cost_model():
     from quickvideo_amd.parallel import choose_layout, layout_efficiency, stage_balance
     assert stage_balance(28, 8) == pytest.approx(3.5 / 4) and stage_balance(28, 4) == 1.0 and stage_balance(80, 8) == 1.0
