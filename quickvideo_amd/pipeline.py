@@ -547,7 +547,11 @@ class PrefillPipeline:
                 if lead:
                     prod.release(g, read_done)
                 if g + 1 < G:
-                    nxt = vit_group(g + 1, gate=p0_prev if self.use_gpu else None)   # ViT of the next group: own stream, beside the prefill
+                    # ViT of the next group: own stream, beside the prefill.  The run-ahead gate is rank 0's alone: its scatter feeds every
+                    # rank's share of the tower, so gating it there bounds them all — while a gate on a LATE pipeline stage's own prefill
+                    # (pp-1 groups behind stage 0) would hold back the all-gather stage 0 is waiting for and cap a pipe of more than
+                    # three stages at 2/(pp-1) of its rate
+                    nxt = vit_group(g + 1, gate=p0_prev if (self.use_gpu and lead) else None)
                     if self.use_gpu:
                         p0_prev = p0
                 start += n
