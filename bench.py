@@ -1278,6 +1278,8 @@ def main():
     single_dev = os.environ.get("QP_BENCH_SINGLE_DEVICE") == "1"
     if single_dev:
         local_rank = 0
+    if world > 1:
+        qp_parallel.multi_gpu_runtime_defaults()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     group, backend = None, None
@@ -1397,7 +1399,8 @@ def main():
                 out[k] = res[k]
         if world > 1:
             out["rccl_ranks"] = {"world_size": torch.distributed.get_world_size(), "backend": backend,
-                                 "note": "backend 'nccl' is RCCL over xGMI on ROCm; 'gloo' only under QP_BENCH_SINGLE_DEVICE=1"}
+                                 "note": "backend 'nccl' is RCCL over xGMI on ROCm; 'gloo' only under QP_BENCH_SINGLE_DEVICE=1",
+                                 "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")}
             if eff_sp is not None:
                 out["sp_efficiency_probe"] = {str(k): v for k, v in eff_sp.items()}
                 # the cost model --parallel auto chose the grid with (quickvideo_amd/parallel.py): fill/drain x heaviest stage x sp efficiency,

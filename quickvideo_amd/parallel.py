@@ -190,13 +190,29 @@ def resolve(parallel: Optional[str] = None, group=None) -> ParallelContext:
     return ParallelContext(mode, world, rank, group)
 
 
+def multi_gpu_runtime_defaults() -> None:
+    """Environment a multi-GPU rank wants BEFORE its first HIP call (setdefault: the user's own setting wins).
+
+    GPU_MAX_HW_QUEUES=16: the HIP runtime multiplexes a process's streams onto 4 hardware queues per priority by default, and streams on
+    one queue run in submission order.  A rank of the pipeline owns more than that — the LLM stream, the ViT stream, the copy stream
+    (rank 0) and one RCCL stream per process group it talks on (front end, pair-send, pair-recv, stage group, the job's group) — and an
+    RCCL kernel that spins for its peer would hold back whatever shares its queue: a hand-off waiting for the NEXT stage would stall THIS
+    stage's compute (lock-step instead of a pipeline).  Measured on one MI355X (tools/probe/probe_hw_queues.py,
+    profiles/r4_hw_queue_classes.txt): main + 8 default + 6 high-priority streams fall into 8 independent classes at the default, 14 at
+    8 and 15 (= all) at 16; the single-GPU pipeline runs at the same speed under 16 (cfg4s: 48.47 k vs 48.44-48.59 k tok/s).
+    Deadlock is excluded either way by construction (a stage posts recv(g) only after its part of all-gather(g) is done), this is
+    about not serialising.  No multi-GPU box has run it."""
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # the host driver only supports dmabuf IPC
+
+
 def init_distributed(backend: Optional[str] = None) -> ParallelContext:
     """Convenience for a script launched with one process per GPU (`python -m torch.distributed.run --nproc-per-node N --master-addr
     127.0.0.1 script.py`): binds this process to its GPU (LOCAL_RANK), initialises torch.distributed (backend "nccl" = RCCL over xGMI on a
     GPU box; "gloo" on CPU) unless that has been done already, and returns the resolved context.  In a plain single-process run it does
     nothing and returns the single context — the same script works on 1 and on 8 GPUs."""
     if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not torch.distributed.is_initialized():
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # the host driver only supports dmabuf IPC
+        multi_gpu_runtime_defaults()
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         cuda = torch.cuda.is_available()
         kw = {}
