@@ -1282,6 +1282,8 @@ def main():
         qp_parallel.multi_gpu_runtime_defaults()
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    if os.environ.get("QP_BENCH_LLM_PRIORITY"):          # experiment: the whole run on a stream of this priority (-1 = high) instead of the default stream
+        torch.cuda.set_stream(torch.cuda.Stream(device, priority=int(os.environ["QP_BENCH_LLM_PRIORITY"])))
     group, backend = None, None
     preflight = None
     if world == 1 and args.nccl_preflight:
