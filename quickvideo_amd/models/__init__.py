@@ -27,9 +27,17 @@ def discover() -> Dict[str, Dict[str, Callable]]:
     return found
 
 
+# The reference's own registry keys (lvu/models/: qwen25_lvu_interleaved.py = overlapped producer, qwen25_lvu.py = fetch-then-prefill,
+# qwen25_vl.py = the older copy of the latter and LVUConfig's default there) resolve to the native plugin with the same schedule, so a
+# reference user's `LVUConfig(..., model_type="qwen25_lvu_interleaved")` runs unchanged.
+REFERENCE_ALIASES = {"qwen25_lvu_interleaved": "qwen2vl_mi355x", "qwen25_lvu": "qwen2vl_mi355x_sequential", "qwen25_vl": "qwen2vl_mi355x_sequential"}
+
 _plugins = discover()
+for _alias, _target in REFERENCE_ALIASES.items():
+    _plugins.setdefault(_alias, _plugins[_target])
 lvu_init_model_map = {name: fns["init_lvu_model"] for name, fns in _plugins.items()}
 lvu_run_model_map = {name: fns["run_lvu_model"] for name, fns in _plugins.items()}
 lvu_chat_model_map = {name: fns["chat_lvu_model"] for name, fns in _plugins.items() if "chat_lvu_model" in fns}
 
-__all__ = sorted(_plugins) + ["lvu_init_model_map", "lvu_run_model_map", "lvu_chat_model_map", "discover"]
+__all__ = sorted(n for n in _plugins if n not in REFERENCE_ALIASES) + ["lvu_init_model_map", "lvu_run_model_map", "lvu_chat_model_map", "discover",
+                                                                          "REFERENCE_ALIASES"]

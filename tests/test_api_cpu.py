@@ -24,6 +24,14 @@ def test_lvu_surface_and_registry():
         lvu.LVU(lvu.LVUConfig("synthetic:tiny", model_type="no_such_plugin"), model=m)       # lvu.py:33-34
     with pytest.raises(ValueError):
         load_native_model("Qwen/NoSuchModel", device="cpu")
+    # the reference's own registry keys (lvu/models/*.py file stems) run unchanged: overlapped <-> interleaved, the other two sequential
+    from quickvideo_amd.models import REFERENCE_ALIASES
+    assert set(REFERENCE_ALIASES) == {"qwen25_lvu_interleaved", "qwen25_lvu", "qwen25_vl"}
+    for alias, target in REFERENCE_ALIASES.items():
+        assert lvu_run_model_map[alias] is lvu_run_model_map[target] and lvu_init_model_map[alias] is lvu_init_model_map[target]
+        assert lvu_chat_model_map[alias] is lvu_chat_model_map[target]
+    ref_style = lvu.LVU(lvu.LVUConfig("synthetic:tiny", model_type="qwen25_lvu_interleaved", top_p=0.5, video_group_size=4, num_frames=8), model=m)
+    assert ref_style.run_model_func.__func__ is lvu_run_model_map["qwen2vl_mi355x"]
     obj = lvu.LVU(lvu.LVUConfig("synthetic:tiny", top_p=0.5, video_group_size=4, num_frames=8), model=m)
     assert callable(obj.generate) and callable(obj.chat) and obj.model is m
 
