@@ -68,6 +68,10 @@ def _nccl_world1_worker(rank, port, ret):
         mk = lambda **kw: QuickPrefillEngine(DecoderWeights.from_named(spec, w, dev), cfg, capacity=T + 8,          # noqa: E731
                                              max_group_tokens=max(plan.tokens + [plan.tail_len]), device=dev, **kw)
         os.environ["QP_NATIVE_SEGMENT"] = "0"       # the bit-for-bit comparison below is between two runs of the per-operator loop (same GEMM calls)
+        # ... and with the GEMM decompositions NOT timed: the plain engine picks row splits / hipBLASLt candidates by stopwatch (a > 3 % win),
+        # the TP projections (_linear_reduced) take fixed row blocks — on these tiny shapes timing noise decides whether the two run the same
+        # kernels, and the logits then agreed bit for bit in 5 runs of 7 (another algorithm = another fp32 accumulation order)
+        os.environ["QP_TUNE_GEMMS"] = "0"
         base = _run_engine(mk(), plan, pos, embeds)
         # tensor parallel layout on a 1-rank RCCL group: 2 x all_reduce bf16 [n, d] + all_gather_into_tensor fp32 [Hkv, n] per layer
         grp = dist.new_group(ranks=[0])                                                  # bench.py builds stage groups like this
