@@ -193,16 +193,18 @@ def resolve(parallel: Optional[str] = None, group=None) -> ParallelContext:
 def multi_gpu_runtime_defaults() -> None:
     """Environment a multi-GPU rank wants BEFORE its first HIP call (setdefault: the user's own setting wins).
 
-    GPU_MAX_HW_QUEUES=16: the HIP runtime multiplexes a process's streams onto 4 hardware queues per priority by default, and streams on
+    GPU_MAX_HW_QUEUES=8: the HIP runtime multiplexes a process's streams onto 4 hardware queues per priority by default, and streams on
     one queue run in submission order.  A rank of the pipeline owns more than that — the LLM stream, the ViT stream, the copy stream
     (rank 0) and one RCCL stream per process group it talks on (front end, pair-send, pair-recv, stage group, the job's group) — and an
     RCCL kernel that spins for its peer would hold back whatever shares its queue: a hand-off waiting for the NEXT stage would stall THIS
     stage's compute (lock-step instead of a pipeline).  Measured on one MI355X (tools/probe/probe_hw_queues.py,
     profiles/r4_hw_queue_classes.txt): main + 8 default + 6 high-priority streams fall into 8 independent classes at the default, 14 at
-    8 and 15 (= all) at 16; the single-GPU pipeline runs at the same speed under 16 (cfg4s: 48.47 k vs 48.44-48.59 k tok/s).
+    8 (every high-priority stream — RCCL's and the copy stream — and the first 7 default ones on queues of their own) and 15 at 16; the
+    single-GPU pipeline runs at the same speed under 16 (cfg4s: 48.47 k vs 48.44-48.59 k tok/s).  8 is enough for a rank's streams and
+    keeps the process's queue count (8 per priority) inside what the command processor schedules without time-slicing.
     Deadlock is excluded either way by construction (a stage posts recv(g) only after its part of all-gather(g) is done), this is
     about not serialising.  No multi-GPU box has run it."""
-    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # the host driver only supports dmabuf IPC
 
 
