@@ -188,6 +188,11 @@ int qp_launch_linear_tune(qp_ctx* ctx, const void* x, const void* const* ws_list
   for (int c = 0; c < best_i; ++c)
     if (t_ms[c] > 0.f && t_ms[c] <= 1.02f * best) { best_i = c; break; }
   (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+  // Every candidate has just used the caller's workspace its own way; stream-K kernels keep their arrival flags there and expect to find
+  // them zero (they reset them on the way out).  Leave the workspace as a fresh allocation would be, so that the algorithm picked here
+  // never meets another candidate's partial tiles where it expects its flags.
+  if (workspace && workspace_bytes && (hipMemsetAsync(workspace, 0, workspace_bytes, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess))
+    return qp_fail(QP_ERR_HIP, "qp_linear_tune: clearing the workspace failed");
   if (best_i < 0) return qp_fail(QP_ERR_HIP, "qp_linear_tune: no candidate ran");
   p.algo = p.cands[best_i].algo;
   p.ws = p.cands[best_i].workspaceSize;
