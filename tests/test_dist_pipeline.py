@@ -186,6 +186,17 @@ def test_forced_grid_env(monkeypatch):
         ctx.grid(4, 28)
 
 
+def test_multi_gpu_runtime_defaults_do_not_override_the_user(monkeypatch):
+    from quickvideo_amd.parallel import multi_gpu_runtime_defaults
+    monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
+    monkeypatch.delenv("HSA_ENABLE_IPC_MODE_LEGACY", raising=False)
+    multi_gpu_runtime_defaults()
+    assert os.environ["GPU_MAX_HW_QUEUES"] == "8" and os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "2")
+    multi_gpu_runtime_defaults()
+    assert os.environ["GPU_MAX_HW_QUEUES"] == "2"
+
+
 def test_layout_cost_model():
     from quickvideo_amd.parallel import choose_layout, layout_efficiency, stage_balance
     assert stage_balance(28, 8) == pytest.approx(3.5 / 4) and stage_balance(28, 4) == 1.0 and stage_balance(80, 8) == 1.0
