@@ -186,6 +186,18 @@ def test_forced_grid_env(monkeypatch):
         ctx.grid(4, 28)
 
 
+def test_run_ahead_gate_model():
+    """tools/sim_pipeline.py (dependency model of the layer pipeline): with every stage gating the ViT run-ahead on its own prefill a deep
+    pipe is throttled towards 2/(pp-1); with rank 0's gate alone (pipeline.py) it runs at full rate."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("sim_pipeline", os.path.join(os.path.dirname(__file__), "..", "tools", "sim_pipeline.py"))
+    sim = importlib.util.module_from_spec(spec); spec.loader.exec_module(sim)
+    for pp in (2, 3, 4, 8):
+        assert sim.rate(pp) == pytest.approx(1.0, abs=0.01)
+    assert sim.rate(4, every_stage_gates=True) < 0.7 and sim.rate(8, every_stage_gates=True) < 0.3
+    assert sim.rate(2, every_stage_gates=True) == pytest.approx(1.0, abs=0.01)
+
+
 def test_multi_gpu_runtime_defaults_do_not_override_the_user(monkeypatch):
     from quickvideo_amd.parallel import multi_gpu_runtime_defaults
     monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
