@@ -634,6 +634,8 @@ def cpu_baseline(name, sample_layers=2):
             "error_band": _cpu_error_band(tok_s, G),
             "full_video_cpu_seconds_extrapolated": round(total, 1),
             "points": [{"group": gi, "prefix_rows": p, "seconds": round(t, 3)} for gi, p, t in pts],
+            "sample_short": f"{sample_layers}/{ps.n_layers} layers x first {rows}/{plan.tokens[-1]} tokens of groups 0,{G // 2},{G - 1} on their full pruned "
+                            f"prefixes: {sum(t for *_, t in pts):.1f}s CPU; line t(P) summed over {G} groups, x L/{sample_layers}, x n/{rows}",
             "sample": f"extrapolated (BASELINE.md §3): {sample_layers} of {ps.n_layers} decoder layers (bf16 torch-CPU oracle incl. key-norm "
                       f"prune) over the first {rows} of {plan.tokens[-1]} new tokens of groups 0, {G // 2}, {G - 1} on their full pruned "
                       f"prefixes ({pts[0][1]}, {pts[1][1]}, {pts[2][1]} rows): {sum(t for *_, t in pts):.1f}s of CPU work; line t(P) fitted "
@@ -1212,6 +1214,90 @@ def secondary_cfg2(args, device, weights):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+# the ONE stdout line (compact, < 4 KB) and the full record beside it
+# ----------------------------------------------------------------------------------------------------------------------
+LINE_LIMIT = 4096
+
+
+def write_full_record(out):
+    """Everything measured (every leg, every note) -> gpurun_out/bench_full.json (merged back from the GPU box) and stderr.  The
+    stdout line carries the contract fields only (round 4's 29 KB line was truncated by the driver and never parsed)."""
+    text = json.dumps(out)
+    path = os.path.join(ROOT, "gpurun_out", os.environ.get("QP_BENCH_FULL_RECORD", "bench_full.json"))
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            f.write(text + "\n")
+    except OSError as e:
+        progress(f"full record not written ({e})")
+        path = None
+    print("[bench full record] " + text, file=sys.stderr, flush=True)
+    return None if path is None else os.path.relpath(path, ROOT)
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if d and k in d and d[k] is not None}
+
+
+def compact_line(out, full_path=None):
+    """Contract keys + config + roofline + cpu_baseline + ttft_ms / value_with_vit, numbers only where a sentence is not required."""
+    c = out["config"]
+    line = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling"))
+    line["vs_baseline"] = out.get("vs_baseline")
+    line.update(_pick(out, ("dtype", "data")))
+    line["config"] = {**_pick(c, ("workload", "groups", "tokens_per_group", "prefill_tokens", "tail_tokens", "layers", "parallelism")),
+                      "step": "1/steps of the video's sequential group loop, all layers; last step + prompt tail -> first-token logits"
+                      if "1/" in c.get("step", "") else "one full pass over the video + prompt tail",
+                      "vit": "excluded from value (embeddings resident in HBM); included in value_with_vit / ttft_ms"}
+    line.update(_pick(out, ("full_prefill_ms", "first_token", "algorithmic_tflop_per_pass", "mfma_frac_whole_pass", "value_with_vit", "ttft_ms")))
+    r = out.get("roofline")
+    if r:
+        rl = _pick(r, ("bound", "achieved", "peak", "unit", "frac"))
+        rl["traffic"] = r.get("traffic")
+        rl.update(_pick(r, ("traffic_over_algorithmic", "launches", "avg_launch_ms", "algorithmic_flops_per_launch", "kernel_ms_per_pass")))
+        rl["kernel"] = r.get("kernel", "").split(" (")[0]
+        rl["timing"] = "HIP events on the launch stream inside the timed region" if "inside" in r.get("timing", "") else "HIP events, one extra pass"
+        rl["traffic_source"] = "rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE child passes in this run" if "IN THIS RUN" in (r.get("traffic_source") or "") \
+            else ("committed profiles/ (not this run)" if r.get("traffic") else None)
+        line["roofline"] = rl
+    rp = out.get("roofline_prune")
+    if rp:
+        line["roofline_prune"] = {**_pick(rp, ("bound", "achieved", "peak", "unit", "frac", "launches", "avg_launch_us", "empty_launch_floor_us")),
+                                  "traffic": rp.get("traffic"), "kernel": "prune_keys_kernel"}
+    cb = out.get("cpu_baseline")
+    if cb:
+        cbl = _pick(cb, ("value", "unit", "cores", "kind", "extrapolated", "full_video_cpu_seconds_extrapolated"))
+        smp = cb.get("sample_short") or cb.get("sample", "")
+        cbl["sample"] = smp if len(smp) <= 200 else smp[:197] + "..."
+        line["cpu_baseline"] = cbl
+    d = out.get("decode")
+    if isinstance(d, dict):
+        line.update({f"decode_{k}": d[k] for k in ("ms_per_token", "tokens_per_s") if k in d})
+    ftc = out.get("first_token_check")
+    if ftc:
+        line["first_token_matches_record"] = ftc.get("match")
+    if out.get("rccl_ranks"):
+        line["rccl_ranks"] = _pick(out["rccl_ranks"], ("world_size", "backend"))
+    if out.get("nccl_preflight"):
+        line["nccl_preflight"] = _pick(out["nccl_preflight"], ("backend", "world_size"))
+    tp = out.get("tp")
+    if isinstance(tp, dict):
+        line["tp"] = _pick(tp, ("parallelism", "value", "ms_per_step", "full_prefill_ms"))
+    if out.get("note"):
+        line["note"] = out["note"][:200]
+    if full_path:
+        line["full_record"] = full_path
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) >= LINE_LIMIT:                       # cannot happen with the fields above; never let the line grow past the limit again
+        for k in ("tp", "roofline_prune", "note", "nccl_preflight", "full_record"):
+            line.pop(k, None)
+            text = json.dumps(line, separators=(",", ":"))
+            if len(text) < LINE_LIMIT:
+                break
+    return text
+
+
+# ----------------------------------------------------------------------------------------------------------------------
 def self_launch(args):
     """`python bench.py --gpus N` from a bare shell: re-exec under torch.distributed.run, one rank per GPU (RCCL)."""
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
@@ -1238,6 +1324,10 @@ def main():
     ap.add_argument("--no-decode", action="store_true", help="skip the greedy-decode leg (hipGraph step, ms per token)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary cfg2 block")
     ap.add_argument("--lean", action="store_true", help="only the timed pass (= all the --no-* switches)")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the in-run rocprofv3 --pmc child passes (roofline.traffic then comes from the "
+                    "committed profiles/, labelled so)")
+    ap.add_argument("--full", action="store_true", help="also run the secondary legs (sequential front end, peaked-softmax attention, host "
+                    "contention, cfg4ref, cfg2): minutes more; their blocks go to the full record (gpurun_out/bench_full.json), never to the line")
     ap.add_argument("--nccl-preflight", action="store_true", help="N=1 only: initialise torch.distributed with backend nccl (= RCCL), "
                     "world_size 1, and run the pass THROUGH that group in the tensor-parallel layout (2 all-reduces of [n, d] + 1 all-gather "
                     "of the key sums per layer, each a 1-rank RCCL call): the multi-GPU code path on a 1-GPU box; `value` must stay put")
@@ -1250,6 +1340,8 @@ def main():
     args = ap.parse_args()
     if args.lean:
         args.no_cpu_baseline = args.no_pipeline = args.no_decode = args.no_secondary = True
+    if not args.full:
+        args.no_secondary = True
     if args.cpu_baseline_check:
         print(json.dumps(cpu_baseline_check(args.cpu_baseline_check)))
         return
@@ -1337,7 +1429,7 @@ def main():
         return
     attach_traffic(res.get("roofline"), name, world)
     attach_hbm_kernels(res, name, world)
-    if world == 1 and res.get("roofline") and not args.lean and not args.no_secondary:
+    if world == 1 and res.get("roofline") and not args.lean and not args.no_pmc:
         live = collect_attention_traffic(name, ctx["spec"], ctx["plan"], ctx["cfg"])
         if live:
             r_ = res["roofline"]
@@ -1427,7 +1519,8 @@ def main():
                 out[k] = v
         if note:
             out["note"] = note
-        emit_line(json.dumps(out))
+        full_path = write_full_record(out)
+        emit_line(compact_line(out, full_path))
 
     if world == 1:
         # The auxiliary legs (decode, video -> first token, cfg2 block, CPU baseline) come after the timed region.  Should one of them
@@ -1446,11 +1539,11 @@ def main():
         if not args.no_decode:
             legs["decode"] = decode_leg(eng, res["first_token"])   # the engine holds the cache of the timed pass (prefill + tail)
             progress("decode leg done")
-        if not args.no_decode and CONFIGS[name][0] == "qwen2-vl-7b":
+        if not args.no_decode and args.full and CONFIGS[name][0] == "qwen2-vl-7b":
             legs["peaked"] = peaked_attention_leg(eng.ops, device)
             progress("peaked-softmax attention leg done")
         if not args.no_pipeline:
-            legs["video_to_first_token"] = pipeline_leg(name, eng, device)
+            legs["video_to_first_token"] = pipeline_leg(name, eng, device, modes=("overlapped", "sequential") if args.full else ("overlapped",))
             progress("video -> first token leg done")
         if not args.no_pipeline and not args.no_secondary and name in ("cfg4", "cfg4s") and CONFIGS[name][0] == "qwen2-vl-7b":
             legs["host_contention"] = host_contention_leg(eng, device)
@@ -1489,7 +1582,8 @@ def main():
         mode = "tp" if parallel == "tp" else {"both": "auto", "auto": "auto", "sp": "sp", "pp": "pp"}[args.parallel]
         mdl = load_native_model(f"synthetic:{CONFIGS[name][0]}", device=device, seed=0, parallel=mode)
         mdl.parallel.sp_efficiency = eff_sp
-        legs["video_to_first_token"] = pipeline_leg(name, None, device, model=mdl, vit_alone=False)
+        legs["video_to_first_token"] = pipeline_leg(name, None, device, model=mdl, vit_alone=False,
+                                                    modes=("overlapped", "sequential") if args.full else ("overlapped",))
         progress("video -> first token leg done")
         if tp_block is not None and parallel != "tp":               # ... and once through the north_star's contract layout
             del mdl

@@ -11,18 +11,33 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_bench(args, env_extra=None, timeout=600):
+_RUN = [0]
+
+
+def run_bench(args, env_extra=None, timeout=600, full=False):
+    """-> the stdout line (compact, < 4 KB: what the driver parses); full=True -> (line, full record written to gpurun_out/)."""
     env = dict(os.environ)
     env.update(env_extra or {})
+    _RUN[0] += 1
+    rec = f"bench_full_test_{os.getpid()}_{_RUN[0]}.json"
+    env["QP_BENCH_FULL_RECORD"] = rec
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = p.stdout.splitlines()
     assert len(lines) == 1 and lines[0].startswith("{"), p.stdout[-2000:]      # stdout = ONE line, the JSON (native libraries' prints go to stderr)
-    return json.loads(lines[0])
+    assert len(lines[0]) < 4096, len(lines[0])                                  # round 4's 29 KB line was truncated by the driver: never again
+    line = json.loads(lines[0])
+    path = os.path.join(ROOT, "gpurun_out", rec)
+    assert line["full_record"] == os.path.join("gpurun_out", rec) and os.path.exists(path)
+    record = json.load(open(path))
+    os.remove(path)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step"):     # the line is a projection of the record
+        assert line[k] == record[k], k
+    return (line, record) if full else line
 
 
 def test_bench_contract_fields_single_gpu():
-    d = run_bench(["--config", "cfg4s", "--steps", "5", "--warmup", "1", "--no-pipeline", "--no-secondary", "--no-decode"])
+    d, rec = run_bench(["--config", "cfg4s", "--steps", "5", "--warmup", "1", "--no-pipeline", "--no-decode"], full=True)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
               "config", "roofline", "cpu_baseline"):
         assert k in d, k
@@ -33,14 +48,21 @@ def test_bench_contract_fields_single_gpu():
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and 0.2 < r["frac"] < 0.8
     assert d["roofline_prune"]["empty_launch_floor_us"] > 0
     c = d["cpu_baseline"]
-    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c.get("extrapolated") and len(c["points"]) == 3
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c.get("extrapolated") and len(c["sample"]) <= 200
+    assert len(rec["cpu_baseline"]["points"]) == 3 and rec["roofline"]["frac"] == r["frac"]
+    # roofline.traffic: collected IN THIS RUN by the rocprofv3 --pmc child passes whenever rocprofv3 is on the box
+    import shutil
+    if shutil.which("rocprofv3"):
+        assert r["traffic"] and "this run" in r["traffic_source"] and 0.9 < r["traffic_over_algorithmic"] < 4.0, r
 
 
 def test_bench_two_ranks_on_one_gpu_reproduce_the_single_gpu_token():
     # (cfg2: 4 groups of 5760 tokens — two ranks time-sharing ONE GPU over gloo with host-staged hand-offs took 575 s on the 45 groups of
     # cfg4s, half of the driver's budget for the whole GPU suite; the layouts' code paths are the same on 4 groups)
     one = run_bench(["--config", "cfg2", "--steps", "2", "--warmup", "1", "--lean"])
-    two = run_bench(["--gpus", "2", "--config", "cfg2", "--steps", "2", "--warmup", "1"], {"QP_BENCH_SINGLE_DEVICE": "1"}, timeout=900)
+    line, two = run_bench(["--gpus", "2", "--config", "cfg2", "--steps", "2", "--warmup", "1", "--full"], {"QP_BENCH_SINGLE_DEVICE": "1"}, timeout=900, full=True)
+    assert line["n_gpus"] == 2 and line["rccl_ranks"] == {"world_size": 2, "backend": "gloo"} and line["tp"]["parallelism"] == "tp2"
+    assert line["ttft_ms"] == two["ttft_ms"] and line["value_with_vit"] == two["value_with_vit"]
     assert two["n_gpus"] == 2 and two["rccl_ranks"]["world_size"] == 2 and two["rccl_ranks"]["backend"] == "gloo"
     assert two["tp"]["parallelism"] == "tp2" and "sp_efficiency_probe" in two
     assert two["first_token"] == one["first_token"] == two["tp"]["first_token"]              # same model under every layout
@@ -66,7 +88,7 @@ def test_bench_nccl_preflight_runs_the_pass_through_rccl_with_the_same_result():
     one = run_bench(["--config", "cfg4s", "--steps", "5", "--warmup", "1", "--lean"])
     pre = run_bench(["--config", "cfg4s", "--steps", "5", "--warmup", "1", "--lean", "--nccl-preflight"])
     assert pre["nccl_preflight"]["backend"] == "nccl" and pre["nccl_preflight"]["world_size"] == 1
-    assert pre["first_token"] == one["first_token"] and pre["first_token_check"]["match"]
+    assert pre["first_token"] == one["first_token"] and pre["first_token_matches_record"]
     # (0.85: the TP layout runs the per-operator loop with o_proj / down_proj in two row blocks + asynchronous all-reduces — on ONE rank
     # nothing can be overlapped and that form costs ~7 % (44.7 k vs 48.1 k tok/s with QP_TP_CHUNKS=1 vs 49.2 k plain, measured in round 4))
     assert 0.85 <= pre["value"] / one["value"] <= 1.05, (pre["value"], one["value"])
