@@ -46,9 +46,14 @@ typedef enum qp_status {
 /* ---- context ------------------------------------------------------------------------------ */
 /* device: HIP ordinal.  One context per device/process (one process per GPU under tensor parallel). */
 int qp_create(qp_ctx** out, int device);
+/* Developer A/B switches (tools/bench_attn.py, the kernel-form parity tests): "attn_variant" (0 production; 1 v1, 2 no kv split, 3 no
+ * XCD map, 4 s4, 7 / 8 = 4- / 8-wave s6), "attn_force_split", "s6_prio", "s6_early_out", "decode_attn_valu", "attn_debug".  Process-wide.
+ * The launch paths never read the environment: the table is filled once at first use from QP_ATTN_VARIANT, QP_ATTN_FORCE_SPLIT,
+ * QP_S6_PRIO, QP_S6_EARLY_OUT, QP_DECODE_ATTN, QP_ATTN_DEBUG and changes only through this call.  Not part of the reference seams. */
+int qp_dev_switch(const char* name, int value);
 void qp_destroy(qp_ctx* ctx);
 const char* qp_last_error(void);
-const char* qp_version(void);          /* "quickprefill-mi355x 0.3 (gfx950)": 0.3 = round 3, prune_mode became a per-call argument */
+const char* qp_version(void);          /* "quickprefill-mi355x 0.5 (gfx950)": 0.3 prune_mode became a per-call argument; 0.4 qp_prefill_segment; 0.5 qp_linear_plan_choice */
 int qp_device_cus(const qp_ctx* ctx);
 
 /* Host helper of the overlap producer (no device work): memcpy `bytes` from src to dst (e.g. decoded uint8 frames into a pinned
@@ -301,6 +306,14 @@ int qp_linear_act(qp_ctx* ctx, const void* x, const void* w, const void* bias, i
  * pick can be 2x off.  SYNCHRONISES `stream` (the only entry point that does); `out` is scratch. */
 int qp_linear_tune(qp_ctx* ctx, const void* x, const void* const* weights, int n_weights, const void* bias, int bias_f32, float alpha,
                    void* out, int64_t m, int64_t n, int64_t k, int act, void* workspace, size_t workspace_bytes, void* stream);
+/* The tuner's decision for a problem is per (device, m, n, k, act, bias kind) and PROCESS-wide: the first qp_linear_tune of a problem
+ * times the candidates, every later one — from this or any other context of the same device — adopts that pick without timing, and a
+ * context that meets the problem in qp_linear_act without having tuned it runs the recorded pick too.  (Two stopwatch runs can disagree
+ * on candidates within noise of each other, and a different algorithm is a different fp32 accumulation order: all contexts of a
+ * process compute the same bits.)  qp_linear_plan_choice -> index of the heuristic candidate THIS context runs for the problem
+ * (0 = hipBLASLt's own first pick), -1 if the context has not seen it, < -1 = qp_status; *tuned (optional) = 1 when a stopwatch
+ * decision is on record for the device.  bias_kind: 0 none, 1 bf16, 2 fp32.  Host-side query, no device work. */
+int qp_linear_plan_choice(qp_ctx* ctx, int64_t m, int64_t n, int64_t k, int act, int bias_kind, int* tuned);
 /* out = y * sigmoid(1.702 y) with torch's bf16 rounding steps (hidden_act = quick_gelu). */
 int qp_quick_gelu(qp_ctx* ctx, const void* x, void* out, int64_t n_elems, void* stream);
 

@@ -599,6 +599,163 @@ def gen_vit_towers():
     json.dump(meta, open(os.path.join(OUT, "gv10_vit_towers.json"), "w"))
 
 
+
+# ---------------------------------------------------------------- GV11: the whole chat_lvu_model — frames -> patches -> ViT -> scatter -> group prefill -> tail -> 4 tokens
+# (qwen25_lvu_interleaved.py:733-942 / qwen25_lvu.py:538-761).  Composite oracle: installed transformers' Qwen2-VL / Qwen2.5-VL (vision tower,
+# embed_tokens, get_rope_index, decoder, lm_head; seeded tiny checkpoints) driven group by group the way the reference's loop drives it
+# (:671-717: ids / positions / pixel rows sliced per group, cache carried), with the REFERENCE's post_process_kv_cache hooked after every
+# attention, then the prompt tail without pruning (:737-742) and greedy decode (:744-761).  The checkpoints are NOT stored: the GPU test
+# re-creates them from the same seed with the installed transformers and checks `weights_sha256`; frames from `frames_seed`.
+
+from oracle.pipeline_model import (CLIP_MEAN, CLIP_STD, PIPE_CASES, PIPE_DECODE, PIPE_FRAMES, PIPE_GROUP, PIPE_IDS, PIPE_QUESTION, PIPE_SEED,  # noqa: E402
+                                   build_hf_pipeline_model, state_sha)
+
+
+def patch_rows(frames: np.ndarray) -> tuple:
+    """uint8 [F, 3, H, W] -> (fp32 rows [t*gh*gw, 3*2*14*14], (t, gh, gw)): CLIP normalisation + the (t, h/2, w/2, 2, 2 | C, T, 14, 14) patch order
+    of transformers' Qwen2VLImageProcessor [3P] (what the reference's processor thread produces, qwen25_lvu_interleaved.py:252-271)."""
+    F_, C, H, W = frames.shape
+    t, gh, gw = F_ // 2, H // 14, W // 14
+    x = frames.astype(np.float32) / 255.0
+    x = (x - np.array(CLIP_MEAN, np.float32).reshape(1, 3, 1, 1)) / np.array(CLIP_STD, np.float32).reshape(1, 3, 1, 1)
+    x = x.reshape(t, 2, C, gh // 2, 2, 14, gw // 2, 2, 14)
+    x = x.transpose(0, 3, 6, 4, 7, 2, 1, 5, 8)               # t, hb, wb, hi, wi, C, T, 14, 14
+    return np.ascontiguousarray(x.reshape(t * gh * gw, C * 2 * 14 * 14)), (t, gh, gw)
+
+
+def pipeline_case(ref, family: str, rho: float, dtn: str):
+    from transformers import DynamicCache
+    from tests.test_processor_seam import installed_qwen2vl_processor
+    U, C = ref["utils"], ref["lvu_config"]
+    hf, cfg = build_hf_pipeline_model(family)
+    wsha = state_sha(hf)
+    dtype = getattr(torch, dtn)
+    hf = hf.to(dtype)
+    fr = PIPE_FRAMES
+    frames = np.random.RandomState(fr["seed"]).randint(0, 256, (fr["n"], 3, fr["h"], fr["w"]), dtype=np.uint8)
+    rows, grid = patch_rows(frames)
+    t, gh, gw = grid
+    # the installed image processor agrees with patch_rows on a frame pair made of one image twice (an image IS such a pair to it)
+    from PIL import Image
+    from transformers import Qwen2VLImageProcessorPil
+    ip = Qwen2VLImageProcessorPil()(images=[Image.fromarray(frames[0].transpose(1, 2, 0))], do_resize=False, return_tensors="pt")
+    assert tuple(ip["image_grid_thw"][0].tolist()) == (1, gh, gw)
+    assert np.allclose(ip["pixel_values"].numpy(), patch_rows(np.stack([frames[0], frames[0]]))[0], atol=1e-5)
+    # prompt ids from the INSTALLED Qwen2VLProcessor (chat template + video-pad expansion; qwen25_lvu.py:546-548, 597-604)
+    pr = installed_qwen2vl_processor(grid)
+    messages = [{"role": "user", "content": [{"type": "video", "video": "v.npy"}, {"type": "text", "text": PIPE_QUESTION}]}]
+    text = pr.apply_chat_template(messages, tokenize=False, add_generation_prompt=True)
+    ids = pr(text=[text], videos=[torch.zeros(fr["n"], 3, 28, 28)], return_tensors="pt")["input_ids"]
+    vid = PIPE_IDS["video_token_id"]
+    n_video = t * (gh // 2) * (gw // 2)
+    assert int((ids == vid).sum()) == n_video
+    first = int((ids[0] == vid).nonzero()[0])
+    prefix, tail = first, ids.shape[1] - first - n_video
+    T = ids.shape[1]
+    sample_fps = fr["n"] / (fr["n"] / fr["fps"])
+    mm = (ids == vid).long() * 2                                 # transformers 5.x: text 0 / image 1 / video 2
+    if family == "qwen2.5-vl":
+        extra = dict(second_per_grid_ts=torch.tensor([2.0 / sample_fps]), mm_token_type_ids=mm)
+        pos, delta = hf.model.get_rope_index(ids, mm, None, torch.tensor([[t, gh, gw]]), second_per_grid_ts=extra["second_per_grid_ts"],
+                                             attention_mask=torch.ones_like(ids))
+    else:
+        extra = dict(mm_token_type_ids=mm)
+        pos, delta = hf.model.get_rope_index(ids, mm, None, torch.tensor([[t, gh, gw]]), torch.ones_like(ids))
+    pos = pos[-3:] if pos.shape[0] == 4 else pos                 # (some versions prepend a text-position row)
+    lm = hf.model.language_model
+    rows_t = torch.from_numpy(rows).to(dtype)
+    # group plan (qwen25_lvu.py:623-665): 2 temporal patches per group; group 0 carries the prefix; pixel rows split by frame share
+    gs_t = PIPE_GROUP // 2
+    per_t_tok, per_t_rows = (gh // 2) * (gw // 2), gh * gw
+    groups, tok0, row0 = [], 0, 0
+    for g0 in range(0, t, gs_t):
+        tt = min(gs_t, t - g0)
+        n = tt * per_t_tok + (prefix if g0 == 0 else 0)
+        groups.append((tok0, n, row0, tt))
+        tok0 += n; row0 += tt * per_t_rows
+    lcfg = C.LVUConfig(model_name_or_path="x", top_p=rho if rho < 1.0 else None, top_k_predict_type="key_norms_small")
+    layer_cfgs = [C.LVULayerConfig(layer_idx=i, total_layers=len(lm.layers), lvu_config=lcfg) for i in range(len(lm.layers))]
+    cache = DynamicCache(config=hf.config.get_text_config())
+    trace = []
+
+    def make_hook(i):
+        def hook(mod, args, kwargs, output):
+            lay = cache.layers[i]
+            before = lay.keys.shape[2]
+            with force_stable_argsort():
+                res = U.post_process_kv_cache(kwargs["hidden_states"], None, None, None, None, None, (lay.keys, lay.values), layer_cfgs[i])
+            lay.keys, lay.values = res[5]
+            trace.append((i, before, lay.keys.shape[2]))
+            return output
+        return hook
+    hooks = [l.self_attn.register_forward_hook(make_hook(i), with_kwargs=True) for i, l in enumerate(lm.layers)]
+    vit = hf.model.visual
+    with torch.no_grad():
+        for (s0, n, r0, tt) in groups:
+            gi = ids[:, s0:s0 + n]
+            emb = lm.embed_tokens(gi)
+            v = vit(rows_t[r0:r0 + tt * per_t_rows], grid_thw=torch.tensor([[tt, gh, gw]]))
+            v = v.pooler_output if hasattr(v, "pooler_output") else v
+            v = v[0] if isinstance(v, (tuple, list)) else v
+            emb = emb.masked_scatter((gi == vid)[..., None].expand_as(emb), v.to(emb.dtype))           # qwen25_lvu.py [3P] forward: masked_scatter of the video embeds
+            o = lm(inputs_embeds=emb, position_ids=pos[:, :, s0:s0 + n], past_key_values=cache, use_cache=True, cache_position=torch.arange(n) + s0)
+        lcfg.enable = False                                          # qwen25_lvu.py:737-738: the prompt tail is not pruned
+        s0 = T - tail
+        o = lm(inputs_embeds=lm.embed_tokens(ids[:, s0:]), position_ids=pos[:, :, s0:], past_key_values=cache, use_cache=True,
+               cache_position=torch.arange(tail) + s0)
+        cache_len = [int(cache.layers[i].keys.shape[2]) for i in range(len(lm.layers))]
+        logits = hf.lm_head(o.last_hidden_state[:, -1]).float()[0]
+        step_logits, toks = [logits.numpy()], []
+        tok = int(torch.argmax(logits))
+        for i in range(PIPE_DECODE - 1):
+            toks.append(tok)
+            pid = torch.full((3, 1, 1), T + int(delta[0, 0]) + i, dtype=torch.long)
+            o = lm(inputs_embeds=lm.embed_tokens(torch.tensor([[tok]])), position_ids=pid, past_key_values=cache, use_cache=True,
+                   cache_position=torch.tensor([T + i]))
+            lg = hf.lm_head(o.last_hidden_state[:, -1]).float()[0]
+            step_logits.append(lg.numpy())
+            tok = int(torch.argmax(lg))
+        toks.append(tok)
+    for h in hooks:
+        h.remove()
+    whole = None
+    if rho >= 1.0 and dtn == "float32":
+        # pins the composite (group slicing, positions, scatter, cache carry) to ONE forward of the installed model over the whole prompt
+        with torch.no_grad():
+            out = hf(input_ids=ids, pixel_values_videos=rows_t, video_grid_thw=torch.tensor([[t, gh, gw]]), attention_mask=torch.ones_like(ids), **extra)
+        whole = float((out.logits[0, -1].float() - logits).abs().max())
+        assert whole < 2e-4, whole
+    meta = dict(family=family, rho=rho, dtype=dtn, weights_sha256=wsha, prefix_ids=ids[0, :prefix].tolist(), tail_ids=ids[0, T - tail:].tolist(),
+                n_video=n_video, grid=[t, gh, gw], group_tokens=[g[1] for g in groups], tail_len=tail, rope_delta=int(delta[0, 0]),
+                cache_len=cache_len, tokens=toks, trace=trace, composite_vs_whole_forward_max_abs=whole,
+                margins=[float(np.sort(l)[-1] - np.sort(l)[-2]) for l in step_logits], max_abs_logit=float(np.abs(step_logits[0]).max()))
+    return meta, np.stack(step_logits)
+
+
+def gen_e2e_pipeline(ref):
+    """GV11.  fp32 run = the reference numbers; bf16 run of the same composite = how far bf16 arithmetic alone moves them (the GPU test's
+    tolerance is stated against that distance)."""
+    out, metas = {}, []
+    fr = PIPE_FRAMES
+    frames = np.random.RandomState(fr["seed"]).randint(0, 256, (fr["n"], 3, fr["h"], fr["w"]), dtype=np.uint8)
+    for family, rho in PIPE_CASES:
+        name = f"{family}_rho{rho}"
+        m32, l32 = pipeline_case(ref, family, rho, "float32")
+        m16, l16 = pipeline_case(ref, family, rho, "bfloat16")
+        m32["bf16_oracle"] = dict(tokens=m16["tokens"], cache_len=m16["cache_len"], first_logits_max_abs_diff=float(np.abs(l16[0] - l32[0]).max()),
+                                  first_logits_cosine=float(np.dot(l16[0], l32[0]) / (np.linalg.norm(l16[0]) * np.linalg.norm(l32[0]))))
+        m32["name"] = name
+        out[f"{name}_logits"] = l32.astype(np.float32)
+        out[f"{name}_logits_bf16_oracle"] = l16.astype(np.float32)
+        metas.append(m32)
+        print(name, "tokens", m32["tokens"], "bf16 oracle tokens", m16["tokens"], "cache", m32["cache_len"], "margins", [round(x, 3) for x in m32["margins"]],
+              "bf16-vs-fp32 first logits", round(m32["bf16_oracle"]["first_logits_max_abs_diff"], 4), "whole-forward", m32["composite_vs_whole_forward_max_abs"])
+    rec = dict(frames=dict(fr, sha256=sha(frames)), question=PIPE_QUESTION, video_group_size=PIPE_GROUP, num_frames=fr["n"], decode_steps=PIPE_DECODE,
+               head_scale=16.0, init_seed=PIPE_SEED, cases=metas)
+    np.savez_compressed(os.path.join(OUT, "gv11_e2e_pipeline.npz"), **out)
+    json.dump(rec, open(os.path.join(OUT, "gv11_e2e_pipeline.json"), "w"), indent=1)
+
+
 # ---------------------------------------------------------------- GV4: frame count + frame size from the video entry
 NFRAMES_ELES = [{}, {"fps": 1}, {"fps": 2}, {"fps": 0.5}, {"fps": 4.0}, {"fps": 2, "min_frames": 16}, {"fps": 2, "max_frames": 128},
                 {"fps": 2, "min_frames": 7, "max_frames": 65}, {"fps": 1, "max_frames": 768}, {"nframes": 64}, {"nframes": 7}, {"nframes": 5},
@@ -712,7 +869,7 @@ def gen_video_plan():
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     ref = load_reference()
-    which = sys.argv[1:] or ["select", "modes", "effk", "compact", "e2e", "e2e_modes", "e2e_decode", "rope", "query", "vit", "video_plan"]
+    which = sys.argv[1:] or ["select", "modes", "effk", "compact", "e2e", "e2e_modes", "e2e_decode", "rope", "query", "vit", "video_plan", "pipeline"]
     if "select" in which: gen_select(ref)
     if "modes" in which: gen_select_modes(ref)
     if "effk" in which: gen_effective_k(ref)
@@ -724,4 +881,5 @@ if __name__ == "__main__":
     if "query" in which: gen_query_scores(ref)
     if "vit" in which: gen_vit_towers()
     if "video_plan" in which: gen_video_plan()
+    if "pipeline" in which: gen_e2e_pipeline(ref)
     if "deep" in which: gen_e2e_deep(ref)       # ~20 min of CPU and 40 GB of RAM: not in the default list

@@ -1,6 +1,7 @@
 // C ABI of libquickprefill.so (include/quickprefill.h): argument validation + launches.  No torch types,
 // no device allocation, no synchronisation: everything is enqueued on the caller's stream.
 #include "qp_common.h"
+#include <string>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -25,15 +26,45 @@ int qp_check_launch(const char* what) {
   return QP_OK;
 }
 
+qp_dev_switches& qp_dev() {
+  static qp_dev_switches* sw = [] {
+    qp_dev_switches* d = new qp_dev_switches;
+    auto geti = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
+    d->attn_variant = geti("QP_ATTN_VARIANT", 0);
+    d->attn_force_split = geti("QP_ATTN_FORCE_SPLIT", 0);
+    d->s6_prio = geti("QP_S6_PRIO", 0) & 3;
+    d->s6_early_out = geti("QP_S6_EARLY_OUT", 3) & 3;
+    { const char* e = getenv("QP_DECODE_ATTN"); d->decode_attn_valu = (e && e[0] == 'v') ? 1 : 0; }
+    d->attn_debug = getenv("QP_ATTN_DEBUG") != nullptr ? 1 : 0;
+    return d;
+  }();
+  return *sw;
+}
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 extern "C" {
 
 const char* qp_last_error(void) { return g_err; }
-const char* qp_version(void) { return "quickprefill-mi355x 0.4 (gfx950)"; }
+const char* qp_version(void) { return "quickprefill-mi355x 0.5 (gfx950)"; }
+
+int qp_dev_switch(const char* name, int value) {
+  QP_REQUIRE(name != nullptr, QP_ERR_INVALID, "qp_dev_switch: name is NULL");
+  qp_dev_switches& d = qp_dev();
+  const std::string k(name);
+  if (k == "attn_variant") d.attn_variant = value;
+  else if (k == "attn_force_split") d.attn_force_split = value;
+  else if (k == "s6_prio") d.s6_prio = value & 3;
+  else if (k == "s6_early_out") d.s6_early_out = value & 3;
+  else if (k == "decode_attn_valu") d.decode_attn_valu = value ? 1 : 0;
+  else if (k == "attn_debug") d.attn_debug = value ? 1 : 0;
+  else return qp_fail(QP_ERR_INVALID, "qp_dev_switch: unknown switch '%s'", name);
+  return QP_OK;
+}
 
 int qp_create(qp_ctx** out, int device) {
   QP_REQUIRE(out != nullptr, QP_ERR_INVALID, "qp_create: out is NULL");
+  (void)qp_dev();                                          // developer switches: environment read once, here
   int count = 0;
   hipError_t e = hipGetDeviceCount(&count);
   if (e != hipSuccess || count <= 0) return qp_fail(QP_ERR_HIP, "qp_create: no HIP device (%s)", hipGetErrorString(e));
@@ -549,6 +580,14 @@ int qp_linear_tune(qp_ctx* ctx, const void* x, const void* const* weights, int n
   for (int i = 0; i < n_weights; ++i) QP_REQUIRE(weights[i] && aligned16(weights[i]), QP_ERR_INVALID, "qp_linear_tune: weight %d", i);
   return qp_launch_linear_tune(ctx, x, weights, n_weights, bias, bias_f32, alpha, out, m, n, k, act, workspace, workspace_bytes,
                                (hipStream_t)stream, nullptr);
+}
+
+int qp_linear_plan_choice(qp_ctx* ctx, int64_t m, int64_t n, int64_t k, int act, int bias_kind, int* tuned) {
+  if (!ctx || m <= 0 || n <= 0 || k <= 0 || act < 0 || act > 1 || bias_kind < 0 || bias_kind > 2) {
+    (void)qp_fail(QP_ERR_INVALID, "qp_linear_plan_choice: m=%lld n=%lld k=%lld act=%d bias_kind=%d", (long long)m, (long long)n, (long long)k, act, bias_kind);
+    return QP_ERR_INVALID;
+  }
+  return qp_linear_plan_choice_impl(ctx, m, n, k, act, bias_kind, tuned);
 }
 
 // ---- decode step (qp_decode.hip) ------------------------------------------------------------------------------------

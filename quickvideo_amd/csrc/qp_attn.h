@@ -32,6 +32,7 @@ struct AttnParams {
   // query sub-range (group-token parallel ranks): q/out hold rows [q_row0, q_row0+nq) of the group's n new tokens
   int q_row0; int nq;
   int qb_rows;                  // query rows per workgroup / work item (128 or 256); partials hold partial_floats(qb_rows) floats
+  int variant;                  // host side only: the developer switch attn_variant this launch was planned under
   int prio_mode;                // s6, 8-wave form: 1 = s_setprio 1 for waves 4-7 (the younger half), 2 = for waves 0-3, 0 = none
 };
 

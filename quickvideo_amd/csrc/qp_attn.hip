@@ -494,7 +494,7 @@ double simulate_makespan(int64_t nq, int64_t Peff, int group, int nqb, int rows,
   return makespan;
 }
 
-AttnPlan plan_items(int64_t n, int64_t P, int hq, int hkv, int cus, int split_mode, int wg_per_cu = 3, int qb_rows = kQB) {
+AttnPlan plan_items(int64_t n, int64_t P, int hq, int hkv, int cus, int split_mode, int wg_per_cu, int qb_rows, int force_split) {
   AttnPlan a;
   const int nqb = (int)((n + qb_rows - 1) / qb_rows), group = hq / hkv;
   a.items = nqb * group; a.rows = qb_rows;
@@ -507,8 +507,8 @@ AttnPlan plan_items(int64_t n, int64_t P, int hq, int hkv, int cus, int split_mo
   const double tstep = qb_rows == 256 ? 0.95 : 1.0;              // measured: an 8-wave tile step is ~5 % shorter (half the DMA pieces per wave)
   a.cost = simulate_makespan(n, P, group, nqb, qb_rows, slots, a.items, 1, c0) * tstep;
   if (split_mode == 0) return a;
-  if (const char* fs = getenv("QP_ATTN_FORCE_SPLIT")) {          // experiment: EVERY item cut into ns kv ranges.  With 2 XCDs per kv head and
-    const int ns = atoi(fs);                                       // ns = 2, split s of every item runs on XCD parity s (item index = 2*slot +
+  {                                                                // experiment: EVERY item cut into ns kv ranges.  With 2 XCDs per kv head and
+    const int ns = force_split;                                    // ns = 2, split s of every item runs on XCD parity s (item index = 2*slot +
     if (ns >= 2 && ns <= kMaxSplit) {                              // xcd%2), so each XCD streams only half of the K/V rows: HBM reads halve.
       a.n_whole = 0; a.nsplit = ns;
       a.cost = (simulate_makespan(n, P, group, nqb, qb_rows, slots, 0, ns, c0) + 3.0) * tstep;
@@ -532,16 +532,17 @@ AttnPlan plan_items(int64_t n, int64_t P, int hq, int hkv, int cus, int split_mo
 
 // cached plans: same (shape, prefix) for every layer of a group
 AttnPlan plan_cached(int64_t n, int64_t P, int hq, int hkv, int cus, int split_mode, int wg_per_cu, int qb_rows) {
-  typedef std::tuple<int64_t, int64_t, int, int, int, int, int, int> Key;
+  typedef std::tuple<int64_t, int64_t, int, int, int, int, int, int, int> Key;
   static std::map<Key, AttnPlan> cache;
   static std::mutex mu;
-  const Key k(n, P, hq, hkv, cus, split_mode, wg_per_cu, qb_rows);
+  const int force_split = qp_dev().attn_force_split.load(std::memory_order_relaxed);
+  const Key k(n, P, hq, hkv, cus, split_mode, wg_per_cu, qb_rows, force_split);
   std::lock_guard<std::mutex> lock(mu);
   auto it = cache.find(k);
   if (it != cache.end()) return it->second;
   if (cache.size() > 4096) cache.clear();
-  const AttnPlan a = plan_items(n, P, hq, hkv, cus, split_mode, wg_per_cu, qb_rows);
-  if (getenv("QP_ATTN_DEBUG"))
+  const AttnPlan a = plan_items(n, P, hq, hkv, cus, split_mode, wg_per_cu, qb_rows, force_split);
+  if (qp_dev().attn_debug.load(std::memory_order_relaxed))
     fprintf(stderr, "[qp_attn plan] n=%lld P=%lld hq=%d hkv=%d wg/cu=%d rows=%d: items=%d n_whole=%d nsplit=%d cost=%.1f\n", (long long)n,
             (long long)P, hq, hkv, wg_per_cu, qb_rows, a.items, a.n_whole, a.nsplit, a.cost);
   cache[k] = a;
@@ -573,11 +574,11 @@ int qp_launch_prefill_attn(const qp_ctx* ctx, const void* q, const void* k_prefi
   p.nqb = (int)((nq + kQB - 1) / kQB); p.hkv = hkv; p.ws = (float*)workspace;
   p.items = p.nqb * p.group; p.n_whole = p.items; p.nsplit = 1;
   p.heads_per_seq = hkv; p.seq_stride16 = 0; p.kv_row_bytes = 256; p.cu_seqlens = nullptr;
-  { const char* pm = getenv("QP_S6_PRIO"); p.prio_mode = pm ? atoi(pm) & 3 : 0; }
-  { const char* eo = getenv("QP_S6_EARLY_OUT"); p.prio_mode |= ((eo ? atoi(eo) : 3) & 3) << 2; }   // A/B switch, see qp_attn_s6.hip
+  const qp_dev_switches& dev = qp_dev();                         // developer A/B switches (qp_dev_switch; tools/bench_attn.py): atomics, no getenv here
+  p.prio_mode = (dev.s6_prio.load(std::memory_order_relaxed) & 3) | ((dev.s6_early_out.load(std::memory_order_relaxed) & 3) << 2);   // see qp_attn_s6.hip
   p.q_row0 = (int)q_row0; p.nq = (int)nq; p.qb_rows = kQB;
-  const char* var = getenv("QP_ATTN_VARIANT");        // developer A/B switch (tools/bench_attn.py); default = production kernel
-  const int variant = var ? atoi(var) : 0;
+  const int variant = dev.attn_variant.load(std::memory_order_relaxed);   // default 0 = production kernel
+  p.variant = variant;
   const bool big = prefix_len * 256 >= (1ll << 31) || n * 256 >= (1ll << 31);
   if ((variant == 1 || big) && !(q_row0 == 0 && nq == n))
     return qp_fail(QP_ERR_UNSUPPORTED, "qp_prefill_attn: query sub-ranges need K/V segments below 2 GiB per head");
@@ -651,8 +652,8 @@ int qp_launch_vit_attn(const qp_ctx* ctx, const void* qkv, int64_t n_seq, int64_
   p.nqb = (int)((S + kQB - 1) / kQB); p.hkv = hk; p.ws = nullptr;
   p.heads_per_seq = heads; p.seq_stride16 = S * row16; p.kv_row_bytes = row16 * 16; p.cu_seqlens = cu_seqlens; p.prio_mode = 0;
   p.items = p.nqb; p.n_whole = p.nqb; p.nsplit = 1; p.q_row0 = 0; p.nq = (int)S; p.qb_rows = kQB;
-  const char* var = getenv("QP_ATTN_VARIANT");        // 3: plain 2-D grid (A/B of the XCD mapping)
-  if (var && atoi(var) == 3) attn_fwd_kernel_s4<false, D, true><<<dim3((unsigned)p.nqb, (unsigned)hk), 256, 0, s>>>(p);
+  p.variant = qp_dev().attn_variant.load(std::memory_order_relaxed);      // 3: plain 2-D grid (A/B of the XCD mapping)
+  if (p.variant == 3) attn_fwd_kernel_s4<false, D, true><<<dim3((unsigned)p.nqb, (unsigned)hk), 256, 0, s>>>(p);
   else attn_fwd_kernel_s4<true, D, true><<<dim3((unsigned)(((hk + 7) / 8) * 8 * p.nqb)), 256, 0, s>>>(p);
   return qp_check_launch("vit_attn");
 }

@@ -21,6 +21,20 @@ struct qp_ctx {
 };
 void qp_lt_destroy(void* lt_state);
 
+// Developer A/B switches of the launch paths.  NOT read from the environment at launch time (rounds 1-4 called getenv() in every
+// attention launch): the table is filled ONCE, when the library is first used, from the QP_* variables named below, and changed at run
+// time only through qp_dev_switch() (include/quickprefill.h) — the launch paths read relaxed atomics.
+#include <atomic>
+struct qp_dev_switches {
+  std::atomic<int> attn_variant{0};        // QP_ATTN_VARIANT: 0 production; 1 v1, 2 no kv split, 3 no XCD map, 4 s4, 7/8 4-/8-wave s6 (9, 10: EXPERIMENTS builds)
+  std::atomic<int> attn_force_split{0};    // QP_ATTN_FORCE_SPLIT: every work item cut into this many kv ranges (0 = planner's choice)
+  std::atomic<int> s6_prio{0};             // QP_S6_PRIO
+  std::atomic<int> s6_early_out{3};        // QP_S6_EARLY_OUT: bit 0 rows past the last query, bit 1 causal diagonal
+  std::atomic<int> decode_attn_valu{0};    // QP_DECODE_ATTN=valu: first (VALU) form of the single-query decode attention
+  std::atomic<int> attn_debug{0};          // QP_ATTN_DEBUG: print every new attention plan
+};
+qp_dev_switches& qp_dev();
+
 // prune_mode argument of the seam-1 entry points (include/quickprefill.h: enum qp_prune_mode): bit 0 = keep the k LARGEST norms,
 // bit 1 = score the VALUE rows
 static inline int qp_mode_largest(int prune_mode) { return prune_mode & 1; }
@@ -61,7 +75,6 @@ __device__ __forceinline__ float sqrt_rn_f32(float s) {
 
 // Kernels that need more than 64 KB of dynamic LDS opt in with hipFuncSetAttribute — per DEVICE (the attribute lives in the
 // per-device function object), so the guard is a bit per device ordinal, not one flag per process.
-#include <atomic>
 static inline int qp_opt_in_lds(std::atomic<unsigned long long>& done, const void* fn, int bytes, const char* what) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) dev = 0;
@@ -133,5 +146,6 @@ int qp_launch_prune_tail_inplace(const uint16_t* norm_keys, int64_t n, int64_t k
                                  int64_t past_len, int hkv, int32_t* kept, int* sync_words, hipStream_t s);
 int qp_launch_linear_tune(qp_ctx* ctx, const void* x, const void* const* ws_list, int n_ws, const void* bias, int bias_f32, float alpha, void* out,
                           int64_t m, int64_t n, int64_t k, int act, void* workspace, size_t workspace_bytes, hipStream_t s, int* chosen);
+int qp_linear_plan_choice_impl(qp_ctx* ctx, int64_t m, int64_t n, int64_t k, int act, int bias_kind, int* tuned);
 int qp_launch_linear_act(qp_ctx* ctx, const void* x, const void* w, const void* bias, int bias_f32, float alpha, void* out, int64_t m, int64_t n,
                          int64_t k, int act, void* workspace, size_t workspace_bytes, hipStream_t s);

@@ -621,7 +621,7 @@ int qp_launch_decode_attn(const qp_ctx* ctx, const void* q, const void* k_cache,
   const dim3 grid((unsigned)ns, (unsigned)hkv);
   const uint4* Q = (const uint4*)q; const uint4* K = (const uint4*)k_cache; const uint4* V = (const uint4*)v_cache;
   float* ws = (float*)workspace;
-  static const bool use_valu = [] { const char* e = getenv("QP_DECODE_ATTN"); return e && e[0] == 'v'; }();   // developer A/B switch
+  const bool use_valu = qp_dev().decode_attn_valu.load(std::memory_order_relaxed) != 0;   // developer A/B switch (qp_dev_switch)
   if (!use_valu && G <= 8) {
     decode_attn_mfma_kernel<false><<<grid, 256, 0, s>>>(Q, nullptr, nullptr, (uint4*)k_cache, (uint4*)v_cache, head_stride / 8, state,
                                                         hq, hkv, c_log2, ws);

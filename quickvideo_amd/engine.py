@@ -32,6 +32,13 @@ from .weights import DecoderWeights
 _TUNE_FAILURES: dict = {}       # (projection, rows, weight shape, bias) -> message: every shape hipBLASLt plan selection failed for
 
 
+class _NoNativePlan(Exception):
+    """qp_linear_tune found no usable hipBLASLt candidate for one projection of the one-call path at this row count."""
+
+
+_NO_NATIVE = "no-native-plan"
+
+
 def _tune_failed(shape_key, exc) -> None:
     """qp_linear_tune threw for this projection shape: the engine stays on torch.mm there (a correct but possibly slower GEMM — a
     broken plan path would otherwise cost ~5 % of the pass and nobody would know).  Logged once per shape on stderr and kept in
@@ -431,7 +438,7 @@ class QuickPrefillEngine:
             pos = pos.index_select(1, row_idx.long())
             n = pos.shape[1]
         assert embeds.shape[0] == n
-        if self._native_segment_ok(n, prune, row_idx):
+        if self._native_segment_ok(n, prune, row_idx) and self._native_gemm_plan(n) is not None:
             return self._forward_segment_native(embeds, pos, prune, video_group)
         L = self.n_layers_total                      # effective_k's decay uses the GLOBAL layer index / count
         cos, sin = ops.mrope_table(pos.contiguous(), s.mrope_section, s.rope_theta, D)
@@ -542,7 +549,15 @@ class QuickPrefillEngine:
         key = ("native", n, self.hq, self.hkv, self.li, self.spec.hidden)
         plan = self._gemm_plans.get(key)
         if plan is not None:
-            return plan
+            return None if plan is _NO_NATIVE else plan
+        try:
+            plan = self._build_native_gemm_plan(n)
+        except _NoNativePlan:
+            plan = _NO_NATIVE                         # remembered: segments of n rows take the per-operator loop (torch.mm where the tuner failed)
+        self._gemm_plans[key] = plan
+        return None if plan is _NO_NATIVE else plan
+
+    def _build_native_gemm_plan(self, n: int):
         lws, li, d = self.w.layers, self.li, self.spec.hidden
         x, act, att = self.b_x[:n], self.b_act[:n], self.b_att[:n].view(n, self.hq * self.D)
 
@@ -552,9 +567,15 @@ class QuickPrefillEngine:
                 xb, ob = xin[r0:r1], out[r0:r1]
                 w0 = wsel(lws[0])
                 lk = ("lt", r1 - r0, w0.shape[0], w0.shape[1], bias is not None)  # shared with _lt_linear: one tuning per GEMM shape
-                if lk not in self._lt_tuned:
-                    self.ops.linear_tune(xb, [wsel(lw) for lw in lws], bias, ob, self.ops.ACT_NONE)
-                    self._lt_tuned[lk] = True
+                if self._lt_tuned.get(lk) is None:
+                    try:
+                        self.ops.linear_tune(xb, [wsel(lw) for lw in lws], bias, ob, self.ops.ACT_NONE)
+                        self._lt_tuned[lk] = True
+                    except Exception as e:            # no usable hipBLASLt candidate for this shape: this row count stays on the per-operator loop
+                        self._lt_tuned[lk] = False
+                        _tune_failed(lk, e)
+                if self._lt_tuned[lk] is not True:
+                    raise _NoNativePlan(lk)
                 self.ops.linear_act(xb, wsel(lws[0]), bias, ob, self.ops.ACT_NONE)
 
         def best_split(name, xin, wsel, out, bias):
@@ -583,7 +604,6 @@ class QuickPrefillEngine:
         if os.environ.get("QP_ENGINE_DEBUG"):
             print(f"[engine] one-call segment path, n={n}: row splits qkv/o/gate_up/down = {s_qkv}/{s_o}/{s_gu}/{s_dn}, gate_up as "
                   f"{'two GEMMs' if two else 'one GEMM'}", flush=True)
-        self._gemm_plans[key] = plan
         return plan
 
     def _forward_segment_native(self, embeds: torch.Tensor, pos: torch.Tensor, prune: bool, video_group: bool) -> torch.Tensor:

@@ -101,6 +101,8 @@ SIGNATURES = {
     "qp_quick_gelu": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "qp_linear_tune": (_i32, [_vp, _vp, _c.POINTER(_vp), _i32, _vp, _i32, _f32, _vp, _i64, _i64, _i64, _i32, _vp, _sz, _vp]),
     "qp_linear_act": (_i32, [_vp, _vp, _vp, _vp, _i32, _f32, _vp, _i64, _i64, _i64, _i32, _vp, _sz, _vp]),
+    "qp_linear_plan_choice": (_i32, [_vp, _i64, _i64, _i64, _i32, _i32, _c.POINTER(_i32)]),
+    "qp_dev_switch": (_i32, [_c.c_char_p, _i32]),
     "qp_add_layernorm": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
 }
 
@@ -151,6 +153,9 @@ class QuickPrefillOps:
             raise QuickPrefillUnavailable("no HIP device visible to torch: the QuickPrefill engine needs an MI355X (gfx950); "
                                           "there is no CPU fallback")
         self.lib = load_library(hold_gil=os.environ.get("QP_CTYPES_RELEASE_GIL") != "1")
+        # entry points that SYNCHRONISE the stream (qp_linear_tune: a timing loop, hundreds of ms per shape) go through a second,
+        # lock-releasing handle of the same .so: the producer thread, RCCL/gloo progress and Ctrl-C keep running meanwhile
+        self.lib_blocking = load_library(hold_gil=False)
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         h = _vp()
         self._check(self.lib.qp_create(ctypes.byref(h), self.device.index or 0))
@@ -435,8 +440,23 @@ class QuickPrefillOps:
         ws = self._lt_workspace()
         arr = (_vp * len(weights))(*[w.data_ptr() for w in weights])
         f32 = 1 if (bias is not None and bias.dtype == torch.float32) else 0
-        self._check(self.lib.qp_linear_tune(self.ctx, x.data_ptr(), arr, len(weights), _ptr(bias), f32, float(alpha), out.data_ptr(), m, n, k,
-                                            act, ws.data_ptr(), ws.numel(), self._stream()))
+        self._check(self.lib_blocking.qp_linear_tune(self.ctx, x.data_ptr(), arr, len(weights), _ptr(bias), f32, float(alpha), out.data_ptr(), m, n, k,
+                                                     act, ws.data_ptr(), ws.numel(), self._stream()))
+
+    def linear_plan_choice(self, m, n, k, act=0, bias=None):
+        """-> (index of the hipBLASLt heuristic candidate THIS context runs for the problem, or -1 if it has not met it;
+        whether the process holds a stopwatch decision for it on this device).  bias: None | a bf16/fp32 bias tensor."""
+        kind = 0 if bias is None else (2 if bias.dtype == torch.float32 else 1)
+        tuned = _i32(0)
+        rc = self.lib.qp_linear_plan_choice(self.ctx, m, n, k, act, kind, ctypes.byref(tuned))
+        if rc < -1:
+            self._check(rc)
+        return rc, bool(tuned.value)
+
+    def dev_switch(self, name: str, value: int):
+        """Developer A/B switch of the launch paths (include/quickprefill.h: qp_dev_switch) — process-wide; the library does not read the
+        environment at launch time."""
+        self._check(self.lib.qp_dev_switch(name.encode(), int(value)))
 
     def quick_gelu(self, x, out):
         self._check(self.lib.qp_quick_gelu(self.ctx, x.data_ptr(), out.data_ptr(), x.numel(), self._stream()))

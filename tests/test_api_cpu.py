@@ -834,8 +834,9 @@ def test_qwen_vl_end_to_end_equals_hf_forward(tmp_path, family, proc):
     ids = torch.tensor([list(P["prompt"].prefix_ids) + [300] * n_video + list(P["prompt"].tail_ids)])
     rows, grid = patchify_frames(frames[torch.from_numpy(P["idx"])], m.vision.spec, torch.float32)
     sample_fps = P["nframes"] / (len(rd) / rd.get_fps())
-    extra = (dict(second_per_grid_ts=torch.tensor([2.0 / sample_fps])) if family == "qwen2.5-vl"
-             else dict(mm_token_type_ids=(ids == 300).long() * 2))          # transformers 5.x Qwen2-VL: text 0 / image 1 / video 2
+    extra = dict(mm_token_type_ids=(ids == 300).long() * 2)               # transformers 5.x: text 0 / image 1 / video 2 (both families)
+    if family == "qwen2.5-vl":
+        extra["second_per_grid_ts"] = torch.tensor([2.0 / sample_fps])
     with torch.no_grad():
         out = hf(input_ids=ids, pixel_values_videos=rows, video_grid_thw=torch.tensor([list(grid)]), attention_mask=torch.ones_like(ids), **extra)
     ref, got = out.logits[0, -1].float(), cap["logits"].float()

@@ -107,9 +107,7 @@ def test_prefill_attn_random_shapes(ops, n, P, heads, staged, sub, sigma, seed, 
     kc = torch.full((hkv, cap, D), float("nan"), dtype=torch.bfloat16, device="cuda"); vc = torch.full_like(kc, float("nan"))
     kc[:, :P] = k[:, :P].cuda(); vc[:, :P] = v[:, :P].cuda()
     out = torch.empty(nq, hq, D, dtype=torch.bfloat16, device="cuda")
-    old = os.environ.pop("QP_ATTN_VARIANT", None)
-    if variant:
-        os.environ["QP_ATTN_VARIANT"] = variant
+    ops.dev_switch("attn_variant", int(variant) if variant else 0)
     try:
         if staged:
             kn, vn = k[:, P:].contiguous().cuda(), v[:, P:].contiguous().cuda()
@@ -120,9 +118,7 @@ def test_prefill_attn_random_shapes(ops, n, P, heads, staged, sub, sigma, seed, 
                              q_row0=q0, nq=nq)
         torch.cuda.synchronize()
     finally:
-        os.environ.pop("QP_ATTN_VARIANT", None)
-        if old is not None:
-            os.environ["QP_ATTN_VARIANT"] = old
+        ops.dev_switch("attn_variant", 0)
     got, want = out.float().cpu(), ref[q0:q0 + nq]
     assert torch.isfinite(got).all()
     err = (got - want).abs()

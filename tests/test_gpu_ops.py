@@ -643,11 +643,11 @@ def test_prefill_attn_full_size_properties(ops, n, P, hq, hkv):
     v = torch.randn(hkv, P + n, D, generator=g, device="cuda").to(torch.bfloat16)
     run = lambda vv, out: ops.prefill_attn(q, k, vv, (P + n) * D, P, k[:, P:], vv[:, P:], (P + n) * D, n, hq, hkv, D, D ** -0.5, out)
     out = torch.empty(n, hq, D, dtype=torch.bfloat16, device="cuda"); run(v, out)
-    os.environ["QP_ATTN_VARIANT"] = "1"
+    ops.dev_switch("attn_variant", 1)
     try:
         out1 = torch.empty_like(out); run(v, out1)
     finally:
-        del os.environ["QP_ATTN_VARIANT"]
+        ops.dev_switch("attn_variant", 0)
     torch.cuda.synchronize()
     assert torch.isfinite(out.float()).all()
     assert (out.float() - out1.float()).abs().max().item() <= 8e-3          # two independent kernels, bf16 outputs |o| < ~1
@@ -773,34 +773,34 @@ def test_prefill_attn_query_subranges(ops, n, P, hq, hkv, parts):
         ops.prefill_attn(q[:10].contiguous(), k, v, (P + n) * D, P, k[:, P:], v[:, P:], (P + n) * D, n, hq, hkv, D, 1.0, full, q_row0=n - 5, nq=10)
 
 
-def test_attention_experiments_are_not_in_the_product_library(ops, monkeypatch):
+def test_attention_experiments_are_not_in_the_product_library(ops, dev_switch):
     """QP_ATTN_VARIANT 9 (staggered s6) and 10 (s7) measured slower and are compiled only by `make EXPERIMENTS=1`: the
     product library refuses them loudly instead of carrying dead kernels."""
     from quickvideo_amd.native import QuickPrefillError
     q = torch.zeros(64, 2, D, dtype=torch.bfloat16, device="cuda"); k = torch.zeros(1, 64, D, dtype=torch.bfloat16, device="cuda")
     for variant in ("9", "10"):
-        monkeypatch.setenv("QP_ATTN_VARIANT", variant)
+        dev_switch("attn_variant", int(variant))
         with pytest.raises(QuickPrefillError, match="EXPERIMENTS=1"):
             ops.prefill_attn(q, None, None, 64 * D, 0, k, k, 64 * D, 64, 2, 1, D, 1.0, torch.empty_like(q))
 
 
 @pytest.mark.parametrize("split", [None, "2"])
-def test_prefill_attn_early_out_is_bit_identical(ops, monkeypatch, split):
+def test_prefill_attn_early_out_is_bit_identical(ops, dev_switch, split):
     """The per-wave early-out of the production kernel (waves stop computing after their last visible key tile and only keep the tile
     DMA + step barrier going; QP_S6_EARLY_OUT, default 3) must not change a single bit against the full walk (=0): ragged last
     blocks in both workgroup forms, query sub-ranges (q_row0 > 0: group-token parallel ranks, the query-score mode's second launch),
     and with every item forced into two KV ranges (QP_ATTN_FORCE_SPLIT: the partial path, where a range may end before the diagonal)."""
     if split:
-        monkeypatch.setenv("QP_ATTN_FORCE_SPLIT", split)
+        dev_switch("attn_force_split", int(split))
     off = 0 if split is None else 1                      # shapes no other test plans: the forced split is part of the cached plan
     cases = [(2240 + off, 5003, 28, 4, 0, None, "8"), (2240 + off, 5003, 28, 4, 0, None, "7"), (301 + off, 0, 4, 2, 0, None, None),
              (1111 + off, 777, 8, 1, 0, None, None), (1500 + off, 2051, 8, 2, 640, 500, None), (903 + off, 4097, 4, 4, 129, 774, "8"),
              (700 + off, 0, 6, 2, 650, 50, None)]
     for (n, P, hq, hkv, q0, nq, variant) in cases:
         if variant:
-            monkeypatch.setenv("QP_ATTN_VARIANT", variant)
+            dev_switch("attn_variant", int(variant))
         else:
-            monkeypatch.delenv("QP_ATTN_VARIANT", raising=False)
+            dev_switch("attn_variant", 0)
         g = torch.Generator(device="cuda"); g.manual_seed(n * 3 + P)
         nq_ = n if nq is None else nq
         q = torch.randn(nq_, hq, D, generator=g, device="cuda").to(torch.bfloat16)
@@ -808,7 +808,7 @@ def test_prefill_attn_early_out_is_bit_identical(ops, monkeypatch, split):
         v = torch.randn(hkv, P + n, D, generator=g, device="cuda").to(torch.bfloat16)
         outs = []
         for eo in ("0", "3"):
-            monkeypatch.setenv("QP_S6_EARLY_OUT", eo)
+            dev_switch("s6_early_out", int(eo))
             o = torch.full((nq_, hq, D), 7.0, dtype=torch.bfloat16, device="cuda")
             ops.prefill_attn(q, k, v, (P + n) * D, P, k[:, P:], v[:, P:], (P + n) * D, n, hq, hkv, D, D ** -0.5, o, q_row0=q0, nq=nq_)
             torch.cuda.synchronize()
@@ -818,11 +818,11 @@ def test_prefill_attn_early_out_is_bit_identical(ops, monkeypatch, split):
 
 
 @pytest.mark.parametrize("variant", ["4", "7", "8", "2", "3"])
-def test_prefill_attn_every_kernel_form(ops, variant, monkeypatch):
+def test_prefill_attn_every_kernel_form(ops, variant, dev_switch):
     """The launch picks a kernel form per shape (s6 with 4- or 8-wave workgroups, planner-chosen kv-split); force each form
     (QP_ATTN_VARIANT: 4 = s4, 7 / 8 = s6 4- / 8-wave, 2 = no kv split, 3 = plain 2-D grid) over ragged sizes, prefix lengths around the tile size,
     single-tile and sub-range launches, and the rescale branch."""
-    monkeypatch.setenv("QP_ATTN_VARIANT", variant)
+    dev_switch("attn_variant", int(variant))
     for (n, P, hq, hkv, staged) in [(1, 0, 2, 1, True), (31, 1, 2, 1, False), (64, 63, 4, 2, True), (65, 64, 2, 1, False),
                                     (127, 65, 4, 4, True), (256, 0, 2, 1, False), (257, 191, 7, 1, True), (300, 1000, 6, 2, False),
                                     (640, 129, 8, 1, True), (1100, 4000, 28, 4, False)]:
@@ -843,7 +843,7 @@ def test_prefill_attn_every_kernel_form(ops, variant, monkeypatch):
         assert (out.float() - full[lo:hi].float()).abs().max().item() <= 4e-3
 
 
-def test_prefill_attn_forms_agree_at_full_size(ops, monkeypatch):
+def test_prefill_attn_forms_agree_at_full_size(ops, dev_switch):
     """s4, s6<4> and s6<8> compute the same math in a different instruction order: outputs agree to bf16 rounding at cfg2 size."""
     n, P, hq, hkv = 5760, 8647, 28, 4
     g = torch.Generator(device="cuda"); g.manual_seed(3)
@@ -852,7 +852,7 @@ def test_prefill_attn_forms_agree_at_full_size(ops, monkeypatch):
     v = torch.randn(hkv, P + n, D, generator=g, device="cuda").to(torch.bfloat16)
     outs = {}
     for variant in ("4", "7", "8"):
-        monkeypatch.setenv("QP_ATTN_VARIANT", variant)
+        dev_switch("attn_variant", int(variant))
         o = torch.empty(n, hq, D, dtype=torch.bfloat16, device="cuda")
         ops.prefill_attn(q, k, v, (P + n) * D, P, k[:, P:], v[:, P:], (P + n) * D, n, hq, hkv, D, D ** -0.5, o)
         outs[variant] = o.float()

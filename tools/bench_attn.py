@@ -51,7 +51,7 @@ for (n, P, hq, hkv) in shapes:
     ref = torch.einsum("hrk,hkd->rhd", torch.softmax(sc, -1), vv)
     del sc, kk, vv
     for vi, var in enumerate(variants):
-        os.environ["QP_ATTN_VARIANT"] = var
+        ops.dev_switch("attn_variant", int(var))
         if vi == 0:                                   # clocks / caches warm before the first timed variant
             bench(lambda: ops.prefill_attn(q, k, v, (P + n) * D, P, k[:, P:], v[:, P:], (P + n) * D, n, hq, hkv, D, D ** -0.5, out), it=20)
         f = lambda: ops.prefill_attn(q, k, v, (P + n) * D, P, k[:, P:], v[:, P:], (P + n) * D, n, hq, hkv, D, D ** -0.5, out)

@@ -24,7 +24,7 @@ for ci in range(cases):
         k[:, rnd.randrange(P + n)] *= 6
     outs = {}
     for var in ("4", "7", "8", "0"):
-        os.environ["QP_ATTN_VARIANT"] = var
+        ops.dev_switch("attn_variant", int(var))
         o = torch.full((nq, hq, D), float("nan"), dtype=torch.bfloat16, device="cuda")
         ops.prefill_attn(q, k, v, (P + n) * D, P, k[:, P:], v[:, P:], (P + n) * D, n, hq, hkv, D, D ** -0.5, o, q_row0=q_row0, nq=nq)
         outs[var] = o.float()
