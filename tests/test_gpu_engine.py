@@ -498,7 +498,7 @@ def test_tuned_gemm_choice_is_shared_by_every_context_of_the_process():
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(5)
     differ_from_default = 0
-    for m, n, k in ((2232, 3584, 18944), (392, 384, 256), (24, 3584, 18944), (952, 3584, 3584)):      # row counts no other test uses
+    for m, n, k in ((2233, 3584, 18944), (393, 384, 256), (27, 3584, 18944), (953, 3584, 3584)):      # row counts no other test uses
         x = (torch.randn(m, k, generator=g) * 0.5).to(torch.bfloat16).to(dev)
         ws = [(torch.randn(n, k, generator=g) * 0.05).to(torch.bfloat16).to(dev) for _ in range(3)]
         early = QuickPrefillOps(dev)

@@ -8,6 +8,10 @@
 //        6 = mode 2 + the softmax's VALU per MFMA (1 v_exp_f32, 1 v_fma_f32, 1 v_add_f32, 1/2 v_cvt_pk_bf16_f32, 1/2 v_max3_f32)
 //        7 = mode 5 + the same VALU per MFMA
 //        10 = mode 6 without the fma (exp, add, 1/2 cvt, 1/2 max3): what folding the max subtraction into the MFMA accumulator would leave
+//        11 = 16x16x32, one ds_read_b128 per FOUR MFMAs (a K/V fragment of 16 rows x 32 k reused against four 16-query sub-blocks held in
+//             registers: the 64-query-rows-per-wave form of VERDICT r4 #4)       12 = mode 11 + the softmax VALU (same work per FLOP as mode 6:
+//             one set per TWO 16x16x32 MFMAs)       14 = 16x16x32, one read per TWO MFMAs (32 query rows per wave) + the VALU
+//        15 = 16x16x32, register operands + the VALU (no LDS at all: the floor of this MFMA shape under the softmax's VALU work)
 //        8 = mode 2 + ONLY the v_exp_f32 per MFMA        9 = mode 2 + ONLY the plain VALU (fma, add, 1/2 cvt_pk, 1/2 max3) per MFMA
 #include <hip/hip_runtime.h>
 #include <atomic>
@@ -99,6 +103,27 @@ __global__ __launch_bounds__(256, 2) void mfma_loop(const uint4* __restrict__ in
         }
       }
       off += 7;
+    } else if (kMode == 11 || kMode == 12 || kMode == 14 || kMode == 15) {
+      constexpr int kReuse = kMode == 14 ? 2 : 4;                 // MFMAs per LDS fragment
+#pragma unroll
+      for (int i = 0; i < 16; i += kReuse) {
+        const bf16x8_t al = kMode == 15 ? a[(i / kReuse) & 3] : __builtin_bit_cast(bf16x8_t, lds[(off + i * 256) & 4095]);
+#pragma unroll
+        for (int j = 0; j < kReuse; ++j)
+          c16[(i + j) & 7] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, b[j & 3], c16[(i + j) & 7], 0, 0, 0);
+        if (kMode != 11) {
+#pragma unroll
+          for (int j = 0; j < kReuse / 2; ++j) {                  // one softmax element set per 32 KFLOP = per two of these MFMAs
+            const int q = (i / 2 + j) & 3;
+            const float x = __builtin_fmaf(vx[q], 0.25f, -1.0f);
+            const float e = __builtin_amdgcn_exp2f(x);
+            vs += e;
+            vx[q] = e + 0.5f;
+            if ((i / 2 + j) & 1) { vm = fmaxf(fmaxf(vm, e), x); typedef __bf16 bf2 __attribute__((ext_vector_type(2))); bf2 pk = {(__bf16)e, (__bf16)x}; vpk ^= __builtin_bit_cast(unsigned, pk); }
+          }
+        }
+      }
+      off += 7;
     } else {
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -180,6 +205,10 @@ int main() {
   run<10>(in, out, hw, "32x32x16 + 1 LDS read + softmax VALU WITHOUT the fma", 8 * 32768.0);
   run<8>(in, out, hw, "32x32x16 + 1 LDS read + ONLY v_exp_f32 (+mul) per MFMA", 8 * 32768.0);
   run<9>(in, out, hw, "32x32x16 + 1 LDS read + ONLY the plain VALU per MFMA", 8 * 32768.0);
+  run<11>(in, out, hw, "16x16x32 + 1 ds_read_b128 per FOUR MFMAs", 16 * 16384.0);
+  run<12>(in, out, hw, "16x16x32 + 1/4 LDS read + softmax VALU", 16 * 16384.0);
+  run<14>(in, out, hw, "16x16x32 + 1/2 LDS read + softmax VALU", 16 * 16384.0);
+  run<15>(in, out, hw, "16x16x32 register operands + softmax VALU", 16 * 16384.0);
   hipMemset(in, 0, 65536 * 16);
   run<4>(in, out, hw, "32x32x16 bf16, register operands, ALL-ZERO data", 8 * 32768.0);
   return 0;
