@@ -301,6 +301,53 @@ def probe_sp_efficiency(name, device, rank, world, single_dev):
     return eff
 
 
+def rccl_preflight(name, device, rank, world, backend):
+    """N > 1, before anything is timed: every collective SHAPE the layouts use, on the job's process group, a few times each, with the
+    time per call (max over ranks) — so that a communicator that cannot be built, or a collective that hangs, shows up in the first half
+    minute as a named step on stderr (and, past the process group's timeout, as an error) instead of a silent stall inside the timed pass.
+      tp  2 x all_reduce of [n, d] bf16 per layer + all_gather_into_tensor of the fp32 key sums [world][Hkv_local][n]
+      sp  all_gather_into_tensor of one rank's K | V | key-sum block
+      pp  [n, d] bf16 hand-off to the next stage (batch_isend_irecv ring on the job's group)
+    -> dict of microseconds per call."""
+    model, frames, fh, fw, gs, rho, prefix, tail = CONFIGS[name]
+    spec = PRESETS[model]
+    n = (gs // 2) * (fh // 28) * (fw // 28) if gs > 0 else (frames // 2) * (fh // 28) * (fw // 28)
+    d, hkv, D = spec.hidden, max(1, spec.n_kv_heads // world), spec.head_dim
+    dist = torch.distributed
+    out = {"backend": backend, "world_size": world, "rows": n}
+
+    def timed(label, fn, reps=5):
+        progress(f"preflight: {label}")
+        fn(); torch.cuda.synchronize(); dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        t = torch.tensor([(time.perf_counter() - t0) / reps * 1e6], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        out[label] = round(float(t.item()), 1)
+
+    x = torch.randn(n, d, device=device, dtype=torch.float32).to(torch.bfloat16)
+    timed("all_reduce_nd_bf16_us", lambda: dist.all_reduce(x))
+    ss = torch.zeros(hkv, n, device=device, dtype=torch.float32)
+    ss_all = torch.empty(world, hkv, n, device=device, dtype=torch.float32)
+    timed("all_gather_key_sums_us", lambda: dist.all_gather_into_tensor(ss_all, ss))
+    m2 = 2 * -(-n // (2 * world))
+    blk = torch.zeros(2 * spec.n_kv_heads * m2 * D * 2 + spec.n_kv_heads * m2 * 4, device=device, dtype=torch.uint8)
+    blk_all = torch.empty(world * blk.numel(), device=device, dtype=torch.uint8)
+    timed("all_gather_sp_kv_block_us", lambda: dist.all_gather_into_tensor(blk_all, blk))
+    y = torch.empty_like(x)
+
+    def ring():
+        ops_ = [dist.P2POp(dist.isend, x, (rank + 1) % world), dist.P2POp(dist.irecv, y, (rank - 1) % world)]
+        for r_ in dist.batch_isend_irecv(ops_):
+            r_.wait()
+    timed("p2p_ring_handoff_nd_bf16_us", ring)
+    out["all_reduce_nd_bf16_gb_s_algorithmic"] = round(x.numel() * 2 / (out["all_reduce_nd_bf16_us"] * 1e-6) / 1e9, 1)
+    progress(f"preflight done: {out}")
+    return out
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # workload
 # ----------------------------------------------------------------------------------------------------------------------
@@ -1278,6 +1325,8 @@ def compact_line(out, full_path=None):
         line["first_token_matches_record"] = ftc.get("match")
     if out.get("rccl_ranks"):
         line["rccl_ranks"] = _pick(out["rccl_ranks"], ("world_size", "backend"))
+    if out.get("rccl_preflight"):
+        line["rccl_preflight_us"] = {k.replace("_us", ""): v for k, v in out["rccl_preflight"].items() if k.endswith("_us")}
     if out.get("nccl_preflight"):
         line["nccl_preflight"] = _pick(out["nccl_preflight"], ("backend", "world_size"))
     tp = out.get("tp")
@@ -1332,11 +1381,14 @@ def main():
                     "world_size 1, and run the pass THROUGH that group in the tensor-parallel layout (2 all-reduces of [n, d] + 1 all-gather "
                     "of the key sums per layer, each a 1-rank RCCL call): the multi-GPU code path on a 1-GPU box; `value` must stay put")
     ap.add_argument("--window", default=None, help="g0:g1 — profile groups [g0, g1) of the video from a fast-forwarded state")
-    ap.add_argument("--parallel", default="both", choices=["both", "auto", "sp", "tp", "pp"],
+    ap.add_argument("--parallel", default="tp", choices=["tp", "both", "auto", "sp", "pp"],
                     help="N>1: tp = tensor parallel over heads / MLP columns (two [n,d] all-reduces + one key-sum all-gather per layer: the "
                          "north_star contract), sp = group-token parallel (replicated weights/KV, one K/V all-gather per layer), pp = layer "
                          "pipeline (each rank holds L/N layers and their KV; one [n,d] hand-off per group and stage), auto = pp x sp "
-                         "factorisation chosen from a measured efficiency probe; both (default) = auto as `value` + a `tp` block")
+                         "factorisation chosen from a measured efficiency probe; both = auto as `value` + a `tp` block.  Default tp: the contract layout, "
+                         "and the only one whose collectives (all_reduce / all_gather on the job's group) need no sub-communicators — the other "
+                         "layouts have run on gloo and on one GPU only, so they are opt-in until a multi-GPU box has executed them")
+    ap.add_argument("--no-preflight", action="store_true", help="N > 1: skip the collective preflight in front of the timed pass")
     args = ap.parse_args()
     if args.lean:
         args.no_cpu_baseline = args.no_pipeline = args.no_decode = args.no_secondary = True
@@ -1371,7 +1423,7 @@ def main():
     if single_dev:
         local_rank = 0
     if world > 1:
-        qp_parallel.multi_gpu_runtime_defaults()
+        qp_parallel.multi_gpu_runtime_defaults(ipc_dmabuf=True)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if os.environ.get("QP_BENCH_LLM_PRIORITY"):          # experiment: the whole run on a stream of this priority (-1 = high) instead of the default stream
@@ -1387,14 +1439,21 @@ def main():
         preflight = torch.distributed.new_group(ranks=[0])
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import datetime
+        # a collective that does not complete within this time ABORTS the job with an error (torch's NCCL watchdog) instead of hanging it
+        tmo = datetime.timedelta(seconds=float(os.environ.get("QP_DIST_TIMEOUT_S", "600")))
         if single_dev:
-            torch.distributed.init_process_group("gloo")
+            torch.distributed.init_process_group("gloo", timeout=tmo)
         else:
-            torch.distributed.init_process_group("nccl", device_id=device)    # nccl == RCCL over xGMI on ROCm
+            torch.distributed.init_process_group("nccl", device_id=device, timeout=tmo)    # nccl == RCCL over xGMI on ROCm
         group = torch.distributed.group.WORLD
         backend = torch.distributed.get_backend()
+        progress(f"torch.distributed up: backend {backend}, world {world}, collective timeout {tmo.total_seconds():.0f} s")
 
     name = args.config
+    rccl_pre = None
+    if world > 1 and not args.no_preflight and not args.window:
+        rccl_pre = rccl_preflight(name, device, rank, world, backend)
     _, frames_, _, _, gs_, _, _, _ = CONFIGS[name]
     n_groups_ = -(-frames_ // gs_) if gs_ > 0 else 1
     timing = "off" if args.no_kernel_timing else "inline"
@@ -1491,6 +1550,8 @@ def main():
         for k in ("roofline_prune", "hbm_kernels", "kernel_ms_per_pass", "telemetry", "segment_path"):
             if k in res:
                 out[k] = res[k]
+        if rccl_pre is not None:
+            out["rccl_preflight"] = rccl_pre
         if world > 1:
             out["rccl_ranks"] = {"world_size": torch.distributed.get_world_size(), "backend": backend,
                                  "note": "backend 'nccl' is RCCL over xGMI on ROCm; 'gloo' only under QP_BENCH_SINGLE_DEVICE=1",

@@ -199,9 +199,9 @@ int qp_query_scores(qp_ctx* ctx, const void* q_prompt, const void* k_group, int6
  * lane, <= 64 KB per workgroup), signals "rows loaded", waits for the (at most two, always LOWER) slices whose source rows its
  * destination rows overlap, and stores to [past_len, past_len+k) — the compaction never bounces through HBM scratch.  The wait is
  * deadlock-free because it only points downwards, the whole grid (<= 512 workgroups) fits at once on the CUs the stream may use
- * (occupancy API x the stream's CU mask; otherwise the staged form runs) and the context keeps at most ONE in-place grid in flight: a
- * call on a different stream than the previous one is ordered behind it on the device (hipStreamWaitEvent; no host wait).  Callers
- * may therefore use any number of streams.  (Inside a stream capture the library records no events: the captured stream orders its
+ * (occupancy API x the stream's CU mask; otherwise the staged form runs) and the library keeps at most ONE in-place grid in flight PER DEVICE
+ * (whichever context or stream launches it): a call on a different stream than the previous one is ordered behind it on the device
+ * (hipStreamWaitEvent; no host wait).  Callers may therefore use any number of streams and contexts.  (Inside a stream capture the library records no events: the captured stream orders its
  * own nodes.)  The in-place workspace only holds the keys and the flags (2.25 bytes per token).  Larger groups use the round-1 form
  * (sums -> select -> gather into the workspace -> copy back), which needs room for the kept rows.
  *   qp_prune_workspace_bytes(...)            an upper bound, sufficient for either form on any device / stream (no context needed)

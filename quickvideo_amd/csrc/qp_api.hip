@@ -1,6 +1,7 @@
 // C ABI of libquickprefill.so (include/quickprefill.h): argument validation + launches.  No torch types,
 // no device allocation, no synchronisation: everything is enqueued on the caller's stream.
 #include "qp_common.h"
+#include <mutex>
 #include <string>
 #include <cstdarg>
 #include <cstdio>
@@ -87,7 +88,6 @@ int qp_create(qp_ctx** out, int device) {
 
 void qp_destroy(qp_ctx* ctx) {
   if (!ctx) return;
-  if (ctx->tail_ev) (void)hipEventDestroy(ctx->tail_ev);
   qp_lt_destroy(ctx->lt);                      // hipBLASLt handles / plans of this context
   delete ctx;
 }
@@ -364,6 +364,15 @@ static size_t staged_tail_bytes(int64_t n, int64_t k, int n_kv_heads, int head_d
 }
 static size_t inplace_tail_bytes(int64_t n) { return align256((size_t)n * 2) + align256((size_t)tail_slices(n) * 4); }
 
+// qp_prune_tail's in-place launch spin-waits on lower-numbered workgroups, which is only deadlock-free while its WHOLE grid can be
+// resident.  At most ONE such grid is in flight per device, whichever context or stream launches it: the event of the last launch lives
+// here (never destroyed: a handful of bytes per device for the life of the process).
+struct TailGuard { std::mutex mu; hipEvent_t ev = nullptr; hipStream_t stream = nullptr; bool pending = false; };
+static TailGuard* tail_guard(int device) {
+  static TailGuard table[64];
+  return &table[device & 63];
+}
+
 // CUs `s` may run on: the population count of its CU mask (hipExtStreamCreateWithCUMask / HSA_CU_MASK); the device's count when the
 // runtime reports none.  The in-place grid must fit on THESE, not on the whole device.
 static int qp_stream_cus(const qp_ctx* ctx, hipStream_t s) {
@@ -386,7 +395,8 @@ size_t qp_prune_workspace_bytes(int64_t n, int64_t k, int n_kv_heads, int head_d
 size_t qp_prune_tail_workspace_bytes(const qp_ctx* ctx, int64_t n, int64_t k, int n_kv_heads, int head_dim, void* stream) {
   if (n <= 0 || k <= 0 || n_kv_heads <= 0 || head_dim <= 0) return 256;
   if (ctx && tail_inplace_ok(n, n_kv_heads) &&
-      tail_slices(n) <= qp_prune_tail_inplace_capacity(stream ? qp_stream_cus(ctx, (hipStream_t)stream) : ctx->cus))
+      tail_slices(n) <= qp_prune_tail_inplace_capacity(qp_stream_cus(ctx, (hipStream_t)stream)))   // the SAME query the launcher makes, NULL stream
+                                                                                                // included (a global HSA_CU_MASK masks it too)
     return inplace_tail_bytes(n);
   return staged_tail_bytes(n, k, n_kv_heads, head_dim);
 }
@@ -417,16 +427,18 @@ int qp_prune_tail(qp_ctx* ctx, void* k_cache, void* v_cache, int64_t head_stride
   if (inplace) {
     uint16_t* keys = (uint16_t*)ws;
     int* sync_words = (int*)(ws + align256((size_t)n * 2));
-    // ONE in-place grid in flight per context: a call on another stream than the previous one waits (on the device) for that one's
-    // event.  Inside a stream capture the event dance is skipped — the captured stream orders its own nodes; a caller that replays
-    // several such graphs at once owns that ordering.
-    std::lock_guard<std::mutex> guard(ctx->tail_mu);
+    // ONE in-place grid in flight per DEVICE (round 5: the guard lives in a process-wide table indexed by the device, not in the
+    // context — three contexts on one device could otherwise oversubscribe the CUs again): a call on another stream than the previous
+    // one waits (on the device) for that one's event.  Inside a stream capture the event dance is skipped — the captured stream orders
+    // its own nodes; a caller that replays several such graphs at once owns that ordering.
+    TailGuard* tg = tail_guard(ctx->device);
+    std::lock_guard<std::mutex> guard(tg->mu);
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     const bool capturing = hipStreamIsCapturing(s, &cap) == hipSuccess && cap == hipStreamCaptureStatusActive;
     if (!capturing) {
-      if (!ctx->tail_ev && hipEventCreateWithFlags(&ctx->tail_ev, hipEventDisableTiming) != hipSuccess)
+      if (!tg->ev && hipEventCreateWithFlags(&tg->ev, hipEventDisableTiming) != hipSuccess)
         return qp_fail(QP_ERR_HIP, "qp_prune_tail: hipEventCreate failed");
-      if (ctx->tail_pending && ctx->tail_stream != s && hipStreamWaitEvent(s, ctx->tail_ev, 0) != hipSuccess)
+      if (tg->pending && tg->stream != s && hipStreamWaitEvent(s, tg->ev, 0) != hipSuccess)
         return qp_fail(QP_ERR_HIP, "qp_prune_tail: hipStreamWaitEvent failed");
     }
     // launch 1: 16-bit norm key of every tail token (all KV heads of a token in one 16-lane group) + clears the sync words
@@ -436,9 +448,9 @@ int qp_prune_tail(qp_ctx* ctx, void* k_cache, void* v_cache, int64_t head_stride
     rc = qp_launch_prune_tail_inplace(keys, n, k, k_cache, v_cache, head_stride, past_len, n_kv_heads, kept_idx_out, sync_words, s);
     if (rc) return rc;
     if (!capturing) {
-      if (hipEventRecord(ctx->tail_ev, s) != hipSuccess) return qp_fail(QP_ERR_HIP, "qp_prune_tail: hipEventRecord failed");
-      ctx->tail_stream = s;
-      ctx->tail_pending = true;
+      if (hipEventRecord(tg->ev, s) != hipSuccess) return qp_fail(QP_ERR_HIP, "qp_prune_tail: hipEventRecord failed");
+      tg->stream = s;
+      tg->pending = true;
     }
     return QP_OK;
   }

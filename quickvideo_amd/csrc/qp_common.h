@@ -5,19 +5,11 @@
 #include <stddef.h>
 #include "../../include/quickprefill.h"
 
-#include <mutex>
 struct qp_ctx {
   int device;
   int cus;
   int lds_per_cu;
   void* lt;          // hipBLASLt handles (one per stream) and GEMM plans of THIS context/device (qp_linear.hip); freed by qp_destroy
-  // qp_prune_tail's in-place launch spin-waits on lower-numbered workgroups, which is only deadlock-free while its WHOLE grid can be
-  // resident.  The context therefore keeps at most ONE such grid in flight: a launch on another stream is ordered behind the previous
-  // one with an event (stream-ordered, no host wait).  tail_ev is recorded after every in-place launch.
-  std::mutex tail_mu;
-  hipEvent_t tail_ev = nullptr;
-  hipStream_t tail_stream = nullptr;
-  bool tail_pending = false;
 };
 void qp_lt_destroy(void* lt_state);
 

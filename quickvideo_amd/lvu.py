@@ -21,7 +21,7 @@ def load_native_model(name_or_path: str, device=None, seed: int = 0, parallel=No
     directory with a HF Qwen2-VL checkpoint (config.json + *.safetensors).
 
     Multi-GPU (one process per GPU, torch.distributed initialised by the launcher; the reference's counterpart is
-    `device_map="auto"`, lvu/lvu.py:11-16): `parallel` = "tp" | "sp" | "pp" | "auto" | "single" (default: $QP_PARALLEL, else "auto" in a
+    `device_map="auto"`, lvu/lvu.py:11-16): `parallel` = "tp" | "sp" | "pp" | "auto" | "single" (default: $QP_PARALLEL, else "tp" in a
     multi-rank job).  "tp" loads this rank's head / MLP-column SHARD; the other modes load a full replica on every rank and cut the
     per-video pipeline stages out of it as views (quickvideo_amd/parallel.py).  The vision tower is replicated in every mode."""
     from .parallel import resolve

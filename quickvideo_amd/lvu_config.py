@@ -4,6 +4,16 @@ from dataclasses import dataclass
 from typing import Optional
 
 
+_IGNORED_WARNED: set = set()
+
+
+def _warn_ignored_once(key: str, msg: str):
+    if key not in _IGNORED_WARNED:
+        _IGNORED_WARNED.add(key)
+        import warnings
+        warnings.warn(msg, stacklevel=4)
+
+
 @dataclass
 class LVUConfig:
     model_name_or_path: str
@@ -34,6 +44,12 @@ class LVUConfig:
             self.top_k_decay_factor = 0.5
         if "query" in self.top_k_predict_type:
             self.query_based = True
+        # The reference's frame cache (cache_dir / save_video_cache: JPEG-encoded frames + processor outputs on disk, qwen25_lvu.py:552-592,
+        # lvu_cache.py:28-49 — and a NameError in the interleaved plugin) is outside this package's scope (§8: the hot
+        # path starts at decoded frames).  The fields stay for drop-in construction; setting them does nothing HERE, and says so once.
+        if self.save_video_cache or self.cache_dir:
+            _warn_ignored_once("save_video_cache / cache_dir", "LVUConfig.save_video_cache / cache_dir are accepted for drop-in compatibility but the "
+                               "on-disk frame cache is not implemented by the MI355X-native plugin: every generate() reads the frames from the video source")
 
 
 @dataclass

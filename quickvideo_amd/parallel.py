@@ -29,6 +29,15 @@ from .weights import DecoderWeights, pp_layer_split
 
 MODES = ("single", "tp", "sp", "pp", "auto")
 
+
+def dist_timeout():
+    """Timeout of every process group this package creates (QP_DIST_TIMEOUT_S, default 600 s): a collective, a pipeline hand-off or a
+    front-end scatter whose peer never arrives — e.g. communicators issued in a rank-dependent order that the runtime cannot keep
+    co-resident — then ABORTS the job with torch's NCCL-watchdog error naming the collective, instead of hanging it.  (No multi-GPU box
+    has executed the sp / pp / auto layouts yet: a mis-ordered communicator must show up as an error.)"""
+    import datetime
+    return datetime.timedelta(seconds=float(os.environ.get("QP_DIST_TIMEOUT_S", "600")))
+
 # Prior for "auto" when nobody measured this machine: efficiency of an s-rank group-token parallel group relative to one GPU (GEMMs at
 # M = n / s, the K/V all-gather, the replicated prune).  bench.py measures the table at start-up (probe_sp_efficiency) and hands it to
 # the pipeline; QP_SP_EFFICIENCY="2:0.93,4:0.8,8:0.6" overrides it.
@@ -130,7 +139,7 @@ class ParallelContext:
             return self.group if self.group is not None else torch.distributed.group.WORLD
         key = (pp, sp)
         if key not in self._subgroups:
-            gs = [torch.distributed.new_group(ranks=[self.global_rank(s * sp + i) for i in range(sp)]) for s in range(pp)]
+            gs = [torch.distributed.new_group(ranks=[self.global_rank(s * sp + i) for i in range(sp)], timeout=dist_timeout()) for s in range(pp)]
             self._subgroups[key] = gs
         return self._subgroups[key][self.rank // sp]
 
@@ -145,7 +154,7 @@ class ParallelContext:
             return None, None
         key = ("pairs", pp, sp)
         if key not in self._subgroups:
-            self._subgroups[key] = {(s, i): torch.distributed.new_group(ranks=[self.global_rank(s * sp + i), self.global_rank((s + 1) * sp + i)])
+            self._subgroups[key] = {(s, i): torch.distributed.new_group(ranks=[self.global_rank(s * sp + i), self.global_rank((s + 1) * sp + i)], timeout=dist_timeout())
                                     for s in range(pp - 1) for i in range(sp)}
         g, (stage, i) = self._subgroups[key], (self.rank // sp, self.rank % sp)
         return g.get((stage, i)), g.get((stage - 1, i))
@@ -172,12 +181,15 @@ class ParallelContext:
 
 
 def resolve(parallel: Optional[str] = None, group=None) -> ParallelContext:
-    """`parallel`: one of MODES, or None -> $QP_PARALLEL, else "auto" when torch.distributed is initialised with more than one rank and
-    "single" otherwise.  A mode other than "single" in a 1-rank job resolves to "single" (the same script runs on 1 and on 8 GPUs)."""
+    """`parallel`: one of MODES, or None -> $QP_PARALLEL, else "tp" when torch.distributed is initialised with more than one rank and
+    "single" otherwise.  A mode other than "single" in a 1-rank job resolves to "single" (the same script runs on 1 and on 8 GPUs).
+    The multi-rank default is the contract layout (tensor parallel: all_reduce / all_gather on the job's own group, no
+    sub-communicators); "auto" / "sp" / "pp" are OPT-IN (argument or QP_PARALLEL) until a real 2/4/8-GPU run of them is on record —
+    they have executed on gloo and with several ranks on one GPU only."""
     mode = parallel or os.environ.get("QP_PARALLEL")
     dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
     if mode is None:
-        mode = "auto" if dist_on and torch.distributed.get_world_size(group) > 1 else "single"
+        mode = "tp" if dist_on and torch.distributed.get_world_size(group) > 1 else "single"
     if mode not in MODES:
         raise ValueError(f"parallel={mode!r}: expected one of {MODES}")
     if mode == "single" or not dist_on:
@@ -190,7 +202,7 @@ def resolve(parallel: Optional[str] = None, group=None) -> ParallelContext:
     return ParallelContext(mode, world, rank, group)
 
 
-def multi_gpu_runtime_defaults() -> None:
+def multi_gpu_runtime_defaults(ipc_dmabuf: Optional[bool] = None) -> None:
     """Environment a multi-GPU rank wants BEFORE its first HIP call (setdefault: the user's own setting wins).
 
     GPU_MAX_HW_QUEUES=8: the HIP runtime multiplexes a process's streams onto 4 hardware queues per priority by default, and streams on
@@ -205,7 +217,12 @@ def multi_gpu_runtime_defaults() -> None:
     Deadlock is excluded either way by construction (a stage posts recv(g) only after its part of all-gather(g) is done), this is
     about not serialising.  No multi-GPU box has run it."""
     os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")           # the host driver only supports dmabuf IPC
+    # HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC) is a property of the HOST DRIVER, not of this package: exported only on request —
+    # `ipc_dmabuf=True` (bench.py, the test launchers: the boxes this repo is measured on support nothing else) or QP_IPC_DMABUF=1
+    if ipc_dmabuf is None:
+        ipc_dmabuf = os.environ.get("QP_IPC_DMABUF") == "1"
+    if ipc_dmabuf:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
 def init_distributed(backend: Optional[str] = None) -> ParallelContext:
@@ -222,5 +239,5 @@ def init_distributed(backend: Optional[str] = None) -> ParallelContext:
             dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
             torch.cuda.set_device(dev)
             kw["device_id"] = dev
-        torch.distributed.init_process_group(backend or ("nccl" if cuda else "gloo"), **kw)
+        torch.distributed.init_process_group(backend or ("nccl" if cuda else "gloo"), timeout=dist_timeout(), **kw)
     return resolve()

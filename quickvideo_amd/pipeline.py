@@ -230,6 +230,51 @@ class _Producer(threading.Thread):
         self.slots_free.release()
 
 
+_WARNED: set = set()
+
+
+def _warn_once(key: str, msg: str):
+    if key not in _WARNED:
+        _WARNED.add(key)
+        import warnings
+        warnings.warn(msg, stacklevel=3)
+
+
+_SWITCH_LOCK = threading.Lock()
+_SWITCH_STATE = {"depth": 0, "saved": None}
+
+
+class _switch_interval_override:
+    """sys.setswitchinterval is process-wide: the override is ref-counted — the first generate() entering saves the interval and
+    lowers it, the last one leaving restores the saved value (two overlapping generates used to restore 5 ms while the other was still
+    running, or save the lowered value as "old" and leave it set for good).  want <= 0: no override."""
+
+    def __init__(self, want: float):
+        self.want = want
+
+    def __enter__(self):
+        import sys
+        if self.want <= 0:
+            return self
+        with _SWITCH_LOCK:
+            if _SWITCH_STATE["depth"] == 0:
+                _SWITCH_STATE["saved"] = sys.getswitchinterval()
+                sys.setswitchinterval(min(_SWITCH_STATE["saved"], self.want))
+            _SWITCH_STATE["depth"] += 1
+        return self
+
+    def __exit__(self, *exc):
+        import sys
+        if self.want <= 0:
+            return False
+        with _SWITCH_LOCK:
+            _SWITCH_STATE["depth"] -= 1
+            if _SWITCH_STATE["depth"] == 0 and _SWITCH_STATE["saved"] is not None:
+                sys.setswitchinterval(_SWITCH_STATE["saved"])
+                _SWITCH_STATE["saved"] = None
+        return False
+
+
 class PrefillPipeline:
     def __init__(self, model: QwenVLNative, config: LVUConfig, processor, ops=None):
         self.model, self.cfg, self.processor, self.ops = model, config, processor, ops
@@ -398,16 +443,10 @@ class PrefillPipeline:
         every torch call of the launching thread (a few hundred per frame group) drops the interpreter lock, and a Python thread that is
         busy beside it — the reference's own processor thread is one, qwen25_lvu_interleaved.py:303-340 — then keeps the lock for a whole
         switch interval (5 ms by default) before the launcher gets it back: measured on cfg4s with ONE such thread, 9x slower
-        (bench.py host_contention).  The other thread loses nothing but a little switching overhead; the setting is restored on return."""
-        import sys
-        old = sys.getswitchinterval()
-        want = float(os.environ.get("QP_SWITCH_INTERVAL_S", "2e-5"))
-        if want > 0:
-            sys.setswitchinterval(min(old, want))
-        try:
+        (bench.py host_contention).  The other thread loses nothing but a little switching overhead; the setting is restored when the LAST concurrent generate of the
+        process returns (ref-counted: two LVU objects may generate at the same time)."""
+        with _switch_interval_override(float(os.environ.get("QP_SWITCH_INTERVAL_S", "2e-5"))):
             return self._generate(*args, **kwargs)
-        finally:
-            sys.setswitchinterval(old)
 
     @torch.no_grad()
     def _generate(self, question, video, max_new_tokens: int = 16, overlap: bool = True, eos_token_id=None,
@@ -520,9 +559,18 @@ class PrefillPipeline:
         last_frames = None
         p0_prev = None                                                # start of the previous group's prefill (the ViT's run-ahead gate)
         ahead = (getattr(eng, "pp_size", 1) or 1) + 3
+        bar = None
+        if self.cfg.use_tqdm and lead:                                # the reference wraps its group loop in tqdm when asked (qwen25_lvu.py:671-672)
+            try:
+                from tqdm import tqdm
+                bar = tqdm(total=G, desc="Processing video groups", disable=False)
+            except ImportError:                                       # no tqdm in the environment: say so once, keep going
+                _warn_once("use_tqdm", "LVUConfig.use_tqdm=True but tqdm is not importable: no progress bar")
         try:
             nxt = vit_group(0)
             for g, n in enumerate(plan.tokens):
+                if bar is not None:
+                    bar.update(1)                                     # groups ENQUEUED (the GPU runs behind the host by design)
                 feats, evs, read_done, last_frames = nxt
                 if self.use_gpu:
                     main = torch.cuda.current_stream(dev)
@@ -561,6 +609,9 @@ class PrefillPipeline:
             if prod is not None:
                 prod.cancel()
             raise
+        finally:
+            if bar is not None:
+                bar.close()
         sync()
         if dbg is not None:
             dbg.stop()

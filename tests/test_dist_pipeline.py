@@ -108,7 +108,7 @@ def test_generate_over_ranks_equals_single_process(world, mode, gs, nframes, lay
 
 
 def test_auto_layout_picks_a_grid_per_video_and_matches():
-    """`parallel="auto"` (the default of a multi-rank job): full replica per rank, grid chosen per video from the group count
+    """`parallel="auto"` (opt-in since round 5; the default of a multi-rank job is "tp"): full replica per rank, grid chosen per video from the group count
     (parallel.choose_layout; 4 ranks, 3 layers, 4 groups -> pp2 x sp2 or pp1 x sp4 by the efficiency table)."""
     from quickvideo_amd.parallel import choose_layout, sp_efficiency_table
     want = choose_layout(4, 4, sp_efficiency_table(), 3)
@@ -202,11 +202,47 @@ def test_multi_gpu_runtime_defaults_do_not_override_the_user(monkeypatch):
     from quickvideo_amd.parallel import multi_gpu_runtime_defaults
     monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
     monkeypatch.delenv("HSA_ENABLE_IPC_MODE_LEGACY", raising=False)
+    monkeypatch.delenv("QP_IPC_DMABUF", raising=False)
     multi_gpu_runtime_defaults()
-    assert os.environ["GPU_MAX_HW_QUEUES"] == "8" and os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    # the dmabuf-IPC switch belongs to the host driver: exported only on request, never for every user of the package
+    assert os.environ["GPU_MAX_HW_QUEUES"] == "8" and "HSA_ENABLE_IPC_MODE_LEGACY" not in os.environ
+    multi_gpu_runtime_defaults(ipc_dmabuf=True)
+    assert os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    monkeypatch.delenv("HSA_ENABLE_IPC_MODE_LEGACY", raising=False)
+    monkeypatch.setenv("QP_IPC_DMABUF", "1")
+    multi_gpu_runtime_defaults()
+    assert os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    monkeypatch.setenv("HSA_ENABLE_IPC_MODE_LEGACY", "1")
     monkeypatch.setenv("GPU_MAX_HW_QUEUES", "2")
-    multi_gpu_runtime_defaults()
-    assert os.environ["GPU_MAX_HW_QUEUES"] == "2"
+    multi_gpu_runtime_defaults(ipc_dmabuf=True)
+    assert os.environ["GPU_MAX_HW_QUEUES"] == "2" and os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "1"
+
+
+def test_multi_rank_default_layout_is_the_contract_one_and_groups_carry_a_timeout(monkeypatch):
+    """A multi-rank job that does not say otherwise gets tensor parallelism (collectives on the job's own group only); sp / pp / auto are
+    opt-in until a multi-GPU box has run them, and every process group the package creates carries a timeout (a peer that never arrives is
+    an error after QP_DIST_TIMEOUT_S, not a hang)."""
+    import inspect
+    from quickvideo_amd import parallel
+    src = inspect.getsource(parallel)
+    assert src.count("new_group(") == src.count("timeout=dist_timeout()") - 1 >= 2      # every new_group + init_process_group
+    monkeypatch.setenv("QP_DIST_TIMEOUT_S", "12.5")
+    assert parallel.dist_timeout().total_seconds() == 12.5
+    monkeypatch.delenv("QP_PARALLEL", raising=False)
+
+    class FakeDist:
+        @staticmethod
+        def is_available(): return True
+        @staticmethod
+        def is_initialized(): return True
+        @staticmethod
+        def get_world_size(group=None): return 4
+        @staticmethod
+        def get_rank(group=None): return 1
+    monkeypatch.setattr(parallel.torch, "distributed", FakeDist)
+    assert parallel.resolve().mode == "tp" and parallel.resolve("auto").mode == "auto"
+    monkeypatch.setenv("QP_PARALLEL", "pp")
+    assert parallel.resolve().mode == "pp"
 
 
 def test_layout_cost_model():

@@ -260,3 +260,35 @@ def test_bench_cpu_baseline_check_mode_runs_without_a_gpu():
     assert p.returncode == 0, p.stderr[-1000:]
     d = json.loads(p.stdout.strip().splitlines()[-1])
     assert d["measured"]["layers"] == 4 and d["estimator_sample"]["layers"] == 1 and d["estimator_over_measured_speed"] > 0
+
+
+def test_switch_interval_override_is_ref_counted():
+    """Two overlapping generate() calls (two LVU objects in one process): the process-wide thread switch interval is lowered by the first
+    to enter and restored by the LAST to leave — never restored under a running call, never left lowered."""
+    import sys
+    from quickvideo_amd.pipeline import _switch_interval_override
+    base = sys.getswitchinterval()
+    a, b = _switch_interval_override(2e-5), _switch_interval_override(2e-5)
+    a.__enter__()
+    assert sys.getswitchinterval() == pytest.approx(2e-5)
+    b.__enter__()
+    a.__exit__(None, None, None)
+    assert sys.getswitchinterval() == pytest.approx(2e-5)          # b is still running
+    b.__exit__(None, None, None)
+    assert sys.getswitchinterval() == pytest.approx(base)
+    with _switch_interval_override(0):                             # QP_SWITCH_INTERVAL_S=0: no override at all
+        assert sys.getswitchinterval() == pytest.approx(base)
+
+
+def test_config_fields_outside_the_scope_warn_once_instead_of_being_silently_ignored():
+    """cache_dir / save_video_cache (the reference's on-disk frame cache, qwen25_lvu.py:552-592) are accepted for drop-in construction but
+    not implemented: the first config that sets them says so (once per process)."""
+    import warnings
+    from quickvideo_amd import lvu_config
+    lvu_config._IGNORED_WARNED.clear()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        lvu_config.LVUConfig("x", save_video_cache=True)
+        lvu_config.LVUConfig("x", cache_dir="/tmp/c")
+        lvu_config.LVUConfig("x")
+    assert len(w) == 1 and "frame cache is not implemented" in str(w[0].message)

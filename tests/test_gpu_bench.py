@@ -60,7 +60,7 @@ def test_bench_two_ranks_on_one_gpu_reproduce_the_single_gpu_token():
     # (cfg2: 4 groups of 5760 tokens — two ranks time-sharing ONE GPU over gloo with host-staged hand-offs took 575 s on the 45 groups of
     # cfg4s, half of the driver's budget for the whole GPU suite; the layouts' code paths are the same on 4 groups)
     one = run_bench(["--config", "cfg2", "--steps", "2", "--warmup", "1", "--lean"])
-    line, two = run_bench(["--gpus", "2", "--config", "cfg2", "--steps", "2", "--warmup", "1", "--full"], {"QP_BENCH_SINGLE_DEVICE": "1"}, timeout=900, full=True)
+    line, two = run_bench(["--gpus", "2", "--config", "cfg2", "--steps", "2", "--warmup", "1", "--full", "--parallel", "both"], {"QP_BENCH_SINGLE_DEVICE": "1"}, timeout=900, full=True)
     assert line["n_gpus"] == 2 and line["rccl_ranks"] == {"world_size": 2, "backend": "gloo"} and line["tp"]["parallelism"] == "tp2"
     assert line["ttft_ms"] == two["ttft_ms"] and line["value_with_vit"] == two["value_with_vit"]
     assert two["n_gpus"] == 2 and two["rccl_ranks"]["world_size"] == 2 and two["rccl_ranks"]["backend"] == "gloo"

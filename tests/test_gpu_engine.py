@@ -525,3 +525,38 @@ def test_tuned_gemm_choice_is_shared_by_every_context_of_the_process():
         assert torch.equal(o_a.view(torch.int16), o_b.view(torch.int16)) and torch.equal(o_a.view(torch.int16), o_early.view(torch.int16)), (m, n, k, choice)
         differ_from_default += int(choice != 0 and not torch.equal(default_bits, o_a.view(torch.int16)))
     print(f"shapes whose tuned candidate rounds differently from candidate 0: {differ_from_default} of 4")
+
+
+def test_one_call_path_falls_back_when_plan_selection_fails(monkeypatch):
+    """qp_linear_tune reporting "no candidate ran" for ONE projection shape at one row count must not abort generate():
+    segments of that size take the per-operator loop (torch.mm for the failed shape, said once on stderr and recorded in
+    engine._TUNE_FAILURES); every other segment size keeps the one-call path.  Result within the engine's tolerance of the untouched run."""
+    from quickvideo_amd import engine as E
+    from quickvideo_amd.native import QuickPrefillError, QuickPrefillOps
+    monkeypatch.setenv("QP_TUNE_GEMMS", "0")
+    spec_o, w, plan, pos, delta, embeds = make_case(24, 16, 24, 8, 15, 20)                  # groups of 399 / 384 / 384 tokens, tail 20
+    cfg = LVUConfig("x", video_group_size=8, top_p=0.5)
+    eng_ok, logits_ok = run_gpu(TINY, w, plan, pos, embeds, cfg)
+    assert eng_ok._native_state is not None
+    real = QuickPrefillOps.linear_tune
+    shared_before = {k: dict(v) for k, v in QuickPrefillEngine._SHARED.items()}
+
+    def failing(self, x, weights, bias, out, act=0, alpha=1.0):
+        if x.shape[0] == 384 and weights[0].shape[0] == TINY.hidden and weights[0].shape[1] == TINY.intermediate:     # the down projection of the 384-row groups
+            raise QuickPrefillError(-3, "qp_linear_tune: no candidate ran")
+        return real(self, x, weights, bias, out, act, alpha)
+    monkeypatch.setattr(QuickPrefillOps, "linear_tune", failing)
+    for d in QuickPrefillEngine._SHARED.values():                   # a fresh process: nothing tuned, nothing planned yet
+        d.clear()
+    E._TUNE_FAILURES.clear()
+    try:
+        eng, logits = run_gpu(TINY, w, plan, pos, embeds, cfg)
+        assert list(eng.arena.len) == list(eng_ok.arena.len)
+        assert any(k[0] == "lt" and k[1] == 384 for k in E._TUNE_FAILURES), E._TUNE_FAILURES
+        plans = {k[1]: v for k, v in eng._gemm_plans.items() if k[0] == "native"}
+        assert plans[384] == E._NO_NATIVE and plans[plan.tokens[0]] != E._NO_NATIVE and plans[plan.tail_len] != E._NO_NATIVE
+        check_logits(logits.numpy(), logits_ok.numpy())
+    finally:
+        for k, d in QuickPrefillEngine._SHARED.items():            # leave the process-wide tables as the other tests expect them
+            d.clear(); d.update(shared_before.get(k, {}))
+        E._TUNE_FAILURES.clear()
