@@ -88,6 +88,23 @@ def make_keys(dist: str, hkv: int, n: int, seed: int, d: int = 128) -> torch.Ten
     elif dist == "few_levels":     # norms drawn from 5 exact levels -> massive ties
         x = np.zeros((hkv, n, d))
         x[0, :, 0] = rs.randint(1, 6, size=n).astype(np.float64)
+    elif dist == "rounding_boundary":
+        # Every row's EXACT sum of squares is built to equal T^2 (to ~2^-32 relative), T = a bf16 value + half a bf16 ulp: the fp32 norm
+        # lands on a bf16 round-to-even tie or one fp32 ulp beside it, so two fp32 summation orders that differ in the last bit of the sum
+        # (torch's vectorised reduce vs the canonical per-head order of the HIP kernel / oracle) round the bf16 norm differently on ~30 %
+        # of the rows.  Small noise everywhere + five "digits" a_j = bf16(sqrt(remaining)) at random positions.
+        def bf16r(v):
+            return torch.from_numpy(np.asarray(v, dtype=np.float32)).to(torch.bfloat16).to(torch.float64).numpy()
+        x = bf16r(rs.standard_normal((hkv, n, d)) * 0.05)
+        b = bf16r(rs.uniform(2, 16, size=n))
+        T = b + 2.0 ** (np.floor(np.log2(b)) - 7) / 2
+        for _ in range(5):
+            h, c = rs.randint(0, hkv, size=n), rs.randint(0, d, size=n)
+            x[h, np.arange(n), c] = 0.0
+            R = np.maximum(T * T - (x ** 2).sum(axis=(0, 2)), 0)
+            a = bf16r(np.sqrt(R))
+            a = np.where(a * a > R, bf16r(a * (1 - 2.0 ** -8)), a)
+            x[h, np.arange(n), c] = a
     else:
         raise ValueError(dist)
     return torch.from_numpy(x.astype(np.float32)).to(torch.bfloat16)[None]
@@ -106,6 +123,9 @@ SELECT_CASES = [  # (dist, Hkv, n, k)
     ("heavy", 4, 2240, 1120), ("all_equal", 4, 257, 100), ("distinct", 4, 100, 37), ("distinct", 2, 64, 63),
     ("few_levels", 4, 1000, 333), ("few_levels", 4, 2880, 720), ("normal", 4, 35, 7), ("normal", 4, 100, 28),
     ("normal", 4, 2, 1), ("heavy", 4, 4097, 1),
+    # built ON the fp32 -> bf16 rounding boundary: ~30 % of the rows get a different bf16 norm from torch's reduce order
+    # than from the canonical one; exercises the "norms differ" branch of the raw-reference check deliberately
+    ("rounding_boundary", 4, 512, 256),
 ]
 
 

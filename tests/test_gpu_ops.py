@@ -33,14 +33,19 @@ def dev_bits(t):
     return O.torch_bf16_to_bits(t.cpu())
 
 
-def check_vs_raw_reference(idx, data, meta, ci, n, k):
+def check_vs_raw_reference(idx, data, meta, ci, n, k, nb=None):
     """The GPU's kept list against the RAW reference list (`ref_idx`: the reference's own torch-CPU `argsort`, not forced stable).
     "Bit-exact vs the reference" means vs the reference WITH A STABLE ARGSORT (`ref_idx_stable`; torch's CUDA sort — the reference's
     deployment device — is assumed stable, which nobody here can run).  Against the raw CPU list only what the reference's own
     semantics pin can be demanded: |kept| = k, ascending, {norm < tau} subset of kept subset of {norm <= tau} on the reference's own
     norms, and the two lists differ exactly by the tie-class members the fixture recorded (`sym_diff_cpu_vs_stable`)."""
     if meta["norm_rows_differ"]:
-        return                                         # the canonical norm differs from torch's by one ulp on one row of this case
+        # the canonical norm differs from torch's by one bf16 ulp on some rows of this case (one row of a natural case; ~30 % of the
+        # deliberately adversarial "rounding_boundary" case): what index parity still pins there — tests/test_oracle_golden.py
+        from tests.test_oracle_golden import check_select_where_norms_differ
+        moved = check_select_where_norms_differ(idx, data[f"c{ci}_ref_idx_stable"], nb, data[f"c{ci}_torch_norm_bits"], k)
+        assert moved <= 2 * meta["norm_rows_differ"] + 2 * meta["n_equal"]
+        return
     ref, tnorm, tau = data[f"c{ci}_ref_idx"], data[f"c{ci}_torch_norm_bits"], meta["tau"]
     assert len(idx) == k and np.all(np.diff(idx) > 0)
     kept = np.zeros(n, bool); kept[idx] = True
@@ -78,7 +83,7 @@ def test_sumsq_select_bit_exact(ops, golden_dir, ci):
     assert np.array_equal(idx, O.select_k_smallest(nb_ref, k))
     if meta["norm_rows_differ"] == 0:     # same norms as the reference -> same kept set as the reference (stable sort)
         assert np.array_equal(idx, data[f"c{ci}_ref_idx_stable"])
-    check_vs_raw_reference(idx, data, meta, ci, n, k)
+    check_vs_raw_reference(idx, data, meta, ci, n, k, nb)
 
 
 @pytest.mark.parametrize("n,k,hkv", [(1, 1, 4), (2, 1, 2), (64, 64, 4), (1025, 1, 4), (5775, 2887, 4), (65536, 32768, 1), (40000, 39999, 2),
@@ -193,7 +198,7 @@ def keys_prune(ops, ks, vs, k, past=0, keys=None, mode=0):
 
 @pytest.mark.parametrize("ci", range(len(SELECT_CASES)))
 def test_prune_keys_golden_select_cases(ops, golden_dir, ci):
-    """Same 18 reference cases as test_sumsq_select_bit_exact, through the engine's one-launch prune: identical index lists and rows."""
+    """Same reference cases as test_sumsq_select_bit_exact, through the engine's one-launch prune: identical index lists and rows."""
     data = np.load(os.path.join(golden_dir, "gv1_select.npz"))
     meta = json.load(open(os.path.join(golden_dir, "gv1_select.json")))[ci]
     dist, hkv, n, k = SELECT_CASES[ci]
@@ -207,7 +212,7 @@ def test_prune_keys_golden_select_cases(ops, golden_dir, ci):
     assert np.array_equal(idx, ref)
     if meta["norm_rows_differ"] == 0:
         assert np.array_equal(idx, data[f"c{ci}_ref_idx_stable"])
-    check_vs_raw_reference(idx, data, meta, ci, n, k)
+    check_vs_raw_reference(idx, data, meta, ci, n, k, kb)
     ti = torch.from_numpy(ref.astype(np.int64))
     assert torch.equal(kc[:, 3:3 + k].cpu(), keys[:, ti]) and torch.equal(vc[:, 3:3 + k].cpu(), vals[:, ti])
     assert torch.count_nonzero(kc[:, :3]).item() == 0 and torch.count_nonzero(kc[:, 3 + k:]).item() == 0
@@ -1145,3 +1150,30 @@ def test_query_scores_two_step_form_for_sharded_heads(ops):
         ops.query_scores_from_head_sums(torch.cat(parts, 0).contiguous(), hq, n, got, value_sumsq=vss, n_kv_total=hkv)
         torch.cuda.synchronize()
         assert torch.equal(got, want), by_v
+
+
+def test_torch_device_argsort_gives_the_stable_list_on_the_reference_expression(golden_dir):
+    """Pins the assumption behind "bit-exact kept indices": the reference computes `key_norms.argsort()[:k]` ON ITS DEVICE (utils.py:134-136),
+    and `ref_idx_stable` — the list the HIP select is held to — is that expression with a stable sort.  torch's device sort
+    (ATen/native/cuda/Sort.cu::sortKeyValueInplace, the same source for CUDA and ROCm builds) is bitonic (unstable) only for slices of
+    <= 32 elements when stable=False; above that it runs warp-merge / block-radix / segmented radix sorts, all stable.  Checked here on
+    this image's torch (ROCm build, MI355X) with the reference's own expression restated in torch: for every GV1 case with n > 32,
+    argsort() on the device == argsort(stable=True) on the device, and — where the device's bf16 norms equal the torch-CPU norms of the
+    fixture — the first k, sorted ascending, equal `ref_idx_stable` exactly."""
+    data = np.load(os.path.join(golden_dir, "gv1_select.npz"))
+    metas = json.load(open(os.path.join(golden_dir, "gv1_select.json")))
+    checked = same_norms = 0
+    for ci, (dist, hkv, n, k) in enumerate(SELECT_CASES):
+        if n <= 32:
+            continue
+        keys = make_keys(dist, hkv, n, metas[ci]["seed"]).cuda()                       # [1, Hkv, n, D] bf16, as the reference holds them
+        norms = keys[0].transpose(0, 1).flatten(1, 2).norm(2, dim=-1)                  # utils.py:134-135
+        order, order_stable = norms.argsort(), norms.argsort(stable=True)
+        assert torch.equal(order, order_stable), (ci, dist, n)
+        checked += 1
+        if np.array_equal(O.torch_bf16_to_bits(norms.cpu()), data[f"c{ci}_torch_norm_bits"]):
+            same_norms += 1
+            got = np.sort(order[:k].cpu().numpy()).astype(np.int32)
+            assert np.array_equal(got, data[f"c{ci}_ref_idx_stable"]), (ci, dist, n, k)
+    assert checked >= 15 and same_norms >= 10, (checked, same_norms)
+    print(f"device argsort == stable argsort on {checked} cases; device norms == fixture's torch-CPU norms on {same_norms} of them")

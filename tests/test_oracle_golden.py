@@ -36,7 +36,10 @@ def test_select_matches_reference(gv1, ci):
     tnorm = data[f"c{ci}_torch_norm_bits"]
     differ = np.nonzero(norms != tnorm)[0]
     # canonical summation order vs torch's: identical bf16 norms except the recorded rounding-boundary rows
-    assert len(differ) == m["norm_rows_differ"] <= 1
+    # (<= 1 on the natural distributions; the deliberately adversarial "rounding_boundary" case sits ON the fp32 -> bf16 tie: ~30 % of its rows)
+    assert len(differ) == m["norm_rows_differ"] and (len(differ) <= 1 or dist == "rounding_boundary")
+    if dist == "rounding_boundary":
+        assert len(differ) >= 100
     if len(differ):
         assert np.all(np.abs(norms[differ].astype(int) - tnorm[differ].astype(int)) == 1)
     idx = O.select_k_smallest(tnorm, k)            # select on the reference's own norms: isolates the tie rule
@@ -53,8 +56,32 @@ def test_select_matches_reference(gv1, ci):
         assert np.all(kept[tnorm < tau]) and not np.any(kept[tnorm > tau])
     assert len(set(idx) ^ set(ref)) == m["sym_diff_cpu_vs_stable"]
     # (3) full oracle path (own norms) agrees with the reference whenever the norms agree
+    own = O.select_k_smallest(norms, k)
     if len(differ) == 0:
-        assert np.array_equal(O.select_k_smallest(norms, k), data[f"c{ci}_ref_idx_stable"])
+        assert np.array_equal(own, data[f"c{ci}_ref_idx_stable"])
+    else:
+        check_select_where_norms_differ(own, data[f"c{ci}_ref_idx_stable"], norms, tnorm, k)
+
+
+def check_select_where_norms_differ(own, ref_stable, norms, tnorm, k):
+    """What "index parity" still pins when the canonical fp32 sum order (HIP kernel = oracle) rounds some rows' bf16 norm one ulp away from
+    torch's (utils.py:134-135 reduces in torch's vectorised order): the two kept lists may differ ONLY on rows whose norm differs, or
+    whose norm lies in the band between the two thresholds (tie class members included); every agreeing row strictly below both
+    thresholds is kept by both, strictly above both by neither."""
+    n = len(norms)
+    differ = norms != tnorm
+    assert np.all(np.abs(norms[differ].astype(int) - tnorm[differ].astype(int)) == 1)        # one bf16 ulp, never more
+    tau_o, tau_t = O.select_threshold(norms, k)[0], O.select_threshold(tnorm, k)[0]
+    lo, hi = min(tau_o, tau_t), max(tau_o, tau_t)
+    ko = np.zeros(n, bool); ko[own] = True
+    kt = np.zeros(n, bool); kt[ref_stable] = True
+    agree = ~differ
+    assert np.all(ko[agree & (norms < lo)]) and np.all(kt[agree & (norms < lo)])
+    assert not np.any(ko[agree & (norms > hi)]) and not np.any(kt[agree & (norms > hi)])
+    moved = ko != kt
+    in_band = ((norms >= lo) & (norms <= hi)) | ((tnorm >= lo) & (tnorm <= hi))
+    assert np.all(differ[moved] | in_band[moved]), np.nonzero(moved & ~differ & ~in_band)[0]
+    return int(moved.sum())
 
 
 def test_effective_k_table(golden_dir):
