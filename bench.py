@@ -317,20 +317,26 @@ def rccl_preflight(name, device, rank, world, backend):
     out = {"backend": backend, "world_size": world, "rows": n}
 
     def timed(label, fn, reps=5):
+        # a preflight step that throws is REPORTED (stderr + the record) and the run goes on: the preflight must never cost the line —
+        # if the layout's own collectives are broken too, the timed pass fails with the real error a few seconds later
         progress(f"preflight: {label}")
-        fn(); torch.cuda.synchronize(); dist.barrier()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            fn()
-        torch.cuda.synchronize()
-        t = torch.tensor([(time.perf_counter() - t0) / reps * 1e6], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        out[label] = round(float(t.item()), 1)
+        try:
+            fn(); torch.cuda.synchronize(); dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            t = torch.tensor([(time.perf_counter() - t0) / reps * 1e6], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            out[label] = round(float(t.item()), 1)
+        except Exception as e:
+            out[label.replace("_us", "_error")] = f"{type(e).__name__}: {e}"[:300]
+            progress(f"preflight step {label} FAILED: {type(e).__name__}: {e}")
 
     x = torch.randn(n, d, device=device, dtype=torch.float32).to(torch.bfloat16)
     timed("all_reduce_nd_bf16_us", lambda: dist.all_reduce(x))
     ss = torch.zeros(hkv, n, device=device, dtype=torch.float32)
-    ss_all = torch.empty(world, hkv, n, device=device, dtype=torch.float32)
+    ss_all = torch.empty(world * hkv, n, device=device, dtype=torch.float32)          # concatenated along dim 0: the form gloo AND nccl accept
     timed("all_gather_key_sums_us", lambda: dist.all_gather_into_tensor(ss_all, ss))
     m2 = 2 * -(-n // (2 * world))
     blk = torch.zeros(2 * spec.n_kv_heads * m2 * D * 2 + spec.n_kv_heads * m2 * 4, device=device, dtype=torch.uint8)
@@ -343,7 +349,8 @@ def rccl_preflight(name, device, rank, world, backend):
         for r_ in dist.batch_isend_irecv(ops_):
             r_.wait()
     timed("p2p_ring_handoff_nd_bf16_us", ring)
-    out["all_reduce_nd_bf16_gb_s_algorithmic"] = round(x.numel() * 2 / (out["all_reduce_nd_bf16_us"] * 1e-6) / 1e9, 1)
+    if "all_reduce_nd_bf16_us" in out:
+        out["all_reduce_nd_bf16_gb_s_algorithmic"] = round(x.numel() * 2 / (out["all_reduce_nd_bf16_us"] * 1e-6) / 1e9, 1)
     progress(f"preflight done: {out}")
     return out
 

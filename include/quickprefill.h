@@ -47,9 +47,10 @@ typedef enum qp_status {
 /* device: HIP ordinal.  One context per device/process (one process per GPU under tensor parallel). */
 int qp_create(qp_ctx** out, int device);
 /* Developer A/B switches (tools/bench_attn.py, the kernel-form parity tests): "attn_variant" (0 production; 1 v1, 2 no kv split, 3 no
- * XCD map, 4 s4, 7 / 8 = 4- / 8-wave s6), "attn_force_split", "s6_prio", "s6_early_out", "decode_attn_valu", "attn_debug".  Process-wide.
+ * XCD map, 4 s4, 7 / 8 = 4- / 8-wave s6), "attn_force_split", "attn_flat" (-1 by cost, 0 never, 1 whenever eligible), "s6_prio", "s6_early_out", "decode_attn_valu", "attn_debug".
+ * Process-wide.
  * The launch paths never read the environment: the table is filled once at first use from QP_ATTN_VARIANT, QP_ATTN_FORCE_SPLIT,
- * QP_S6_PRIO, QP_S6_EARLY_OUT, QP_DECODE_ATTN, QP_ATTN_DEBUG and changes only through this call.  Not part of the reference seams. */
+ * QP_ATTN_FLAT, QP_S6_PRIO, QP_S6_EARLY_OUT, QP_DECODE_ATTN, QP_ATTN_DEBUG and changes only through this call.  Not part of the reference seams. */
 int qp_dev_switch(const char* name, int value);
 void qp_destroy(qp_ctx* ctx);
 const char* qp_last_error(void);

@@ -37,6 +37,7 @@ qp_dev_switches& qp_dev() {
     d->s6_early_out = geti("QP_S6_EARLY_OUT", 3) & 3;
     { const char* e = getenv("QP_DECODE_ATTN"); d->decode_attn_valu = (e && e[0] == 'v') ? 1 : 0; }
     d->attn_debug = getenv("QP_ATTN_DEBUG") != nullptr ? 1 : 0;
+    d->attn_flat = geti("QP_ATTN_FLAT", -1);
     return d;
   }();
   return *sw;
@@ -59,6 +60,7 @@ int qp_dev_switch(const char* name, int value) {
   else if (k == "s6_early_out") d.s6_early_out = value & 3;
   else if (k == "decode_attn_valu") d.decode_attn_valu = value ? 1 : 0;
   else if (k == "attn_debug") d.attn_debug = value ? 1 : 0;
+  else if (k == "attn_flat") d.attn_flat = value < 0 ? -1 : (value ? 1 : 0);
   else return qp_fail(QP_ERR_INVALID, "qp_dev_switch: unknown switch '%s'", name);
   return QP_OK;
 }

@@ -32,9 +32,42 @@ struct AttnParams {
   // query sub-range (group-token parallel ranks): q/out hold rows [q_row0, q_row0+nq) of the group's n new tokens
   int q_row0; int nq;
   int qb_rows;                  // query rows per workgroup / work item (128 or 256); partials hold partial_floats(qb_rows) floats
+  // "flat" split (round 5; stream-K for attention): per kv head the items' key tiles are laid end to end, heaviest item first, and cut into
+  // `flat_pieces` equal ranges — one workgroup per range, whatever item boundary falls inside it.  A workgroup walks its range segment by
+  // segment (segment = the part of ONE item inside the range): a segment that covers its whole item writes the output, any other one
+  // leaves a partial in slot (kv head, piece, first segment ? 0 : 1) for attn_combine_flat_kernel.  0 = the n_whole / nsplit scheme above.
+  int flat_pieces;
+  long long flat_total;         // key tiles of all items of one kv head (sum of attn_item_tiles)
   int variant;                  // host side only: the developer switch attn_variant this launch was planned under
   int prio_mode;                // s6, 8-wave form: 1 = s_setprio 1 for waves 4-7 (the younger half), 2 = for waves 0-3, 0 = none
 };
+
+// key tiles item `item` walks: the prefix tiles + the causal tiles up to the last row of its q block (the same count the kernels use)
+__host__ __device__ inline int attn_qb_tiles(const AttnParams& p, int qb) {
+  int blk_end = qb * p.qb_rows + p.qb_rows;
+  if (blk_end > p.nq) blk_end = p.nq;
+  blk_end += p.q_row0;
+  return (int)((p.P + kKV - 1) / kKV) + (blk_end + kKV - 1) / kKV;
+}
+// flat position f (in tiles, items heaviest = latest q block first, `group` items per q block) -> item index, *off = tiles into that item
+__host__ __device__ inline int attn_flat_locate(const AttnParams& p, long long f, int* off) {
+  int item = 0;
+  for (int qb = p.nqb - 1; qb >= 0; --qb) {
+    const int nt = attn_qb_tiles(p, qb);
+    const long long cls = (long long)nt * p.group;
+    if (f < cls) { *off = (int)(f % nt); return item + (int)(f / nt); }
+    f -= cls; item += p.group;
+  }
+  *off = 0;
+  return item;                                            // == p.items: past the end
+}
+__host__ __device__ inline long long attn_flat_item_start(const AttnParams& p, int item) {
+  long long f = 0;
+  const int cls_of = item / p.group;
+  for (int c = 0; c < cls_of; ++c) f += (long long)attn_qb_tiles(p, p.nqb - 1 - c) * p.group;
+  return f + (long long)attn_qb_tiles(p, p.nqb - 1 - cls_of) * (item % p.group);
+}
+__host__ __device__ inline long long attn_flat_bound(const AttnParams& p, int j) { return (long long)j * p.flat_total / p.flat_pieces; }
 
 __device__ __forceinline__ bf16x8_t lds_read_b128(const unsigned char* lds, int off) {
   return *reinterpret_cast<const bf16x8_t*>(lds + off);

@@ -310,6 +310,77 @@ __global__ __launch_bounds__(64) void attn_combine_kernel(AttnParams p) {
   }
 }
 
+// Flat split (AttnParams::flat_pieces): merges the partial segments of one item.  An item whose tiles [F0, F0 + nt) lie in pieces
+// j0..j1 has one part per piece; the part in piece j sits in slot 0 of that piece when the item is the piece's FIRST segment, else in
+// slot 1 (a later segment that is partial is always the piece's last).  Items covered by a single whole-item segment were written by
+// the producer and exit here.  Same thread geometry and accumulation as attn_combine_kernel.
+__global__ __launch_bounds__(64) void attn_combine_flat_kernel(AttnParams p) {
+  const int kvh = blockIdx.x / p.items, item = blockIdx.x % p.items;
+  const int lane = threadIdx.x, wave = blockIdx.y, db = blockIdx.z, hi = lane >> 5;
+  const int qb = p.nqb - 1 - item / p.group;
+  const int head = kvh * p.group + item % p.group;
+  if (qb * p.qb_rows + wave * 32 >= p.nq) return;
+  const int nt = attn_qb_tiles(p, qb);
+  const long long F0 = attn_flat_item_start(p, item), F1 = F0 + nt;
+  auto piece_of = [&](long long f) {
+    int j = (int)(f * p.flat_pieces / p.flat_total);
+    while (j + 1 < p.flat_pieces && attn_flat_bound(p, j + 1) <= f) ++j;
+    while (j > 0 && attn_flat_bound(p, j) > f) --j;
+    return j;
+  };
+  const int j0 = piece_of(F0), j1 = piece_of(F1 - 1);
+  if (j0 == j1 && attn_flat_bound(p, j0) <= F0 && attn_flat_bound(p, j0 + 1) >= F1) return;     // one whole-item segment: output already written
+  const int parts = j1 - j0 + 1;                            // <= kMaxSplit (checked by the planner)
+  const int qi = qb * p.qb_rows + wave * 32 + (lane & 31);
+  const int pfl = partial_floats(p.qb_rows), o_floats = p.qb_rows * 128;
+  int dummy;
+  const int first_item_of_j0 = attn_flat_locate(p, attn_flat_bound(p, j0), &dummy);
+  auto slot_base = [&](int s) {                             // part s lives in piece j0 + s
+    const int slot = (s == 0 && first_item_of_j0 != item) ? 1 : 0;
+    return p.ws + (((int64_t)kvh * p.flat_pieces + (j0 + s)) * 2 + slot) * pfl;
+  };
+  float ms[kMaxSplit], f[kMaxSplit];
+  float M = -1e30f;
+#pragma unroll
+  for (int s = 0; s < kMaxSplit; ++s) {
+    ms[s] = -1e30f; f[s] = 0.f;
+    if (s < parts) {
+      const float* wm = slot_base(s) + o_floats + wave * 128 + lane;
+      ms[s] = wm[0]; f[s] = wm[64];
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < kMaxSplit; ++s) M = fmaxf(M, ms[s]);
+  float L = 0.f;
+#pragma unroll
+  for (int s = 0; s < kMaxSplit; ++s) {
+    const float e = __builtin_amdgcn_exp2f((ms[s] - M) * p.c);
+    L += f[s] * e;
+    f[s] = e;
+  }
+  f32x4_t acc[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int s = 0; s < kMaxSplit; ++s) {
+    if (s < parts) {
+      const f32x4_t* wo = reinterpret_cast<const f32x4_t*>(slot_base(s)) + (wave * 16 + db * 4) * 64 + lane;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] += wo[r * 64] * f[s];
+    }
+  }
+  if (qi < p.nq) {
+    const float inv = 1.0f / L;
+    uint2* op = p.out + ((int64_t)qi * p.hq + head) * 32;
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+      const f32x4_t a = acc[r4];
+      bf16x4_t v = {(__bf16)(a[0] * inv), (__bf16)(a[1] * inv), (__bf16)(a[2] * inv), (__bf16)(a[3] * inv)};
+      op[db * 8 + r4 * 2 + hi] = __builtin_bit_cast(uint2, v);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // v1: first correct kernel of round 1 (clamped global loads, 4 inlined tile bodies, always-rescale, plain 2-D grid).
 // Kept as an independent implementation: QP_ATTN_VARIANT=1 cross-checks the production kernel in tools/bench_attn.py,
@@ -549,6 +620,37 @@ AttnPlan plan_cached(int64_t n, int64_t P, int hq, int hkv, int cus, int split_m
   return a;
 }
 
+// Flat (stream-K) plan for one workgroup form: `pieces` = the resident workgroup slots of a kv head (ONE round, every slot the same
+// number of tiles), cost in the units of plan_items (tile steps).  Not eligible (cost = inf) when a piece would be shorter than 16 tiles
+// (prologue-dominated), an item would be spread over more than kMaxSplit pieces, or the flat positions would not fit 31 bits.
+struct FlatPlan { int pieces; long long total; double cost; };
+FlatPlan plan_flat(const AttnParams& base, int cus, int wg_per_cu, int qb_rows, bool forced) {
+  AttnParams q = base;
+  q.qb_rows = qb_rows; q.nqb = (int)((q.nq + qb_rows - 1) / qb_rows); q.items = q.nqb * q.group;
+  FlatPlan f; f.pieces = 0; f.total = 0; f.cost = 1e300;
+  const int slots = cus * wg_per_cu / q.hkv > 0 ? cus * wg_per_cu / q.hkv : 1;
+  long long W = 0; int nt_max = 0;
+  for (int qb = 0; qb < q.nqb; ++qb) { const int nt = attn_qb_tiles(q, qb); W += (long long)nt * q.group; if (nt > nt_max) nt_max = nt; }
+  if (W <= 0 || W >= (1ll << 30)) return f;
+  const double len = (double)W / slots;
+  if (len < (forced ? 2.0 : 16.0) || nt_max / len + 2.0 > (double)kMaxSplit) return f;   // forced (tests, A/B): any range of >= 2 tiles
+  if (!forced) {
+    // Measured (tools/bench_attn_flat.py, profiles/r5_attn_flat_ab.txt): equal tile ranges start at a different key offset in every
+    // workgroup, so the workgroups of an XCD no longer stream the SAME K/V tiles at the same time and the L2 sharing the item-granular
+    // plan lives on is gone.  The flat form therefore only wins while all K/V rows of the launch sit in the Infinity Cache (<= 96 MB:
+    // +4 % at n = 960..1024 over 20-50 k prefix rows; -3 % at 123 MB, -5 % at 216 k rows, -15 % on the 1-hour video's steady state) and
+    // while a range holds at most two segments (items <= slots; with more, the per-segment prologues cost more than the balance gains:
+    // -7 % at n = 2880).
+    const double kv_bytes = (double)(q.P + q.n) * q.hkv * 2.0 * 256.0;
+    if (kv_bytes > 96e6 || q.items > slots) return f;
+  }
+  const double c0 = wg_per_cu == 1 ? 8.0 : 4.0, tstep = qb_rows == 256 ? 0.95 : 1.0;
+  const double segs = 1.0 + (double)q.items / slots;      // item boundaries inside a piece, on average, + 1
+  f.pieces = slots; f.total = W;
+  f.cost = (len + c0 * (segs < 2.0 ? 2.0 : segs + 1.0) + 1.0 + 3.0) * tstep;   // + partial stores, + combine launch
+  return f;
+}
+
 }  // namespace
 
 size_t qp_attn_workspace_bytes_impl(const qp_ctx* ctx, int64_t nq, int64_t prefix_len, int hq, int hkv) {
@@ -559,6 +661,13 @@ size_t qp_attn_workspace_bytes_impl(const qp_ctx* ctx, int64_t nq, int64_t prefi
     const size_t b = (size_t)hkv * (size_t)(a.items - a.n_whole) * (size_t)a.nsplit * partial_floats(rows) * sizeof(float);
     if (b > need) need = b;
   }
+  // the flat (stream-K) form: two partial slots per resident workgroup, whatever the shape (69 MB on an unmasked MI355X)
+  for (int form = 0; form < 2; ++form) {
+    const int wg = form == 0 ? 2 : 1, rows = form == 0 ? 128 : 256;
+    const int slots = ctx->cus * wg / hkv > 0 ? ctx->cus * wg / hkv : 1;
+    const size_t b = (size_t)hkv * (size_t)slots * 2 * partial_floats(rows) * sizeof(float);
+    if (b > need) need = b;
+  }
   return need + 256;
 }
 
@@ -567,6 +676,7 @@ int qp_launch_prefill_attn(const qp_ctx* ctx, const void* q, const void* k_prefi
                            int64_t new_head_stride, int64_t n, int64_t q_row0, int64_t nq, int hq, int hkv, float scale, void* out,
                            void* workspace, size_t workspace_bytes, hipStream_t s) {
   AttnParams p;
+  p.flat_pieces = 0; p.flat_total = 0; p.variant = 0;
   p.q = (const uint4*)q; p.out = (uint2*)out;
   p.kp = (const uint4*)k_prefix; p.vp = (const uint4*)v_prefix; p.pre_hs16 = prefix_head_stride / 8; p.P = prefix_len;
   p.kn = (const uint4*)k_new; p.vn = (const uint4*)v_new; p.new_hs16 = new_head_stride / 8; p.n = n;
@@ -598,6 +708,32 @@ int qp_launch_prefill_attn(const qp_ctx* ctx, const void* q, const void* k_prefi
     a = plan_cached(nq, prefix_len + q_row0, hq, hkv, ctx->cus, split_mode, 2, 128);
     const AttnPlan b = plan_cached(nq, prefix_len + q_row0, hq, hkv, ctx->cus, split_mode, 1, 256);
     if (b.cost < a.cost) a = b;
+  }
+  // flat (stream-K) split: taken when one round of equal tile ranges beats the item-granular plan by > 3 % in the same cost model —
+  // short groups over long prefixes (n <= 1024: 28-56 equal items for 64-128 slots, where an item-granular split leaves 1/8 of the
+  // chip idle).  Developer switch attn_flat: 0 never, 1 whenever eligible, -1 (default) by cost.  s6 forms only; needs the workspace.
+  p.flat_pieces = 0; p.flat_total = 0;
+  const int flat_mode = dev.attn_flat.load(std::memory_order_relaxed);
+  if (flat_mode != 0 && split_mode == 1 && variant != 4 && variant != 9 && variant != 10) {
+    FlatPlan best; best.pieces = 0; best.cost = 1e300; int best_rows = 0;
+    for (int form = 0; form < 2; ++form) {
+      const int wg = form == 0 ? 2 : 1, rows_f = form == 0 ? 128 : 256;
+      if ((variant == 7 && form == 1) || (variant == 8 && form == 0)) continue;
+      const FlatPlan f = plan_flat(p, ctx->cus, wg, rows_f, flat_mode == 1);
+      if (f.pieces > 0 && f.cost < best.cost) { best = f; best_rows = rows_f; }
+    }
+    const size_t need_f = best.pieces > 0 ? (size_t)hkv * best.pieces * 2 * partial_floats(best_rows) * sizeof(float) : 0;
+    if (best.pieces > 0 && need_f <= workspace_bytes && (flat_mode == 1 || best.cost < 0.97 * a.cost)) {
+      p.qb_rows = best_rows; p.nqb = (int)((nq + best_rows - 1) / best_rows);
+      p.items = p.nqb * p.group; p.n_whole = p.items; p.nsplit = 1;
+      p.flat_pieces = best.pieces; p.flat_total = best.total;
+      const bool xcd_f = (hkv <= 8 && 8 % hkv == 0 && variant != 3);
+      qp_launch_attn_s6(p, xcd_f, (unsigned)best.pieces, s);
+      int rc_f = qp_check_launch("prefill_attn(flat)");
+      if (rc_f) return rc_f;
+      attn_combine_flat_kernel<<<dim3((unsigned)(hkv * p.items), (unsigned)(best_rows / 32), 4), 64, 0, s>>>(p);
+      return qp_check_launch("prefill_attn(flat combine)");
+    }
   }
   const int rows = a.rows;
   p.qb_rows = rows; p.nqb = (int)((nq + rows - 1) / rows);
@@ -643,6 +779,7 @@ int qp_launch_vit_attn(const qp_ctx* ctx, const void* qkv, int64_t n_seq, int64_
   (void)ctx;
   constexpr int D = 80;
   AttnParams p;
+  p.flat_pieces = 0; p.flat_total = 0; p.variant = 0;
   const uint4* base = (const uint4*)qkv;
   const int row16 = 3 * heads * D / 8;
   p.q = base; p.kp = base + heads * D / 8; p.vp = base + 2 * heads * D / 8; p.kn = p.kp; p.vn = p.vp;

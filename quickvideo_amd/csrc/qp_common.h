@@ -24,6 +24,7 @@ struct qp_dev_switches {
   std::atomic<int> s6_early_out{3};        // QP_S6_EARLY_OUT: bit 0 rows past the last query, bit 1 causal diagonal
   std::atomic<int> decode_attn_valu{0};    // QP_DECODE_ATTN=valu: first (VALU) form of the single-query decode attention
   std::atomic<int> attn_debug{0};          // QP_ATTN_DEBUG: print every new attention plan
+  std::atomic<int> attn_flat{-1};          // QP_ATTN_FLAT: flat (stream-K) split of the attention launch: -1 by cost (default), 0 never, 1 whenever eligible
 };
 qp_dev_switches& qp_dev();
 

@@ -17,7 +17,7 @@ def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
 
 
-DEV_SWITCH_DEFAULTS = {"attn_variant": 0, "attn_force_split": 0, "s6_prio": 0, "s6_early_out": 3, "decode_attn_valu": 0, "attn_debug": 0}
+DEV_SWITCH_DEFAULTS = {"attn_variant": 0, "attn_force_split": 0, "s6_prio": 0, "s6_early_out": 3, "decode_attn_valu": 0, "attn_debug": 0, "attn_flat": -1}
 
 
 @pytest.fixture

@@ -848,6 +848,46 @@ def test_prefill_attn_every_kernel_form(ops, variant, dev_switch):
         assert (out.float() - full[lo:hi].float()).abs().max().item() <= 4e-3
 
 
+@pytest.mark.parametrize("variant", ["0", "7", "8"])
+def test_prefill_attn_flat_split(ops, variant, dev_switch):
+    """The flat (stream-K) split of round 5: per kv head the items' key tiles laid end to end and cut into one equal range per resident
+    workgroup, segments of up to three items per workgroup, partials merged by attn_combine_flat_kernel.  Forced (attn_flat = 1) in both
+    workgroup forms over the shapes it is meant for (short groups over long prefixes: cfg4ref / cfg5's rank shape), ragged ones, sub-ranges of
+    the queries, the rescale branch and a causal-dominated launch where ranges cover several whole items."""
+    dev_switch("attn_flat", 1)
+    dev_switch("attn_variant", int(variant))
+    for (n, P, hq, hkv, staged) in [(960, 5000, 28, 4, True), (960, 9000, 8, 1, False), (1000, 3000, 7, 1, True), (333, 6000, 4, 2, False),
+                                    (2240, 2500, 28, 4, True), (1500, 0, 8, 2, False), (257, 4097, 12, 4, True)]:
+        attn_case(ops, n, P, hq, hkv, staged, seed=n * 5 + P + int(variant))
+    attn_case(ops, 600, 5000, 4, 2, True, seed=9, spike=True)
+    n, P, hq, hkv = 900, 7000, 8, 2                        # query sub-ranges tile the full result
+    g = torch.Generator(device="cuda"); g.manual_seed(21)
+    q = torch.randn(n, hq, D, generator=g, device="cuda").to(torch.bfloat16)
+    k = torch.randn(hkv, P + n, D, generator=g, device="cuda").to(torch.bfloat16)
+    v = torch.randn(hkv, P + n, D, generator=g, device="cuda").to(torch.bfloat16)
+    full = torch.empty(n, hq, D, dtype=torch.bfloat16, device="cuda")
+    ops.prefill_attn(q, k, v, (P + n) * D, P, k[:, P:], v[:, P:], (P + n) * D, n, hq, hkv, D, D ** -0.5, full)
+    dev_switch("attn_flat", 0)
+    classic = torch.empty_like(full)
+    ops.prefill_attn(q, k, v, (P + n) * D, P, k[:, P:], v[:, P:], (P + n) * D, n, hq, hkv, D, D ** -0.5, classic)
+    assert (full.float() - classic.float()).abs().max().item() <= 4e-3               # same math, different partial boundaries
+    dev_switch("attn_flat", 1)
+    for lo, hi in [(0, 300), (300, 650), (650, 900)]:
+        out = torch.zeros(hi - lo, hq, D, dtype=torch.bfloat16, device="cuda")
+        ops.prefill_attn(q[lo:hi].contiguous(), k, v, (P + n) * D, P, k[:, P:], v[:, P:], (P + n) * D, n, hq, hkv, D, D ** -0.5, out,
+                         q_row0=lo, nq=hi - lo)
+        assert (out.float() - full[lo:hi].float()).abs().max().item() <= 4e-3
+    # the early-out (waves stop at their last visible tile) stays bit-neutral under the flat split
+    outs = []
+    for eo in (0, 3):
+        dev_switch("s6_early_out", eo)
+        o = torch.full((n, hq, D), 7.0, dtype=torch.bfloat16, device="cuda")
+        ops.prefill_attn(q, k, v, (P + n) * D, P, k[:, P:], v[:, P:], (P + n) * D, n, hq, hkv, D, D ** -0.5, o)
+        torch.cuda.synchronize()
+        outs.append(o)
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+
+
 def test_prefill_attn_forms_agree_at_full_size(ops, dev_switch):
     """s4, s6<4> and s6<8> compute the same math in a different instruction order: outputs agree to bf16 rounding at cfg2 size."""
     n, P, hq, hkv = 5760, 8647, 28, 4
