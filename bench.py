@@ -889,9 +889,9 @@ def pipeline_leg(name, eng, device, modes=("overlapped", "sequential"), warm_vid
 
 def peaked_attention_leg(ops, device):
     """The dominant kernel at the metric's steady-state launch (group 228 of the 1-hour video: n = 2240 new tokens over a 255 367-row
-    prefix, 28/4 heads) with the softmax's input scaled to score sigma 0.05 / 1 / 4.  The random-weight benchmark's softmax is
-    nearly uniform (sigma ~ 0.05): that is the FAST end — peaked rows move the running maximum more often and toggle more bits.
-    Trained checkpoints sit at sigma >= 1, so this block is the realistic end of `roofline`."""
+    prefix, 28/4 heads) with the softmax's input scaled to score sigma 0.05 / 1 / 4: peaked rows move the running maximum more often and toggle more
+    bits.  The benchmark's own workload sits at sigma = 1.4 at every layer (measured in round 5: tools/probe/probe_score_sigma.py,
+    profiles/r5_score_sigma_cfg4s.json — rounds 3-4 assumed 0.05), i.e. at the peakedness of a trained checkpoint (sigma >= 1)."""
     n, P, hq, hkv, D = 2240, 255367, 28, 4, 128
     g = torch.Generator(device=device); g.manual_seed(n + P)
     k = torch.randn(hkv, P + n, D, generator=g, device=device).to(torch.bfloat16)
@@ -915,7 +915,7 @@ def peaked_attention_leg(ops, device):
     return {"shape": f"n={n} new tokens over a {P}-row pruned prefix, {hq} q / {hkv} kv heads (cfg4 steady state)", "by_score_sigma": res,
             "timing": "HIP events, 20 back-to-back launches per sigma after 6 warm-up launches, N(0,1) keys/values, queries scaled so that "
                       "q.k/sqrt(D) ~ N(0, sigma^2)",
-            "note": "sigma 0.05 ~ the random-weight synthetic benchmark (near-uniform softmax, the fast end); real checkpoints: sigma >= 1"}
+            "note": "the benchmark's own scores have sigma = 1.4 per query row at every layer (profiles/r5_score_sigma_cfg4s.json); real checkpoints: sigma >= 1"}
 
 
 # first-token ids of earlier runs of the SAME command (seeded weights and inputs: the token is deterministic up to the GEMM algorithm the

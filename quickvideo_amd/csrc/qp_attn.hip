@@ -661,12 +661,26 @@ size_t qp_attn_workspace_bytes_impl(const qp_ctx* ctx, int64_t nq, int64_t prefi
     const size_t b = (size_t)hkv * (size_t)(a.items - a.n_whole) * (size_t)a.nsplit * partial_floats(rows) * sizeof(float);
     if (b > need) need = b;
   }
-  // the flat (stream-K) form: two partial slots per resident workgroup, whatever the shape (69 MB on an unmasked MI355X)
-  for (int form = 0; form < 2; ++form) {
-    const int wg = form == 0 ? 2 : 1, rows = form == 0 ? 128 : 256;
-    const int slots = ctx->cus * wg / hkv > 0 ? ctx->cus * wg / hkv : 1;
-    const size_t b = (size_t)hkv * (size_t)slots * 2 * partial_floats(rows) * sizeof(float);
-    if (b > need) need = b;
+  // the flat (stream-K) form — two partial slots per resident workgroup (69 MB on an unmasked MI355X) — only for the shapes the launcher
+  // would take it for (by cost, or forced by the developer switch): every other shape keeps the size it had before round 5, and a launch
+  // that finds less workspace than the flat form needs simply runs the item-granular plan
+  const int flat_mode = qp_dev().attn_flat.load(std::memory_order_relaxed);
+  if (flat_mode != 0 && hq % hkv == 0) {
+    AttnParams q;
+    q.P = prefix_len; q.n = nq; q.nq = (int)nq; q.q_row0 = 0; q.hq = hq; q.hkv = hkv; q.group = hq / hkv;
+    double classic = 1e300;
+    for (int cfg = 1; cfg < 3; ++cfg) {
+      const AttnPlan a = plan_cached(nq, prefix_len, hq, hkv, ctx->cus, 1, cfg == 1 ? 2 : 1, cfg == 1 ? 128 : 256);
+      if (a.cost < classic) classic = a.cost;
+    }
+    for (int form = 0; form < 2; ++form) {
+      const int wg = form == 0 ? 2 : 1, rows = form == 0 ? 128 : 256;
+      const FlatPlan f = plan_flat(q, ctx->cus, wg, rows, flat_mode == 1);
+      if (f.pieces > 0 && (flat_mode == 1 || f.cost < 0.97 * classic)) {
+        const size_t b = (size_t)hkv * (size_t)f.pieces * 2 * partial_floats(rows) * sizeof(float);
+        if (b > need) need = b;
+      }
+    }
   }
   return need + 256;
 }
