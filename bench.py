@@ -106,10 +106,66 @@ def progress(msg):
 
 
 _JSON_FD = None
+_GUARD = None
+
+
+class LineGuard:
+    """The line survives the death of the process that measured it.  A child forked BEFORE the first HIP call (rank 0 only) holds the
+    original stdout and the read end of a pipe; the bench sends it the line as soon as the timed pass is done (`provisional`) and
+    again when everything else has run (`final`).  The child prints the LAST line it received when the pipe closes — because the bench
+    finished, or because it died in an auxiliary leg (a native abort inside RCCL's watchdog or a profiler child is not a Python
+    exception; `guarded()` cannot catch it) — so stdout still carries exactly one line, and it is the graded number either way."""
+
+    def __init__(self, json_fd):
+        import signal
+        r, w = os.pipe()
+        pid = os.fork()
+        if pid == 0:                                   # the guard: no torch call, no HIP, no Python threads — read, print once, leave
+            try:
+                os.close(w)
+                for sig in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP):
+                    signal.signal(sig, signal.SIG_IGN)     # a launcher tearing the job down must not take the line with it
+                buf = b""
+                while True:
+                    chunk = os.read(r, 65536)
+                    if not chunk:
+                        break
+                    buf += chunk
+                    if buf.count(b"\n") > 1:               # keep only the last complete line (+ an incomplete tail)
+                        head, _, tail = buf.rpartition(b"\n")
+                        buf = head.rpartition(b"\n")[2] + b"\n" + tail
+                line = buf.rpartition(b"\n")[0].rpartition(b"\n")[2]
+                if line:
+                    data = line + b"\n"
+                    while data:
+                        data = data[os.write(json_fd, data):]
+            finally:
+                os._exit(0)
+        os.close(r)
+        self.w, self.pid = w, pid
+
+    def send(self, text):
+        data = (text + "\n").encode()
+        while data:
+            data = data[os.write(self.w, data):]
+
+    def final(self, text):
+        self.send(text)
+        os.close(self.w)
+        try:
+            os.waitpid(self.pid, 0)                    # the line is on stdout when this returns (the watchdog path _exit()s right after)
+        except ChildProcessError:
+            pass
 
 
 def emit_line(text):
-    """The JSON line -> the process's ORIGINAL stdout (see main(): fd 1 itself is redirected to stderr)."""
+    """The JSON line -> the process's ORIGINAL stdout (see main(): fd 1 itself is redirected to stderr), through the guard process
+    when there is one."""
+    global _GUARD
+    if _GUARD is not None:
+        g, _GUARD = _GUARD, None
+        g.final(text)
+        return
     data = (text + "\n").encode()
     if _JSON_FD is None:
         sys.stdout.write(text + "\n"); sys.stdout.flush()
@@ -1236,8 +1292,8 @@ def host_contention_leg(eng, device):
                    "host core (a busy loop in its own interpreter: what a decoder pool or another job does to the machine) for the whole leg; ...and_one_python_thread = the same "
                    "plus ONE pure-Python spinner that holds the interpreter lock between switch intervals (what the reference's HF-processor "
                    "thread does); jpeg_folder = frames decoded from 720 JPEG files by ImageFolderVideoReader under the saturated host.  The "
-                   "product's own producer is a Python thread whose only work is next(reader) + a GIL-free memcpy + three stream-ordered "
-                   "enqueues (DESIGN 1); kernel-launch entry points are bound through ctypes.PyDLL (lock held across the microsecond call)")
+                   "product's own producer is a native thread of the library (qp_frame_ring_*) whose callback runs next(reader) straight into the pinned "
+                   "slot (DESIGN 1); kernel-launch entry points are bound through ctypes.PyDLL (lock held across the microsecond call)")
     return out
 
 
@@ -1418,10 +1474,15 @@ def main():
     # stdout carries exactly ONE line (the driver's contract).  Native libraries print there too — RCCL writes a five-line version
     # banner to C stdout when its first communicator is created (seen under --nccl-preflight) — so file descriptor 1 is pointed at
     # stderr for the whole run and the JSON line is written to the saved original.
-    global _JSON_FD
+    global _JSON_FD, _GUARD
     sys.stdout.flush()
     _JSON_FD = os.dup(1)
     os.dup2(2, 1)
+    if rank == 0 and os.environ.get("QP_BENCH_NO_GUARD") != "1":
+        try:
+            _GUARD = LineGuard(_JSON_FD)              # forked here: no HIP call has been made yet
+        except OSError as e:
+            progress(f"line guard not started ({e}): the line is printed by this process only")
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # QP_BENCH_SINGLE_DEVICE=1: developer hook to exercise the multi-process path on a 1-GPU box (all ranks on cuda:0, gloo
@@ -1495,20 +1556,6 @@ def main():
         return
     attach_traffic(res.get("roofline"), name, world)
     attach_hbm_kernels(res, name, world)
-    if world == 1 and res.get("roofline") and not args.lean and not args.no_pmc:
-        live = collect_attention_traffic(name, ctx["spec"], ctx["plan"], ctx["cfg"])
-        if live:
-            r_ = res["roofline"]
-            r_["traffic_committed_builder_box"] = {"traffic": r_.get("traffic"), "source": r_.get("traffic_source")}
-            r_["traffic"], r_["traffic_source"], r_["traffic_over_algorithmic"] = live["traffic"], live["source"], live["traffic_over_algorithmic"]
-            r_["traffic_window"] = {k: live[k] for k in ("window", "algorithmic_bytes_this_launch", "fetch_size_kb", "write_size_kb")}
-            if live.get("prune") and res.get("roofline_prune"):
-                rp = res["roofline_prune"]
-                rp["traffic_committed_builder_box"] = {"traffic": rp.get("traffic"), "source": rp.get("traffic_source")}
-                rp.update(live["prune"])
-                rp["traffic_source"] = live["source"]
-            progress("attention HBM traffic collected in-run (rocprofv3 --pmc)")
-
     leg_errors = {}
 
     def guarded(key, fn, *a, **kw):
@@ -1527,9 +1574,16 @@ def main():
             "cpu_baseline": None}
     emitted = threading.Lock()
 
-    def emit(note=None):
-        """The ONE JSON line (rank 0).  Called once: at the end, or by the watchdog when an auxiliary leg overruns its budget."""
-        if rank != 0 or not emitted.acquire(blocking=False):
+    def emit(note=None, provisional=False):
+        """The ONE JSON line (rank 0).  Called once: at the end, or by the watchdog when an auxiliary leg overruns its budget.
+        provisional=True: the line as it stands goes to the guard process only (LineGuard), which prints it if this process dies."""
+        if rank != 0:
+            return
+        if provisional:
+            if _GUARD is None:
+                return
+            note = "auxiliary legs did not finish (the bench process ended early): line printed by its guard process; timed pass and roofline are complete"
+        elif not emitted.acquire(blocking=False):
             return
         plan, spec = ctx["plan"], ctx["spec"]
         plan_desc = {"groups": len(plan.tokens), "tokens_per_group": plan.tokens[-1], "prefill_tokens": ctx["tokens"],
@@ -1604,8 +1658,29 @@ def main():
             note = ((note + "; ") if note else "") + "auxiliary legs failed (not measured): " + ", ".join(sorted(leg_errors))
         if note:
             out["note"] = note
+        if provisional:
+            _GUARD.send(compact_line(out, None))
+            return
         full_path = write_full_record(out)
         emit_line(compact_line(out, full_path))
+
+    # from here on the graded number exists: hand it to the guard process before anything else runs (PMC child processes, the
+    # front-end leg over RCCL, the CPU baseline), and again whenever the line gains a block
+    emit(provisional=True)
+    if world == 1 and res.get("roofline") and not args.lean and not args.no_pmc:
+        live = collect_attention_traffic(name, ctx["spec"], ctx["plan"], ctx["cfg"])
+        if live:
+            r_ = res["roofline"]
+            r_["traffic_committed_builder_box"] = {"traffic": r_.get("traffic"), "source": r_.get("traffic_source")}
+            r_["traffic"], r_["traffic_source"], r_["traffic_over_algorithmic"] = live["traffic"], live["source"], live["traffic_over_algorithmic"]
+            r_["traffic_window"] = {k: live[k] for k in ("window", "algorithmic_bytes_this_launch", "fetch_size_kb", "write_size_kb")}
+            if live.get("prune") and res.get("roofline_prune"):
+                rp = res["roofline_prune"]
+                rp["traffic_committed_builder_box"] = {"traffic": rp.get("traffic"), "source": rp.get("traffic_source")}
+                rp.update(live["prune"])
+                rp["traffic_source"] = live["source"]
+            progress("attention HBM traffic collected in-run (rocprofv3 --pmc)")
+            emit(provisional=True)
 
     if world == 1:
         # The auxiliary legs (decode, video -> first token, cfg2 block, CPU baseline) come after the timed region.  Should one of them
@@ -1623,23 +1698,23 @@ def main():
         threading.Thread(target=watchdog, daemon=True).start()
         if not args.no_decode:
             legs["decode"] = guarded("decode", decode_leg, eng, res["first_token"])   # the engine holds the cache of the timed pass (prefill + tail)
-            progress("decode leg done")
+            progress("decode leg done"); emit(provisional=True)
         if not args.no_decode and args.full and CONFIGS[name][0] == "qwen2-vl-7b":
             legs["peaked"] = guarded("peaked", peaked_attention_leg, eng.ops, device)
             progress("peaked-softmax attention leg done")
         if not args.no_pipeline:
             legs["video_to_first_token"] = guarded("video_to_first_token", pipeline_leg, name, eng, device,
                                                    modes=("overlapped", "sequential") if args.full else ("overlapped",))
-            progress("video -> first token leg done")
+            progress("video -> first token leg done"); emit(provisional=True)
         if not args.no_pipeline and not args.no_secondary and name in ("cfg4", "cfg4s") and CONFIGS[name][0] == "qwen2-vl-7b":
             legs["host_contention"] = guarded("host_contention", host_contention_leg, eng, device)
-            progress("host contention leg done")
+            progress("host contention leg done"); emit(provisional=True)
         if not args.no_secondary and name == "cfg4":
             legs["cfg4ref"] = guarded("cfg4ref", secondary_cfg4ref, args, device, eng.w)
             progress("secondary cfg4ref block done (the reference's own operating point)")
         if not args.no_secondary and name != "cfg2" and CONFIGS[name][0] == "qwen2-vl-7b":
             legs["cfg2"] = guarded("cfg2", secondary_cfg2, args, device, eng.w)
-            progress("secondary cfg2 block done")
+            progress("secondary cfg2 block done"); emit(provisional=True)
         if not args.no_cpu_baseline and rank == 0:
             legs["cpu_baseline"] = guarded("cpu_baseline", cpu_baseline, name)
             progress("cpu baseline done")
@@ -1674,7 +1749,7 @@ def main():
         # (N > 1: an exception on ONE rank leaves the others inside a collective — the process-group timeout ends them; rank 0 prints the
         # line from its watchdog or from here, whichever comes first)
         legs["video_to_first_token"] = guarded("video_to_first_token", front_end_leg, mode, ("overlapped", "sequential") if args.full else ("overlapped",))
-        progress("video -> first token leg done")
+        progress("video -> first token leg done"); emit(provisional=True)
         if tp_block is not None and parallel != "tp":               # ... and once through the north_star's contract layout
             torch.cuda.empty_cache()
             v = guarded("tp_video_to_first_token", front_end_leg, "tp", ("overlapped",))

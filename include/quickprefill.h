@@ -54,7 +54,7 @@ int qp_create(qp_ctx** out, int device);
 int qp_dev_switch(const char* name, int value);
 void qp_destroy(qp_ctx* ctx);
 const char* qp_last_error(void);
-const char* qp_version(void);          /* "quickprefill-mi355x 0.5 (gfx950)": 0.3 prune_mode became a per-call argument; 0.4 qp_prefill_segment; 0.5 qp_linear_plan_choice */
+const char* qp_version(void);          /* "quickprefill-mi355x 0.6 (gfx950)": 0.3 prune_mode became a per-call argument; 0.4 qp_prefill_segment; 0.5 qp_linear_plan_choice; 0.6 qp_frame_ring_* */
 int qp_device_cus(const qp_ctx* ctx);
 
 /* Host helper of the overlap producer (no device work): memcpy `bytes` from src to dst (e.g. decoded uint8 frames into a pinned
@@ -385,6 +385,49 @@ typedef struct qp_vit_block {
 int qp_vit_blocks(qp_ctx* ctx, const qp_vit_block* blocks, int n_blocks, int64_t n_seq, int64_t seq_len, int dim, int heads, int mlp_dim,
                   void* x, void* y, void* qkv, void* att, void* pending, void* z, const float* cos, const float* sin, float ln_eps,
                   void* gemm_ws, size_t gemm_ws_bytes, void* stream);
+
+/* ---- frame ring of the overlap producer (reference: the daemon thread + Queue(maxsize=3) + 10 ms polling of
+ *      lvu/models/qwen25_lvu_interleaved.py:237-342, 853-871) -------------------------------------------------------------------------
+ * A NATIVE producer thread (std::thread of this library) pulls frame groups from a source callback straight into pinned host slots,
+ * enqueues each H2D copy on `copy_stream` and signals the consumer with events; nothing polls.  Slot reuse is ordered in both
+ * directions: a host slot is refilled only after the previous copy out of it has finished (the producer thread waits on the event),
+ * a device slot is overwritten only after the consumer's last GPU read of it (the copy stream waits on the event recorded by
+ * qp_frame_ring_mark_read / _release).  The frame source runs one group ahead of the ring (it fills host slot g % depth while the
+ * device slots still hold groups g-depth .. g-1), like the reference's thread that decodes before it blocks in put().
+ * Ownership: host slots (pinned) and device slots are the CALLER's (depth buffers of slot_bytes each) and must outlive the ring;
+ * the ring owns its events and its thread.  ctx == NULL and dev_slots == NULL: host-only ring (no HIP call; acquire hands out the
+ * host slot, the source is not called for a slot before its group has been released).
+ * One video per ring: create -> start[_file] -> acquire / mark_read / release per group, in order -> stop -> destroy.
+ * qp_frame_ring_acquire and _stop BLOCK on the producer thread: call them with the GIL released (ctypes.CDLL does) — a Python source
+ * callback needs the GIL to run. */
+typedef struct qp_frame_ring qp_frame_ring;
+/* Fill `dst` (capacity bytes) with frame group g (uint8 [frames, 3, H, W], contiguous); return the bytes written, 0 when the video has
+ * no group g (early end), < 0 on failure.  Called on the ring's thread, one group at a time, g ascending from 0. */
+typedef int64_t (*qp_frame_source_fn)(void* user, int64_t g, void* dst, size_t capacity);
+int qp_frame_ring_create(qp_ctx* ctx, int depth, size_t slot_bytes, void* const* host_slots, void* const* dev_slots, void* copy_stream,
+                         qp_frame_ring** out);
+int qp_frame_ring_start(qp_frame_ring* ring, qp_frame_source_fn source, void* user, int64_t n_groups);
+/* Built-in source for pre-decoded videos (a raw uint8 [F, 3, H, W] array in a file, e.g. the data section of a .npy): group g =
+ * frames frame_idx[g*frames_per_group ...], each pread() at data_offset + idx*frame_bytes directly into the pinned slot by up to
+ * io_threads threads.  No interpreter anywhere on the frame path. */
+int qp_frame_ring_start_file(qp_frame_ring* ring, const char* path, int64_t data_offset, int64_t frame_bytes, const int64_t* frame_idx,
+                             int64_t n_frames, int frames_per_group, int io_threads);
+/* origin_event: a hipEvent_t (timing enabled) the caller recorded; qp_frame_ring_h2d_ms reports against it.  Optional. */
+int qp_frame_ring_set_origin(qp_frame_ring* ring, void* origin_event);
+/* Blocks the HOST until group g's copy has been enqueued, then makes `consumer_stream` wait for it ON THE DEVICE (no host sync on the
+ * copy).  *ptr_out = the device slot (host slot of a host-only ring), *bytes_out = what the source wrote.  Errors of the source or of
+ * the producer thread surface here. */
+int qp_frame_ring_acquire(qp_frame_ring* ring, int64_t g, void* consumer_stream, void** ptr_out, size_t* bytes_out);
+/* Record "last GPU read of group g's slot" on consumer_stream now (optional; _release records it if nobody did). */
+int qp_frame_ring_mark_read(qp_frame_ring* ring, int64_t g, void* consumer_stream);
+int qp_frame_ring_release(qp_frame_ring* ring, int64_t g, void* consumer_stream);
+int qp_frame_ring_stop(qp_frame_ring* ring);                       /* cancel + join; safe at any point, idempotent */
+/* out[0..5] = seconds inside the source / waiting for a released slot / waiting for a previous copy / enqueueing copies, groups
+ * published, groups the video has (shrinks if the source ended early). */
+int qp_frame_ring_stats(qp_frame_ring* ring, double* out, int n_out);
+/* Per group: when its H2D copy finished, in ms after the origin event (NaN: unknown / no origin).  After the producer has ended. */
+int qp_frame_ring_h2d_ms(qp_frame_ring* ring, float* out, int64_t n_out);
+void qp_frame_ring_destroy(qp_frame_ring* ring);
 
 #ifdef __cplusplus
 }

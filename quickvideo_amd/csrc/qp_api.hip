@@ -48,7 +48,7 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 extern "C" {
 
 const char* qp_last_error(void) { return g_err; }
-const char* qp_version(void) { return "quickprefill-mi355x 0.5 (gfx950)"; }
+const char* qp_version(void) { return "quickprefill-mi355x 0.6 (gfx950)"; }
 
 int qp_dev_switch(const char* name, int value) {
   QP_REQUIRE(name != nullptr, QP_ERR_INVALID, "qp_dev_switch: name is NULL");

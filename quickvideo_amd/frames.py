@@ -33,6 +33,15 @@ import numpy as np
 import torch
 
 
+def _out_array(out, n, H, W):
+    """The array a reader fills: a fresh one, or the caller's (a pinned ring slot) after a shape check."""
+    if out is None:
+        return np.empty((n, 3, H, W), dtype=np.uint8)
+    if tuple(out.shape) != (n, 3, H, W) or out.dtype != np.uint8:
+        raise ValueError(f"frames are uint8 {(n, 3, H, W)}, the destination is {out.dtype} {tuple(out.shape)}")
+    return out
+
+
 class VideoReaderBase:
     height: Optional[int] = None
     width: Optional[int] = None
@@ -46,7 +55,8 @@ class VideoReaderBase:
 
     def __len__(self) -> int: raise NotImplementedError
     def get_fps(self) -> float: raise NotImplementedError
-    def _frames(self, idx: np.ndarray) -> np.ndarray: raise NotImplementedError   # uint8 [len(idx), 3, H, W]
+    def _frames(self, idx: np.ndarray, out: Optional[np.ndarray] = None) -> np.ndarray:
+        raise NotImplementedError                                                 # uint8 [len(idx), 3, H, W]; written into `out` when given
 
     def process(self, idx):
         self._idx = np.asarray(idx, dtype=np.int64)
@@ -63,6 +73,25 @@ class VideoReaderBase:
         sel = self._idx[self._cursor:self._cursor + self.frame_iter]
         self._cursor += len(sel)
         return torch.from_numpy(self._frames(sel))
+
+    def next_into(self, dst: np.ndarray) -> int:
+        """next() that decodes STRAIGHT into `dst` (uint8 [>= frame_iter, 3, H, W], e.g. a pinned ring slot: no intermediate array, no
+        memcpy); returns the number of frames written, 0 at the end of the selection.  Used by the native frame ring (ring.py)."""
+        if self._idx is None:
+            raise RuntimeError("call process(indices) before iterating")
+        sel = self._idx[self._cursor:self._cursor + self.frame_iter]
+        if len(sel) == 0:
+            return 0
+        if len(sel) > dst.shape[0]:
+            raise ValueError(f"a group of {len(sel)} frames does not fit a slot of {dst.shape[0]}")
+        self._cursor += len(sel)
+        out = dst[:len(sel)]
+        got = self._frames(sel, out=out)
+        if got is not out:                       # a subclass that ignores `out`
+            if tuple(got.shape) != tuple(out.shape):
+                raise ValueError(f"reader produced frames of shape {tuple(got.shape)}, the slot holds {tuple(out.shape)}")
+            np.copyto(out, got)
+        return len(sel)
 
 
 class SyntheticVideoReader(VideoReaderBase):
@@ -118,9 +147,9 @@ class SyntheticVideoReader(VideoReaderBase):
         else:
             out[j] = np.random.RandomState((self.seed * 1_000_003 + int(i)) % (2 ** 31)).randint(0, 256, (3, H, W), dtype=np.uint8)
 
-    def _frames(self, idx):
+    def _frames(self, idx, out=None):
         H, W = self.height or self.src_h, self.width or self.src_w
-        out = np.empty((len(idx), 3, H, W), dtype=np.uint8)
+        out = _out_array(out, len(idx), H, W)
         if self.num_threads > 1 and len(idx) > 1 and H * W >= 1 << 16:
             # like the reference's decoder pool (QUICKCODEC_CORES, qwen25_lvu_interleaved.py:385-396): frames of a group in parallel
             # (numpy's generators release the GIL while they fill the buffer)
@@ -148,10 +177,23 @@ class ArrayVideoReader(VideoReaderBase):
     def __len__(self): return self.arr.shape[0]
     def get_fps(self): return self.fps
 
-    def _frames(self, idx):
+    def _frames(self, idx, out=None):
         if self.height and self.width and (self.height, self.width) != tuple(self.arr.shape[2:]):
             raise ValueError(f"stored frames are {tuple(self.arr.shape[2:])}, requested {(self.height, self.width)}: no resizer without a codec")
-        return np.ascontiguousarray(self.arr[idx])
+        if out is None:
+            return np.ascontiguousarray(self.arr[idx])
+        out = _out_array(out, len(idx), *self.arr.shape[2:])
+        for j, i in enumerate(idx):
+            out[j] = self.arr[int(i)]
+        return out
+
+    def raw_layout(self):
+        """(path, byte offset of frame 0, bytes per frame) when the frames lie contiguously in a plain file (.npy, C order) — what the
+        native ring's built-in file source needs (qp_frame_ring_start_file); None otherwise (.pt)."""
+        a = self.arr
+        if isinstance(a, np.memmap) and a.flags["C_CONTIGUOUS"]:
+            return str(a.filename), int(a.offset), int(np.prod(a.shape[1:]))
+        return None
 
 
 class ImageFolderVideoReader(VideoReaderBase):
@@ -185,9 +227,9 @@ class ImageFolderVideoReader(VideoReaderBase):
                 im = im.resize((W, H), flt)
             out[j] = np.asarray(im).transpose(2, 0, 1)
 
-    def _frames(self, idx):
+    def _frames(self, idx, out=None):
         H, W = self.height or self.src_h, self.width or self.src_w
-        out = np.empty((len(idx), 3, H, W), dtype=np.uint8)
+        out = _out_array(out, len(idx), H, W)
         if self.num_threads > 1 and len(idx) > 1:
             if self._pool is None:
                 from concurrent.futures import ThreadPoolExecutor
@@ -233,12 +275,12 @@ class AnimatedImageVideoReader(VideoReaderBase):
                 if i in want:
                     self._decoded[i] = im.convert("RGB").copy()
 
-    def _frames(self, idx):
+    def _frames(self, idx, out=None):
         from PIL import Image
         H, W = self.height or self.src_h, self.width or self.src_w
         flt = {"LANCZOS": Image.LANCZOS, "BICUBIC": Image.BICUBIC, "BILINEAR": Image.BILINEAR, "NEAREST": Image.NEAREST}.get(
             str(self.interpolation).upper(), Image.LANCZOS)
-        out = np.empty((len(idx), 3, H, W), dtype=np.uint8)
+        out = _out_array(out, len(idx), H, W)
         for j, i in enumerate(idx):
             im = self._decoded[int(i)]
             if im.size != (W, H):

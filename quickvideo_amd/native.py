@@ -104,7 +104,20 @@ SIGNATURES = {
     "qp_linear_plan_choice": (_i32, [_vp, _i64, _i64, _i64, _i32, _i32, _c.POINTER(_i32)]),
     "qp_dev_switch": (_i32, [_c.c_char_p, _i32]),
     "qp_add_layernorm": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
+    # frame ring of the overlap producer (ring.py)
+    "qp_frame_ring_create": (_i32, [_vp, _i32, _sz, _c.POINTER(_vp), _c.POINTER(_vp), _vp, _c.POINTER(_vp)]),
+    "qp_frame_ring_start": (_i32, [_vp, _vp, _vp, _i64]),
+    "qp_frame_ring_start_file": (_i32, [_vp, _c.c_char_p, _i64, _i64, _c.POINTER(_i64), _i64, _i32, _i32]),
+    "qp_frame_ring_set_origin": (_i32, [_vp, _vp]),
+    "qp_frame_ring_acquire": (_i32, [_vp, _i64, _vp, _c.POINTER(_vp), _c.POINTER(_sz)]),
+    "qp_frame_ring_mark_read": (_i32, [_vp, _i64, _vp]),
+    "qp_frame_ring_release": (_i32, [_vp, _i64, _vp]),
+    "qp_frame_ring_stop": (_i32, [_vp]),
+    "qp_frame_ring_stats": (_i32, [_vp, _c.POINTER(_c.c_double), _i32]),
+    "qp_frame_ring_h2d_ms": (_i32, [_vp, _c.POINTER(_f32), _i64]),
+    "qp_frame_ring_destroy": (None, [_vp]),
 }
+FRAME_SOURCE_FN = _c.CFUNCTYPE(_i64, _vp, _i64, _vp, _sz)      # qp_frame_source_fn
 
 
 def load_library(path: str = LIB_PATH, hold_gil: bool = False) -> ctypes.CDLL:

@@ -229,6 +229,82 @@ class _Producer(threading.Thread):
         self.read_done[g % self.depth] = read_done
         self.slots_free.release()
 
+    def mark_read(self, g: int):
+        pass                                                          # the consumer's torch event, handed to release(), plays this role
+
+    def h2d_ms(self, origin):
+        return None                                                   # the consumer holds the torch events of the copies itself
+
+
+class _NativeProducer:
+    """The same seat as `_Producer`, filled by the library: the thread, the slot bookkeeping, the H2D enqueue and both event
+    hand-shakes are qp_frame_ring_* (csrc/qp_ring.hip; ring.py) — the product path on a GPU.  A reader of this package decodes
+    straight into the pinned slot (no intermediate array, no memcpy); a pre-decoded .npy video is read by the library itself and
+    never touches the interpreter; any other reader's next() result is copied in by the native memcpy.
+    get() makes `consumer_stream` wait for the copy on the device, so the consumer gets no event to wait on (ev = None)."""
+
+    def __init__(self, reader, n_groups, frames_per_group, device, ctx, consumer_stream, depth=3, ring_cache=None, copy_stream=None):
+        from .ring import FrameRing
+        self.reader, self.n_groups, self.depth, self.device = reader, n_groups, depth, device
+        self.consumer_stream = consumer_stream
+        self.copy_stream = copy_stream if copy_stream is not None else torch.cuda.Stream(device, priority=-1)
+        H = getattr(reader, "height", None)
+        W = getattr(reader, "width", None)
+        if H is None or W is None:                                    # array-backed source served at its stored size
+            H, W = (int(v) for v in reader.arr.shape[2:])
+        shape = (frames_per_group, 3, int(H), int(W))
+        self.ring_cache = ring_cache if ring_cache is not None else {}
+        key = (depth, shape, str(device))
+        if key not in self.ring_cache:
+            self.ring_cache.clear()                                   # one video geometry at a time
+            self.ring_cache[key] = [(torch.empty(shape, dtype=torch.uint8).pin_memory(),
+                                     torch.empty(shape, dtype=torch.uint8, device=device)) for _ in range(depth)]
+        slots = self.ring_cache[key]
+        self.ring = FrameRing([h for h, _ in slots], [d for _, d in slots], ctx=ctx, copy_stream=self.copy_stream)
+        self.fpg = frames_per_group
+        self.native_file = False
+        self.t_busy = self.t_blocked = self.t_copy = self.t_sem = self.t_sync = self.t_put = 0.0
+
+    def start(self):
+        layout = getattr(self.reader, "raw_layout", None)
+        layout = layout() if callable(layout) else None
+        if layout is not None and getattr(self.reader, "_idx", None) is not None and os.environ.get("QP_NATIVE_FILE_SOURCE", "1") != "0":
+            path, off, _ = layout
+            self.native_file = True
+            self.ring.start_file(path, off, self.reader._idx[self.reader._cursor:], self.fpg,
+                                 io_threads=max(1, int(getattr(self.reader, "num_threads", 8))))
+        else:
+            self.ring.start_reader(self.reader, self.n_groups)
+
+    def set_origin(self, event):
+        self.ring.set_origin(event)
+
+    def get(self):
+        g = self._next = getattr(self, "_next", -1) + 1
+        return g, self.ring.acquire(g, self.consumer_stream), None
+
+    def mark_read(self, g: int):
+        self.ring.mark_read(g, self.consumer_stream)
+
+    def release(self, g: int = 0, read_done=None):
+        self.ring.release(g, self.consumer_stream)
+
+    def cancel(self):
+        self.ring.stop()
+
+    def finish(self):
+        """After the last group was acquired and released: totals of the producer thread, then the ring is closed."""
+        st = self.ring.stats()
+        self.t_busy, self.t_copy = st["busy"], st["copy"]
+        self.t_sem, self.t_sync = st["wait_slot"], st["wait_h2d"]
+        self.t_blocked = self.t_sem + self.t_sync
+
+    def h2d_ms(self, origin):
+        return self.ring.h2d_ms(self.n_groups)
+
+    def close(self):
+        self.ring.close()
+
 
 _WARNED: set = set()
 
@@ -507,7 +583,16 @@ class PrefillPipeline:
             self._ring_cache = {}
         prod = None
         if lead:
-            prod = _Producer(reader, G, gs, dev, depth=3, ring_cache=self._ring_cache, copy_stream=self.copy_stream)   # bounded like the reference's Queue(maxsize=3)
+            # bounded like the reference's Queue(maxsize=3).  On a GPU the producer is the library's native thread (qp_frame_ring_*);
+            # the Python thread remains for the CPU test double and as an A/B (QP_NATIVE_PRODUCER=0)
+            ctx = None
+            if self.use_gpu and os.environ.get("QP_NATIVE_PRODUCER", "1") != "0":
+                _ = self.tower
+                ctx = getattr(self.ops, "ctx", None)
+            if ctx is not None:
+                prod = _NativeProducer(reader, G, gs, dev, ctx, self.vit_stream, depth=3, ring_cache=self._ring_cache, copy_stream=self.copy_stream)
+            else:
+                prod = _Producer(reader, G, gs, dev, depth=3, ring_cache=self._ring_cache, copy_stream=self.copy_stream)
             prod.start()
         sync = (lambda: torch.cuda.synchronize(dev)) if self.use_gpu else (lambda: None)
         ev_t = (lambda: torch.cuda.Event(enable_timing=True)) if self.use_gpu else (lambda: None)
@@ -538,6 +623,7 @@ class PrefillPipeline:
                         rows, grid = patchify_frames(frames, self.model.vision.spec, self.model.text.embed.dtype)
                         read_done = torch.cuda.Event()
                         read_done.record(self.vit_stream)         # last read of the ring's device slot
+                        prod.mark_read(g)                         # (native ring: its own event, recorded at the same point)
                         feats = self.tower.forward(rows, grid)
                     e_ev.record(self.vit_stream)
                 return feats, (s_ev, e_ev, ev), read_done, frames
@@ -550,6 +636,8 @@ class PrefillPipeline:
         origin = ev_t()
         if self.use_gpu:
             origin.record(torch.cuda.current_stream(dev))
+            if isinstance(prod, _NativeProducer):
+                prod.set_origin(origin)
         start, trace = 0, []                                          # trace[g] = (h2d_done, vit_start, vit_end, prefill_start, prefill_end)
         dbg = _GpuProgress(G) if (self.use_gpu and os.environ.get("QP_PIPELINE_DEBUG")) else None
         # query-based predict types: the prompt (everything after the last video token) is appended to every group and scores its
@@ -608,6 +696,8 @@ class PrefillPipeline:
         except BaseException:            # leave no producer thread behind that waits for a slot nobody will release
             if prod is not None:
                 prod.cancel()
+                if isinstance(prod, _NativeProducer):
+                    prod.close()
             raise
         finally:
             if bar is not None:
@@ -616,6 +706,12 @@ class PrefillPipeline:
         if dbg is not None:
             dbg.stop()
         tm.prefill = time.perf_counter() - t_pre
+        if isinstance(prod, _NativeProducer):                         # every group acquired and released: totals, copy timestamps, ring closed
+            prod.cancel()
+            prod.finish()
+            ms = prod.h2d_ms(origin)
+            trace = [(ms[i],) + t[1:] for i, t in enumerate(trace)]
+            prod.close()
         tm.tokens, tm.groups = start, G
         t_dec = time.perf_counter()
         logits = eng.prefill_tail(eng.embed_tokens(tail), pos[:, start:])     # pruning off for the tail (qwen25_lvu.py:737-742)
@@ -732,7 +828,8 @@ class PrefillPipeline:
         """Event timestamps (ms since `origin`) -> who the main stream waited for between two groups.  The stall in front of group g,
         [end of prefill(g-1), start of prefill(g)], is split at the moment group g's frames finished uploading: before it the GPU
         could not have started ViT(g) (frame wait, the producer's fault); after it the ViT simply was not finished (the tower's)."""
-        at = lambda e: origin.elapsed_time(e) * 1e-3
+        # an event of this process, or (native ring) the copy's finish time in ms after `origin` as the library measured it
+        at = lambda e: (e if e == e else 0.0) * 1e-3 if isinstance(e, float) else origin.elapsed_time(e) * 1e-3   # noqa: E731
         prev_end = 0.0
         tm.group_gaps = []
         for h2d, v0, v1, p0, p1 in trace:
