@@ -1749,6 +1749,14 @@ def main():
         # (N > 1: an exception on ONE rank leaves the others inside a collective — the process-group timeout ends them; rank 0 prints the
         # line from its watchdog or from here, whichever comes first)
         legs["video_to_first_token"] = guarded("video_to_first_token", front_end_leg, mode, ("overlapped", "sequential") if args.full else ("overlapped",))
+        if "video_to_first_token" in leg_errors:
+            # THIS rank threw inside a multi-rank leg: its peers are now waiting in a collective it will never join.  Waiting for their
+            # process-group timeout (QP_DIST_TIMEOUT_S, 10 min) buys nothing: print the line (rank 0; any other rank's exit makes the
+            # launcher stop the job, and rank 0's guard process prints the line it was handed after the timed pass) and leave at once.
+            progress(f"rank {rank}: leaving after the failed N>1 leg (peers would otherwise wait for the collective timeout)")
+            emit()
+            sys.stdout.flush(); sys.stderr.flush()
+            os._exit(1)
         progress("video -> first token leg done"); emit(provisional=True)
         if tp_block is not None and parallel != "tp":               # ... and once through the north_star's contract layout
             torch.cuda.empty_cache()

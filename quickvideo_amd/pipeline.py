@@ -2,9 +2,10 @@
 
 Reference shape (lvu/models/qwen25_lvu_interleaved.py:237-342, 733-942): a daemon thread pulls frame groups from
 the reader, runs the HF processor on the CPU and feeds a bounded Queue(3); the main thread polls it every 10 ms and
-runs the group loop.  Here the producer thread only moves uint8 frames into a pinned host ring and enqueues an
-async H2D copy on a dedicated HIP stream (event-signalled, no polling); normalise + patchify + ViT run on the GPU on a
-second stream, one group ahead of the LLM prefill that runs on the main stream.  Token ids and M-RoPE positions are
+runs the group loop.  Here the producer is a native thread of the library (qp_frame_ring_*, csrc/qp_ring.hip): the frame source
+decodes uint8 frames straight into a pinned host ring, the thread enqueues the async H2D copy on a dedicated HIP stream
+(event-signalled in both directions, no polling); normalise + patchify + ViT run on the GPU on a second stream, one group ahead of the
+LLM prefill that runs on the main stream.  Token ids and M-RoPE positions are
 built before any pixel exists from (nframes, H, W) alone, like the reference's dummy_call (interleaved:522-638, 786-810).
 """
 from __future__ import annotations
@@ -243,16 +244,12 @@ class _NativeProducer:
     never touches the interpreter; any other reader's next() result is copied in by the native memcpy.
     get() makes `consumer_stream` wait for the copy on the device, so the consumer gets no event to wait on (ev = None)."""
 
-    def __init__(self, reader, n_groups, frames_per_group, device, ctx, consumer_stream, depth=3, ring_cache=None, copy_stream=None):
+    def __init__(self, reader, n_groups, frames_per_group, frame_hw, device, ctx, consumer_stream, depth=3, ring_cache=None, copy_stream=None):
         from .ring import FrameRing
         self.reader, self.n_groups, self.depth, self.device = reader, n_groups, depth, device
         self.consumer_stream = consumer_stream
         self.copy_stream = copy_stream if copy_stream is not None else torch.cuda.Stream(device, priority=-1)
-        H = getattr(reader, "height", None)
-        W = getattr(reader, "width", None)
-        if H is None or W is None:                                    # array-backed source served at its stored size
-            H, W = (int(v) for v in reader.arr.shape[2:])
-        shape = (frames_per_group, 3, int(H), int(W))
+        shape = (frames_per_group, 3, int(frame_hw[0]), int(frame_hw[1]))   # the plan's frame size (the reader may be a bare iterator)
         self.ring_cache = ring_cache if ring_cache is not None else {}
         key = (depth, shape, str(device))
         if key not in self.ring_cache:
@@ -457,7 +454,8 @@ class PrefillPipeline:
         group g+1's features would then wait for every stage to finish group g — serialising the pipe."""
         if self._vit_pg is None:
             dist = torch.distributed
-            self._vit_pg = dist.new_group(ranks=[self.par.global_rank(r) for r in range(self.par.world)])
+            from .parallel import dist_timeout
+            self._vit_pg = dist.new_group(ranks=[self.par.global_rank(r) for r in range(self.par.world)], timeout=dist_timeout())
         return self._vit_pg
 
     def _vit_parallel(self, frames, n_frames: int, H: int, W: int):
@@ -590,7 +588,8 @@ class PrefillPipeline:
                 _ = self.tower
                 ctx = getattr(self.ops, "ctx", None)
             if ctx is not None:
-                prod = _NativeProducer(reader, G, gs, dev, ctx, self.vit_stream, depth=3, ring_cache=self._ring_cache, copy_stream=self.copy_stream)
+                prod = _NativeProducer(reader, G, gs, (P["H"], P["W"]), dev, ctx, self.vit_stream, depth=3, ring_cache=self._ring_cache,
+                                       copy_stream=self.copy_stream)
             else:
                 prod = _Producer(reader, G, gs, dev, depth=3, ring_cache=self._ring_cache, copy_stream=self.copy_stream)
             prod.start()
