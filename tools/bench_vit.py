@@ -7,7 +7,8 @@ w = VisionWeights.synthetic(QWEN25_VL_VIT_7B if os.environ.get('QP_VIT_ARCH') ==
 from quickvideo_amd.native import QuickPrefillOps
 tower = VisionTower(w, ops=QuickPrefillOps(dev) if os.environ.get('QP_VIT_OPS','1')=='1' else None)
 H_, W_ = (int(v) for v in os.environ.get("QP_VIT_HW", "560,1008").split(","))     # QP_VIT_HW=392,560: one group of the 1-hour video (cfg4)
-frames = torch.randint(0, 256, (16, 3, H_, W_), dtype=torch.uint8, device=dev)
+NF = int(os.environ.get("QP_VIT_FRAMES", "16"))                                    # QP_VIT_FRAMES=32: two frame groups in ONE tower pass (M doubles)
+frames = torch.randint(0, 256, (NF, 3, H_, W_), dtype=torch.uint8, device=dev)
 def f():
     rows, grid = patchify_frames(frames, w.spec)
     return tower.forward(rows, grid)
@@ -18,6 +19,6 @@ s.record()
 for _ in range(3): f()
 e.record(); torch.cuda.synchronize()
 ms = s.elapsed_time(e) / 3
-npatch, seq = 8 * (H_ // 14) * (W_ // 14), (H_ // 14) * (W_ // 14)
-fl = w.spec.flops_per_patch() * npatch + 32 * 8 * 16 * 4 * seq * seq * 80
-print(f"ViT group: {ms:.2f} ms, {fl/ms/1e9:.1f} TF (linear+attn flops {fl/1e12:.2f} T)")
+npatch, seq = (NF // 2) * (H_ // 14) * (W_ // 14), (H_ // 14) * (W_ // 14)
+fl = w.spec.flops_per_patch() * npatch + 32 * (NF // 2) * 16 * 4 * seq * seq * 80
+print(f"ViT pass of {NF} frames {H_}x{W_} ({npatch} patch rows): {ms:.2f} ms = {ms * 16 / NF:.2f} ms per 16 frames, {fl/ms/1e9:.1f} TF (linear+attn flops {fl/1e12:.2f} T)")
