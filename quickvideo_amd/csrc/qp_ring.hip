@@ -30,6 +30,17 @@
 namespace {
 using clk = std::chrono::steady_clock;
 inline double secs(clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); }
+// create / destroy run on the CALLER's thread: they make the ring's device current for their HIP calls and put the caller's back
+struct DeviceScope {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceScope(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    else prev = -1;
+  }
+  ~DeviceScope() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
 }  // namespace
 
 struct qp_frame_ring {
@@ -45,6 +56,7 @@ struct qp_frame_ring {
   hipEvent_t origin = nullptr;           // caller's timing event (recorded before the first acquire): h2d_ms are relative to it
 
   std::mutex mu;
+  std::mutex join_mu;                    // stop() / h2d_ms() / destroy() from different threads: one of them joins
   std::condition_variable cv;
   int64_t n_groups = 0, produced = 0;
   bool cancelled = false, started = false, finished = false;
@@ -208,7 +220,8 @@ int qp_frame_ring_create(qp_ctx* ctx, int depth, size_t slot_bytes, void* const*
   r->slot_group.assign(depth, -1);
   r->slot_fill.assign(depth, 0);
   if (r->device >= 0) {
-    hipError_t e = hipSetDevice(r->device);
+    DeviceScope scope(r->device);
+    hipError_t e = scope.ok ? hipSuccess : hipErrorInvalidDevice;
     r->h2d_done.assign(depth, nullptr);
     r->read_done.assign(depth, nullptr);
     for (int i = 0; i < depth && e == hipSuccess; ++i) {
@@ -349,6 +362,7 @@ int qp_frame_ring_stop(qp_frame_ring* r) {
     r->cancelled = true;
   }
   r->cv.notify_all();
+  std::lock_guard<std::mutex> jl(r->join_mu);
   if (r->th.joinable()) r->th.join();
   return QP_OK;
 }
@@ -368,7 +382,10 @@ int qp_frame_ring_h2d_ms(qp_frame_ring* r, float* out, int64_t n_out) {
     QP_REQUIRE(!r->started || r->finished || r->cancelled, QP_ERR_INVALID,
                "qp_frame_ring_h2d_ms: the producer is still running (read the timestamps after the last group was acquired)");
   }
-  if (r->th.joinable()) r->th.join();
+  {
+    std::lock_guard<std::mutex> jl(r->join_mu);
+    if (r->th.joinable()) r->th.join();
+  }
   if (r->device >= 0 && r->origin)
     for (int s = 0; s < r->depth; ++s)
       if (r->h2d_valid[s] && hipEventSynchronize(r->h2d_done[s]) == hipSuccess) ring_stamp(r, s);
@@ -380,7 +397,7 @@ void qp_frame_ring_destroy(qp_frame_ring* r) {
   if (!r) return;
   (void)qp_frame_ring_stop(r);
   if (r->device >= 0) {
-    (void)hipSetDevice(r->device);
+    DeviceScope scope(r->device);
     for (int s = 0; s < r->depth; ++s) {
       if (r->h2d_valid[s]) (void)hipEventSynchronize(r->h2d_done[s]);      // the caller's buffers outlive the copies that read them
       if (r->h2d_done[s]) (void)hipEventDestroy(r->h2d_done[s]);
