@@ -52,7 +52,7 @@ def el_stage(p, sc, gap):
         ops.append(f"S6_ELC({e & 3});" + (f" S6_PACK({e >> 1}, {(e - 1) & 3}, {e & 3});" if e & 1 else ""))
     e = gap + 6
     if 0 <= e <= 31:
-        ops.append(f"S6_ELB({e & 1}, {e & 3});")
+        ops.append(f"S6_ELB({sc}, {e}, {e & 1}, {e & 3});")
     e = gap + 7
     if 0 <= e <= 31:
         ops.append(f"S6_ELA({sc}, {e}, {e & 1});")
