@@ -1742,6 +1742,11 @@ def main():
         torch.cuda.empty_cache()
         mode = "tp" if parallel == "tp" else {"both": "auto", "auto": "auto", "sp": "sp", "pp": "pp"}[args.parallel]
         def front_end_leg(mode_, modes_):
+            fail = os.environ.get("QP_BENCH_TEST_FAIL_FRONTEND")    # test hook: "<rank>" throws there, "<rank>:abort" dies natively there
+            if fail and int(fail.split(":")[0]) == rank:
+                if fail.endswith(":abort"):
+                    os.abort()
+                raise RuntimeError("QP_BENCH_TEST_FAIL_FRONTEND: injected failure of the N>1 front-end leg")
             mdl = load_native_model(f"synthetic:{CONFIGS[name][0]}", device=device, seed=0, parallel=mode_)
             mdl.parallel.sp_efficiency = eff_sp
             return pipeline_leg(name, None, device, model=mdl, vit_alone=False, modes=modes_)

@@ -92,3 +92,25 @@ def test_bench_nccl_preflight_runs_the_pass_through_rccl_with_the_same_result():
     # (0.85: the TP layout runs the per-operator loop with o_proj / down_proj in two row blocks + asynchronous all-reduces — on ONE rank
     # nothing can be overlapped and that form costs ~7 % (44.7 k vs 48.1 k tok/s with QP_TP_CHUNKS=1 vs 49.2 k plain, measured in round 4))
     assert 0.85 <= pre["value"] / one["value"] <= 1.05, (pre["value"], one["value"])
+
+
+@pytest.mark.parametrize("fail", ["1", "0", "0:abort"])
+def test_bench_n2_line_survives_a_rank_that_fails_in_the_front_end_leg(fail):
+    """N > 1: the front-end leg is the part of a multi-GPU run RCCL has never executed.  A rank that throws there (rank 1: the launcher then
+    stops rank 0, whose guard process prints the line it was handed after the timed pass; rank 0: it prints the line itself and leaves) or
+    dies natively there (abort(): no Python handler runs) must cost neither the line nor ten minutes of collective timeout."""
+    import time
+    env = dict(os.environ, QP_BENCH_SINGLE_DEVICE="1", QP_BENCH_TEST_FAIL_FRONTEND=fail, QP_BENCH_FULL_RECORD=f"bench_full_test_fail_{os.getpid()}.json")
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "cfg2", "--steps", "2", "--warmup", "1", "--no-preflight"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    took = time.time() - t0
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), (p.returncode, p.stdout[-1500:], p.stderr[-1500:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["roofline"]["frac"] > 0 and "ttft_ms" not in d and "note" in d, d
+    assert p.returncode != 0                       # the job did fail: the launcher says so; the line is there anyway
+    assert took < 300, took                        # ... and nobody sat in a collective until the process-group timeout
+    rec = os.path.join(ROOT, "gpurun_out", env["QP_BENCH_FULL_RECORD"])
+    if os.path.exists(rec):
+        os.remove(rec)
