@@ -1659,7 +1659,12 @@ def main():
         if note:
             out["note"] = note
         if provisional:
-            _GUARD.send(compact_line(out, None))
+            g = _GUARD
+            try:
+                if g is not None:
+                    g.send(compact_line(out, None))
+            except OSError:                             # the watchdog thread printed the final line meanwhile: nothing left to hand over
+                pass
             return
         full_path = write_full_record(out)
         emit_line(compact_line(out, full_path))
