@@ -260,6 +260,7 @@ class _NativeProducer:
         self.ring = FrameRing([h for h, _ in slots], [d for _, d in slots], ctx=ctx, copy_stream=self.copy_stream)
         self.fpg = frames_per_group
         self.native_file = False
+        self._next = 0                                                # next group the consumer will ask for (get() is called in order)
         self.t_busy = self.t_blocked = self.t_copy = self.t_sem = self.t_sync = self.t_put = 0.0
 
     def start(self):
@@ -277,7 +278,8 @@ class _NativeProducer:
         self.ring.set_origin(event)
 
     def get(self):
-        g = self._next = getattr(self, "_next", -1) + 1
+        g = self._next
+        self._next += 1
         return g, self.ring.acquire(g, self.consumer_stream), None
 
     def mark_read(self, g: int):
