@@ -106,9 +106,12 @@ int make_plan(int device, hipblasLtHandle_t handle, Plan& p, int64_t m, int64_t 
   LT_CHECK(hipblasLtMatmulPreferenceCreate(&pref));
   const uint64_t ws64 = max_ws;
   LT_CHECK(hipblasLtMatmulPreferenceSetAttribute(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &ws64, sizeof(ws64)));
-  hipblasLtMatmulHeuristicResult_t res[32];
+#ifndef QP_LT_MAX_CANDS
+#define QP_LT_MAX_CANDS 32       // heuristic candidates the tuner times per problem (an A/B build with 128 found nothing faster: DESIGN 6)
+#endif
+  hipblasLtMatmulHeuristicResult_t res[QP_LT_MAX_CANDS];
   int found = 0;
-  hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(handle, p.desc, p.a, p.b, p.d, p.d, pref, 32, res, &found);
+  hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(handle, p.desc, p.a, p.b, p.d, p.d, pref, QP_LT_MAX_CANDS, res, &found);
   hipblasLtMatmulPreferenceDestroy(pref);
   if (st != HIPBLAS_STATUS_SUCCESS || found < 1)
     return qp_fail(QP_ERR_UNSUPPORTED, "qp_linear_act: hipBLASLt has no algorithm for m=%lld n=%lld k=%lld act=%d (status %d)", (long long)m,
