@@ -765,7 +765,7 @@ def _leg_record(t, overlap, reader_threads):
            "producer": {"busy_in_frame_source_ms": ms(t.producer_busy), "blocked_on_full_ring_ms": ms(t.producer_blocked),
                         "ring_fill_and_h2d_enqueue_ms": ms(t.producer_copy), "threads": reader_threads},
            "gpu": {"prefill_busy_ms": ms(t.gpu_prefill_busy), "stall_waiting_for_frames_ms": ms(t.gpu_stall_frames),
-                   "stall_waiting_for_vit_ms": ms(t.gpu_stall_vit), "vit_span_sharing_cus_with_prefill_ms": ms(t.vit_span),
+                   "stall_waiting_for_vit_ms": ms(t.gpu_stall_vit), "stall_unattributed_ms": ms(getattr(t, "gpu_stall_unknown", 0.0)), "vit_span_sharing_cus_with_prefill_ms": ms(t.vit_span),
                    "vit_alone_ms": ms(t.vit_uncontended)},
            "host_consumer_blocked_in_queue_get_ms": ms(t.consumer_get_wait)}
     if not overlap:

@@ -40,7 +40,8 @@ typedef enum qp_status {
   QP_ERR_INVALID = -1,     /* bad argument (maps to ValueError / AssertionError in the Python mirror) */
   QP_ERR_UNSUPPORTED = -2, /* shape outside what the kernels implement                               */
   QP_ERR_HIP = -3,         /* a HIP runtime call failed                                              */
-  QP_ERR_WORKSPACE = -4    /* workspace too small                                                    */
+  QP_ERR_WORKSPACE = -4,   /* workspace too small                                                    */
+  QP_ERR_TIMEOUT = -5      /* a bounded wait ran out (qp_frame_ring_acquire_for): not a failure, call again */
 } qp_status;
 
 /* ---- context ------------------------------------------------------------------------------ */
@@ -54,7 +55,7 @@ int qp_create(qp_ctx** out, int device);
 int qp_dev_switch(const char* name, int value);
 void qp_destroy(qp_ctx* ctx);
 const char* qp_last_error(void);
-const char* qp_version(void);          /* "quickprefill-mi355x 0.6 (gfx950)": 0.3 prune_mode became a per-call argument; 0.4 qp_prefill_segment; 0.5 qp_linear_plan_choice; 0.6 qp_frame_ring_* */
+const char* qp_version(void);          /* "quickprefill-mi355x 0.7 (gfx950)": 0.3 prune_mode became a per-call argument; 0.4 qp_prefill_segment; 0.5 qp_linear_plan_choice; 0.6 qp_frame_ring_*; 0.7 qp_linear_plan_choice returns a status, qp_frame_ring_acquire_for */
 int qp_device_cus(const qp_ctx* ctx);
 
 /* Host helper of the overlap producer (no device work): memcpy `bytes` from src to dst (e.g. decoded uint8 frames into a pinned
@@ -311,10 +312,13 @@ int qp_linear_tune(qp_ctx* ctx, const void* x, const void* const* weights, int n
  * times the candidates, every later one — from this or any other context of the same device — adopts that pick without timing, and a
  * context that meets the problem in qp_linear_act without having tuned it runs the recorded pick too.  (Two stopwatch runs can disagree
  * on candidates within noise of each other, and a different algorithm is a different fp32 accumulation order: all contexts of a
- * process compute the same bits.)  qp_linear_plan_choice -> index of the heuristic candidate THIS context runs for the problem
- * (0 = hipBLASLt's own first pick), -1 if the context has not seen it, < -1 = qp_status; *tuned (optional) = 1 when a stopwatch
- * decision is on record for the device.  bias_kind: 0 none, 1 bf16, 2 fp32.  Host-side query, no device work. */
-int qp_linear_plan_choice(qp_ctx* ctx, int64_t m, int64_t n, int64_t k, int act, int bias_kind, int* tuned);
+ * process compute the same bits.)  What is recorded is the ALGORITHM, not its place in a candidate list (the list depends on the
+ * workspace limit it was asked with): a context adopts the record only when its own list holds that algorithm within the workspace
+ * the caller offers, and re-times otherwise.  qp_linear_plan_choice: returns a qp_status (0.7: the status no longer shares the return
+ * value with the index); *choice = index of the heuristic candidate THIS context runs for the problem (0 = hipBLASLt's own first
+ * pick), -1 if the context has not seen it; *tuned (optional) = 0 no stopwatch decision on record for the device, 1 on record, 2 on
+ * record and this context's plan runs exactly that algorithm.  bias_kind: 0 none, 1 bf16, 2 fp32.  Host-side query, no device work. */
+int qp_linear_plan_choice(qp_ctx* ctx, int64_t m, int64_t n, int64_t k, int act, int bias_kind, int* choice, int* tuned);
 /* out = y * sigmoid(1.702 y) with torch's bf16 rounding steps (hidden_act = quick_gelu). */
 int qp_quick_gelu(qp_ctx* ctx, const void* x, void* out, int64_t n_elems, void* stream);
 
@@ -418,6 +422,10 @@ int qp_frame_ring_set_origin(qp_frame_ring* ring, void* origin_event);
  * copy).  *ptr_out = the device slot (host slot of a host-only ring), *bytes_out = what the source wrote.  Errors of the source or of
  * the producer thread surface here. */
 int qp_frame_ring_acquire(qp_frame_ring* ring, int64_t g, void* consumer_stream, void** ptr_out, size_t* bytes_out);
+/* The same with a bounded host wait: returns QP_ERR_TIMEOUT (qp_last_error untouched, ring state untouched) when group g has not been
+ * published within timeout_ms; timeout_ms < 0 waits for good.  A host that must stay interruptible — the reference's consumer polls
+ * its queue every 10 ms (qwen25_lvu_interleaved.py:853-871), so Ctrl-C works while the decoder hangs — calls this in a loop. */
+int qp_frame_ring_acquire_for(qp_frame_ring* ring, int64_t g, void* consumer_stream, int64_t timeout_ms, void** ptr_out, size_t* bytes_out);
 /* Record "last GPU read of group g's slot" on consumer_stream now (optional; _release records it if nobody did). */
 int qp_frame_ring_mark_read(qp_frame_ring* ring, int64_t g, void* consumer_stream);
 int qp_frame_ring_release(qp_frame_ring* ring, int64_t g, void* consumer_stream);

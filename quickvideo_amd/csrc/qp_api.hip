@@ -48,7 +48,7 @@ static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t
 extern "C" {
 
 const char* qp_last_error(void) { return g_err; }
-const char* qp_version(void) { return "quickprefill-mi355x 0.6 (gfx950)"; }
+const char* qp_version(void) { return "quickprefill-mi355x 0.7 (gfx950)"; }
 
 int qp_dev_switch(const char* name, int value) {
   QP_REQUIRE(name != nullptr, QP_ERR_INVALID, "qp_dev_switch: name is NULL");
@@ -596,12 +596,13 @@ int qp_linear_tune(qp_ctx* ctx, const void* x, const void* const* weights, int n
                                (hipStream_t)stream, nullptr);
 }
 
-int qp_linear_plan_choice(qp_ctx* ctx, int64_t m, int64_t n, int64_t k, int act, int bias_kind, int* tuned) {
-  if (!ctx || m <= 0 || n <= 0 || k <= 0 || act < 0 || act > 1 || bias_kind < 0 || bias_kind > 2) {
-    (void)qp_fail(QP_ERR_INVALID, "qp_linear_plan_choice: m=%lld n=%lld k=%lld act=%d bias_kind=%d", (long long)m, (long long)n, (long long)k, act, bias_kind);
-    return QP_ERR_INVALID;
-  }
-  return qp_linear_plan_choice_impl(ctx, m, n, k, act, bias_kind, tuned);
+int qp_linear_plan_choice(qp_ctx* ctx, int64_t m, int64_t n, int64_t k, int act, int bias_kind, int* choice, int* tuned) {
+  QP_REQUIRE(ctx && choice, QP_ERR_INVALID, "qp_linear_plan_choice: NULL argument");
+  *choice = -1;
+  if (tuned) *tuned = 0;
+  QP_REQUIRE(m > 0 && n > 0 && k > 0 && act >= 0 && act <= 1 && bias_kind >= 0 && bias_kind <= 2, QP_ERR_INVALID,
+             "qp_linear_plan_choice: m=%lld n=%lld k=%lld act=%d bias_kind=%d", (long long)m, (long long)n, (long long)k, act, bias_kind);
+  return qp_linear_plan_choice_impl(ctx, m, n, k, act, bias_kind, choice, tuned);
 }
 
 // ---- decode step (qp_decode.hip) ------------------------------------------------------------------------------------

@@ -139,6 +139,6 @@ int qp_launch_prune_tail_inplace(const uint16_t* norm_keys, int64_t n, int64_t k
                                  int64_t past_len, int hkv, int32_t* kept, int* sync_words, hipStream_t s);
 int qp_launch_linear_tune(qp_ctx* ctx, const void* x, const void* const* ws_list, int n_ws, const void* bias, int bias_f32, float alpha, void* out,
                           int64_t m, int64_t n, int64_t k, int act, void* workspace, size_t workspace_bytes, hipStream_t s, int* chosen);
-int qp_linear_plan_choice_impl(qp_ctx* ctx, int64_t m, int64_t n, int64_t k, int act, int bias_kind, int* tuned);
+int qp_linear_plan_choice_impl(qp_ctx* ctx, int64_t m, int64_t n, int64_t k, int act, int bias_kind, int* choice, int* tuned);
 int qp_launch_linear_act(qp_ctx* ctx, const void* x, const void* w, const void* bias, int bias_f32, float alpha, void* out, int64_t m, int64_t n,
                          int64_t k, int act, void* workspace, size_t workspace_bytes, hipStream_t s);

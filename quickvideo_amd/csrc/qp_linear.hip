@@ -10,6 +10,8 @@
 #include <hipblaslt/hipblaslt.h>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <algorithm>
 #include <map>
 #include <mutex>
 #include <tuple>
@@ -46,13 +48,32 @@ std::mutex g_create_mu;
 // accumulation order whenever the first context's tuner had picked another candidate.  That was the "one in ~15 suite runs" rounding
 // mismatch between the one-call and the per-operator path in tests/test_gpu_engine.py: two engines, two contexts, and a
 // first pick != 0 on a noise-dominated tiny shape.  One table for all contexts: a problem is timed ONCE per device and process.
+// What is recorded is the ALGORITHM (hipBLASLt's 16-byte algo blob + its workspace need), not its position in a candidate list: the
+// list hipblasLtMatmulAlgoGetHeuristic returns depends on the workspace limit and the handle it was asked with, so the same index can
+// name different algorithms in two contexts.  A context adopts the record only when its own list holds that very algorithm.
+struct Choice {
+  hipblasLtMatmulAlgo_t algo;
+  size_t ws = 0;
+};
 std::mutex g_choice_mu;
-std::map<std::tuple<int, int64_t, int64_t, int64_t, int, int>, int> g_choice;   // (device, m, n, k, act, bias kind) -> candidate index
+std::map<std::tuple<int, int64_t, int64_t, int64_t, int, int>, Choice> g_choice;   // (device, m, n, k, act, bias kind) -> tuned algorithm
 
-int recorded_choice(int device, int64_t m, int64_t n, int64_t k, int act, int bias_kind) {
+bool recorded_choice(int device, int64_t m, int64_t n, int64_t k, int act, int bias_kind, Choice* out) {
   std::lock_guard<std::mutex> g(g_choice_mu);
   auto it = g_choice.find(std::make_tuple(device, m, n, k, act, bias_kind));
-  return it == g_choice.end() ? -1 : it->second;
+  if (it == g_choice.end()) return false;
+  if (out) *out = it->second;
+  return true;
+}
+
+bool same_algo(const hipblasLtMatmulAlgo_t& a, const hipblasLtMatmulAlgo_t& b) { return memcmp(a.data, b.data, sizeof(a.data)) == 0; }
+
+// position of the recorded algorithm in this context's candidate list, -1 if the list does not hold it (or it needs more workspace
+// than this caller offers)
+int find_choice(const std::vector<hipblasLtMatmulHeuristicResult_t>& cands, const Choice& c, size_t workspace_bytes) {
+  for (int i = 0; i < (int)cands.size(); ++i)
+    if (same_algo(cands[i].algo, c.algo)) return cands[i].workspaceSize <= workspace_bytes ? i : -1;
+  return -1;
 }
 
 #ifdef QP_EXPERIMENTS
@@ -116,8 +137,10 @@ int make_plan(int device, hipblasLtHandle_t handle, Plan& p, int64_t m, int64_t 
   if (st != HIPBLAS_STATUS_SUCCESS || found < 1)
     return qp_fail(QP_ERR_UNSUPPORTED, "qp_linear_act: hipBLASLt has no algorithm for m=%lld n=%lld k=%lld act=%d (status %d)", (long long)m,
                    (long long)n, (long long)k, act, (int)st);
-  int pick = recorded_choice(device, m, n, k, act, bias_kind);  // tuned earlier in this process (any context of this device): same algorithm
-  if (pick < 0 || pick >= found) pick = 0;
+  p.cands.assign(res, res + found);
+  int pick = 0;
+  Choice rec;                                                   // tuned earlier in this process (any context of this device): same algorithm
+  if (recorded_choice(device, m, n, k, act, bias_kind, &rec)) pick = std::max(0, find_choice(p.cands, rec, max_ws));
 #ifdef QP_EXPERIMENTS                                          // developer probe: QP_LT_ALGO_INDEX = i-th heuristic candidate
   if (const char* e = env_lt_algo_index()) { pick = atoi(e); if (pick >= found) pick = found - 1; if (pick < 0) pick = 0; }
 #endif
@@ -126,7 +149,6 @@ int make_plan(int device, hipblasLtHandle_t handle, Plan& p, int64_t m, int64_t 
                                      (long long)n, (long long)k, act, found, pick, res[pick].workspaceSize);
   p.algo = res[pick].algo;
   p.ws = res[pick].workspaceSize;
-  p.cands.assign(res, res + found);
   return QP_OK;
 }
 
@@ -164,9 +186,10 @@ int qp_launch_linear_act(qp_ctx* ctx, const void* x, const void* w, const void* 
   Plan& p = it->second;
   {
     // another context of this device tuned the problem after this one planned it: converge on the recorded pick
-    const int rec = recorded_choice(ctx->device, m, n, k, act, bias_kind);
-    if (rec >= 0 && rec != p.pick && rec < (int)p.cands.size() && p.cands[rec].workspaceSize <= workspace_bytes) {
-      p.algo = p.cands[rec].algo; p.ws = p.cands[rec].workspaceSize; p.pick = rec;
+    Choice rec;
+    if (recorded_choice(ctx->device, m, n, k, act, bias_kind, &rec) && !same_algo(rec.algo, p.algo)) {
+      const int i = find_choice(p.cands, rec, workspace_bytes);
+      if (i >= 0) { p.algo = p.cands[i].algo; p.ws = p.cands[i].workspaceSize; p.pick = i; }
     }
   }
   if (p.ws > workspace_bytes) return qp_fail(QP_ERR_WORKSPACE, "qp_linear_act: workspace %zu < %zu bytes", workspace_bytes, p.ws);
@@ -176,14 +199,18 @@ int qp_launch_linear_act(qp_ctx* ctx, const void* x, const void* w, const void* 
   return QP_OK;
 }
 
-// Which heuristic candidate this context runs for the problem: its index (0 = hipBLASLt's own first pick), or -1 when the context has
-// not seen the problem yet.  *tuned (optional) = 1 when the process holds a stopwatch decision for it on this device.
-int qp_linear_plan_choice_impl(qp_ctx* ctx, int64_t m, int64_t n, int64_t k, int act, int bias_kind, int* tuned) {
+// Which heuristic candidate this context runs for the problem: *choice = its index in the context's own candidate list (0 =
+// hipBLASLt's first pick), or -1 when the context has not seen the problem yet.  *tuned (optional) = 1 when the process holds a
+// stopwatch decision for it on this device, 2 when this context's plan runs exactly that algorithm.
+int qp_linear_plan_choice_impl(qp_ctx* ctx, int64_t m, int64_t n, int64_t k, int act, int bias_kind, int* choice, int* tuned) {
   LtState& st = lt(ctx);
   std::lock_guard<std::mutex> g(st.mu);
-  if (tuned) *tuned = recorded_choice(ctx->device, m, n, k, act, bias_kind) >= 0 ? 1 : 0;
+  Choice rec;
+  const bool have = recorded_choice(ctx->device, m, n, k, act, bias_kind, &rec);
   auto it = st.plans.find(std::make_tuple(m, n, k, act, bias_kind));
-  return it == st.plans.end() ? -1 : it->second.pick;
+  *choice = it == st.plans.end() ? -1 : it->second.pick;
+  if (tuned) *tuned = !have ? 0 : (it != st.plans.end() && same_algo(rec.algo, it->second.algo) ? 2 : 1);
+  return QP_OK;
 }
 
 // Times every heuristic candidate of this problem with COLD weights — the caller passes the same projection of several layers,
@@ -209,11 +236,16 @@ int qp_launch_linear_tune(qp_ctx* ctx, const void* x, const void* const* ws_list
   {
     // already timed in this process on this device (by this or another context): adopt that pick, no second stopwatch run — two
     // runs of the tuner may disagree on candidates within timing noise of each other, and every context must compute the same bits
-    const int rec = recorded_choice(ctx->device, m, n, k, act, bias_kind);
-    if (rec >= 0 && rec < (int)p.cands.size() && p.cands[rec].workspaceSize <= workspace_bytes) {
-      p.algo = p.cands[rec].algo; p.ws = p.cands[rec].workspaceSize; p.pick = rec;
-      if (chosen) *chosen = rec;
-      return QP_OK;
+    // (a record this context's list does not hold — planned under another workspace limit — is re-timed here and replaced: the other
+    // contexts converge on the new record at their next qp_linear_act)
+    Choice rec;
+    if (recorded_choice(ctx->device, m, n, k, act, bias_kind, &rec)) {
+      const int i = find_choice(p.cands, rec, workspace_bytes);
+      if (i >= 0) {
+        p.algo = p.cands[i].algo; p.ws = p.cands[i].workspaceSize; p.pick = i;
+        if (chosen) *chosen = i;
+        return QP_OK;
+      }
     }
   }
   if (bias) LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)));
@@ -255,7 +287,9 @@ int qp_launch_linear_tune(qp_ctx* ctx, const void* x, const void* const* ws_list
   p.pick = best_i;
   {
     std::lock_guard<std::mutex> gc(g_choice_mu);
-    g_choice[std::make_tuple(ctx->device, m, n, k, act, bias_kind)] = best_i;
+    Choice c;
+    c.algo = p.algo; c.ws = p.ws;
+    g_choice[std::make_tuple(ctx->device, m, n, k, act, bias_kind)] = c;
   }
   if (chosen) *chosen = best_i;
   if (env_lt_debug()) fprintf(stderr, "[qp_linear_tune] m=%lld n=%lld k=%lld: candidate %d of %zu, %.1f us per call\n", (long long)m,

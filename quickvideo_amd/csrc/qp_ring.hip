@@ -74,6 +74,12 @@ struct qp_frame_ring {
 
   double t_busy = 0, t_wait_slot = 0, t_wait_h2d = 0, t_copy = 0;
   std::vector<float> h2d_ms;             // per group: H2D finished, ms after `origin` (NaN until known)
+  // One timed event PER GROUP (recorded on the copy stream right behind the copy), kept until qp_frame_ring_h2d_ms resolves them all
+  // against `origin` — a slot's own event is re-recorded `depth` groups later, so a stamp that could not be taken at that moment
+  // (origin set late, or not complete yet) used to be lost for good and the group's frame wait was booked to the ViT.
+  // Videos of more than kMaxStampEvents groups fall back to the per-slot stamps.
+  static constexpr int64_t kMaxStampEvents = 8192;
+  std::vector<hipEvent_t> stamp_ev;
 
   void fail(int status, const std::string& msg) {
     std::lock_guard<std::mutex> lk(mu);
@@ -175,6 +181,12 @@ static void producer_main(qp_frame_ring* r) {
       if (r->read_valid[slot]) e = hipStreamWaitEvent(r->copy_stream, r->read_done[slot], 0);
       if (e == hipSuccess) e = hipMemcpyAsync(r->dev[slot], r->host[slot], (size_t)got, hipMemcpyHostToDevice, r->copy_stream);
       if (e == hipSuccess) e = hipEventRecord(r->h2d_done[slot], r->copy_stream);
+      if (e == hipSuccess && g < (int64_t)r->stamp_ev.size()) {      // the group's own timing event (best effort: a failure costs a stamp)
+        if (hipEventCreate(&r->stamp_ev[g]) != hipSuccess || hipEventRecord(r->stamp_ev[g], r->copy_stream) != hipSuccess) {
+          (void)hipGetLastError();
+          if (r->stamp_ev[g]) { (void)hipEventDestroy(r->stamp_ev[g]); r->stamp_ev[g] = nullptr; }
+        }
+      }
       if (e != hipSuccess) { r->fail(QP_ERR_HIP, std::string("frame ring: H2D enqueue: ") + hipGetErrorString(e)); return; }
       r->h2d_valid[slot] = 1;
       copy += secs(t3, clk::now());
@@ -205,25 +217,31 @@ int qp_frame_ring_create(qp_ctx* ctx, int depth, size_t slot_bytes, void* const*
   QP_REQUIRE(depth >= 1 && depth <= 64 && slot_bytes > 0, QP_ERR_INVALID, "qp_frame_ring_create: depth=%d slot_bytes=%zu", depth, slot_bytes);
   QP_REQUIRE((ctx != nullptr) == (dev_slots != nullptr), QP_ERR_INVALID,
              "qp_frame_ring_create: a device ring needs a context AND device slots; a host-only ring neither");
-  qp_frame_ring* r = new qp_frame_ring();
+  for (int i = 0; i < depth; ++i)
+    QP_REQUIRE(host_slots[i] && (!dev_slots || dev_slots[i]), QP_ERR_INVALID, "qp_frame_ring_create: slot %d is NULL", i);
+  qp_frame_ring* r = nullptr;
+  try {                                                   // allocation failures must not cross the C boundary (std::terminate)
+    r = new qp_frame_ring();
+    r->host.assign(host_slots, host_slots + depth);
+    if (dev_slots) r->dev.assign(dev_slots, dev_slots + depth);
+    r->h2d_valid.assign(depth, 0);
+    r->read_valid.assign(depth, 0);
+    r->slot_free.assign(depth, 1);
+    r->slot_group.assign(depth, -1);
+    r->slot_fill.assign(depth, 0);
+    r->h2d_done.assign(depth, nullptr);
+    r->read_done.assign(depth, nullptr);
+  } catch (const std::exception& ex) {
+    delete r;
+    return qp_fail(QP_ERR_HIP, "qp_frame_ring_create: %s", ex.what());
+  }
   r->device = ctx ? ctx->device : -1;
   r->depth = depth;
   r->slot_bytes = slot_bytes;
   r->copy_stream = (hipStream_t)copy_stream;
-  r->host.assign(host_slots, host_slots + depth);
-  if (dev_slots) r->dev.assign(dev_slots, dev_slots + depth);
-  for (int i = 0; i < depth; ++i)
-    if (!r->host[i] || (dev_slots && !r->dev[i])) { delete r; return qp_fail(QP_ERR_INVALID, "qp_frame_ring_create: slot %d is NULL", i); }
-  r->h2d_valid.assign(depth, 0);
-  r->read_valid.assign(depth, 0);
-  r->slot_free.assign(depth, 1);
-  r->slot_group.assign(depth, -1);
-  r->slot_fill.assign(depth, 0);
   if (r->device >= 0) {
     DeviceScope scope(r->device);
     hipError_t e = scope.ok ? hipSuccess : hipErrorInvalidDevice;
-    r->h2d_done.assign(depth, nullptr);
-    r->read_done.assign(depth, nullptr);
     for (int i = 0; i < depth && e == hipSuccess; ++i) {
       e = hipEventCreate(&r->h2d_done[i]);                                   // timed: h2d_ms
       if (e == hipSuccess) e = hipEventCreateWithFlags(&r->read_done[i], hipEventDisableTiming);
@@ -242,10 +260,16 @@ int qp_frame_ring_create(qp_ctx* ctx, int depth, size_t slot_bytes, void* const*
 static int ring_start(qp_frame_ring* r, int64_t n_groups) {
   QP_REQUIRE(!r->started, QP_ERR_INVALID, "qp_frame_ring_start: the ring has been started already (one video per ring)");
   QP_REQUIRE(n_groups >= 0, QP_ERR_INVALID, "qp_frame_ring_start: n_groups=%lld", (long long)n_groups);
-  r->n_groups = n_groups;
-  r->h2d_ms.assign((size_t)n_groups, NAN);
-  r->started = true;
-  r->th = std::thread(producer_main, r);
+  try {
+    r->n_groups = n_groups;
+    r->h2d_ms.assign((size_t)n_groups, NAN);
+    if (r->device >= 0 && n_groups <= qp_frame_ring::kMaxStampEvents) r->stamp_ev.assign((size_t)n_groups, nullptr);
+    r->started = true;
+    r->th = std::thread(producer_main, r);
+  } catch (const std::exception& ex) {                    // bad_alloc / system_error must not cross the C boundary
+    r->started = false;
+    return qp_fail(QP_ERR_HIP, "qp_frame_ring_start: %s", ex.what());
+  }
   return QP_OK;
 }
 
@@ -276,7 +300,13 @@ int qp_frame_ring_start_file(qp_frame_ring* r, const char* path, int64_t data_of
   r->frame_bytes = frame_bytes;
   r->frames_per_group = frames_per_group;
   r->io_threads = io_threads < 1 ? 1 : (io_threads > 32 ? 32 : io_threads);
-  r->frame_idx.assign(frame_idx, frame_idx + n_frames);
+  try {
+    r->frame_idx.assign(frame_idx, frame_idx + n_frames);
+  } catch (const std::exception& ex) {
+    close(fd);
+    r->fd = -1;
+    return qp_fail(QP_ERR_HIP, "qp_frame_ring_start_file: %s", ex.what());
+  }
   r->fn = file_source;
   r->user = r;
   return ring_start(r, (n_frames + frames_per_group - 1) / frames_per_group);
@@ -290,13 +320,20 @@ int qp_frame_ring_set_origin(qp_frame_ring* r, void* origin_event) {
 }
 
 int qp_frame_ring_acquire(qp_frame_ring* r, int64_t g, void* consumer_stream, void** ptr_out, size_t* bytes_out) {
+  return qp_frame_ring_acquire_for(r, g, consumer_stream, -1, ptr_out, bytes_out);
+}
+
+int qp_frame_ring_acquire_for(qp_frame_ring* r, int64_t g, void* consumer_stream, int64_t timeout_ms, void** ptr_out, size_t* bytes_out) {
   QP_REQUIRE(r && ptr_out && bytes_out, QP_ERR_INVALID, "qp_frame_ring_acquire: NULL argument");
   QP_REQUIRE(r->started && g >= 0, QP_ERR_INVALID, "qp_frame_ring_acquire: group %lld of a ring that %s", (long long)g,
              r->started ? "was started" : "has not been started");
   int slot = (int)(g % r->depth);
   {
     std::unique_lock<std::mutex> lk(r->mu);
-    r->cv.wait(lk, [&] { return r->produced > g || r->error || r->cancelled || r->finished; });
+    auto ready = [&] { return r->produced > g || r->error || r->cancelled || r->finished; };
+    if (timeout_ms < 0) r->cv.wait(lk, ready);
+    else if (!r->cv.wait_for(lk, std::chrono::milliseconds(timeout_ms), ready))
+      return QP_ERR_TIMEOUT;                               // not an error: nothing is written to qp_last_error, call again
     // a group that was published is delivered even if the source failed on a LATER one (the reference's queue hands out the items
     // in front of the exception, qwen25_lvu_interleaved.py:291-292)
     if (r->produced <= g && r->error) return qp_fail(r->error, "%s", r->error_msg.c_str());
@@ -386,9 +423,19 @@ int qp_frame_ring_h2d_ms(qp_frame_ring* r, float* out, int64_t n_out) {
     std::lock_guard<std::mutex> jl(r->join_mu);
     if (r->th.joinable()) r->th.join();
   }
-  if (r->device >= 0 && r->origin)
+  if (r->device >= 0 && r->origin) {
+    DeviceScope scope(r->device);
     for (int s = 0; s < r->depth; ++s)
       if (r->h2d_valid[s] && hipEventSynchronize(r->h2d_done[s]) == hipSuccess) ring_stamp(r, s);
+    // the per-group events: every copy has finished by now (the slots' events above are the last ones on the copy stream); origin is
+    // waited for explicitly so that "not ready" cannot cost a stamp
+    if (!r->stamp_ev.empty() && hipEventSynchronize(r->origin) == hipSuccess)
+      for (size_t g = 0; g < r->stamp_ev.size() && g < r->h2d_ms.size(); ++g) {
+        float ms = NAN;
+        if (r->stamp_ev[g] && hipEventElapsedTime(&ms, r->origin, r->stamp_ev[g]) == hipSuccess) r->h2d_ms[g] = ms;
+        else (void)hipGetLastError();
+      }
+  }
   for (int64_t g = 0; g < n_out; ++g) out[g] = g < (int64_t)r->h2d_ms.size() ? r->h2d_ms[g] : NAN;
   return QP_OK;
 }
@@ -403,6 +450,7 @@ void qp_frame_ring_destroy(qp_frame_ring* r) {
       if (r->h2d_done[s]) (void)hipEventDestroy(r->h2d_done[s]);
       if (r->read_done[s]) (void)hipEventDestroy(r->read_done[s]);
     }
+    for (auto ev : r->stamp_ev) if (ev) (void)hipEventDestroy(ev);
   }
   if (r->fd >= 0) close(r->fd);
   delete r;

@@ -74,6 +74,16 @@ class VideoReaderBase:
         self._cursor += len(sel)
         return torch.from_numpy(self._frames(sel))
 
+    def pending_indices(self) -> Optional[np.ndarray]:
+        """Frame indices of the current selection that have not been handed out yet (None before process()) — what a consumer that
+        fetches the frames itself (the native ring's file source) needs, together with `advance`."""
+        return None if self._idx is None else self._idx[self._cursor:]
+
+    def advance(self, n_frames: int):
+        """Mark the next n_frames of the selection as consumed (they were delivered by other means than next())."""
+        if self._idx is not None:
+            self._cursor = min(len(self._idx), self._cursor + int(n_frames))
+
     def next_into(self, dst: np.ndarray) -> int:
         """next() that decodes STRAIGHT into `dst` (uint8 [>= frame_iter, 3, H, W], e.g. a pinned ring slot: no intermediate array, no
         memcpy); returns the number of frames written, 0 at the end of the selection.  Used by the native frame ring (ring.py)."""
@@ -191,9 +201,15 @@ class ArrayVideoReader(VideoReaderBase):
         """(path, byte offset of frame 0, bytes per frame) when the frames lie contiguously in a plain file (.npy, C order) — what the
         native ring's built-in file source needs (qp_frame_ring_start_file); None otherwise (.pt)."""
         a = self.arr
-        if isinstance(a, np.memmap) and a.flags["C_CONTIGUOUS"]:
+        if isinstance(a, np.memmap) and a.flags["C_CONTIGUOUS"] and type(self)._frames is ArrayVideoReader._frames:
+            # (a subclass that produces its frames differently is not "the file as it lies")
+            if self.height and self.width and (self.height, self.width) != tuple(a.shape[2:]):
+                return None                               # _frames() raises for this request: let the caller hear it there
             return str(a.filename), int(a.offset), int(np.prod(a.shape[1:]))
         return None
+
+    def stored_hw(self):
+        return tuple(int(v) for v in self.arr.shape[2:])
 
 
 class ImageFolderVideoReader(VideoReaderBase):

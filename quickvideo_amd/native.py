@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("QUICKPREFILL_LIB") or os.path.join(_HERE, "libquickprefill.so")   # override: kernel A/B builds (tools/)
 
-QP_OK, QP_ERR_INVALID, QP_ERR_UNSUPPORTED, QP_ERR_HIP, QP_ERR_WORKSPACE = 0, -1, -2, -3, -4
+QP_OK, QP_ERR_INVALID, QP_ERR_UNSUPPORTED, QP_ERR_HIP, QP_ERR_WORKSPACE, QP_ERR_TIMEOUT = 0, -1, -2, -3, -4, -5
 
 
 class QuickPrefillUnavailable(RuntimeError):
@@ -101,7 +101,7 @@ SIGNATURES = {
     "qp_quick_gelu": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "qp_linear_tune": (_i32, [_vp, _vp, _c.POINTER(_vp), _i32, _vp, _i32, _f32, _vp, _i64, _i64, _i64, _i32, _vp, _sz, _vp]),
     "qp_linear_act": (_i32, [_vp, _vp, _vp, _vp, _i32, _f32, _vp, _i64, _i64, _i64, _i32, _vp, _sz, _vp]),
-    "qp_linear_plan_choice": (_i32, [_vp, _i64, _i64, _i64, _i32, _i32, _c.POINTER(_i32)]),
+    "qp_linear_plan_choice": (_i32, [_vp, _i64, _i64, _i64, _i32, _i32, _c.POINTER(_i32), _c.POINTER(_i32)]),
     "qp_dev_switch": (_i32, [_c.c_char_p, _i32]),
     "qp_add_layernorm": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
     # frame ring of the overlap producer (ring.py)
@@ -110,6 +110,7 @@ SIGNATURES = {
     "qp_frame_ring_start_file": (_i32, [_vp, _c.c_char_p, _i64, _i64, _c.POINTER(_i64), _i64, _i32, _i32]),
     "qp_frame_ring_set_origin": (_i32, [_vp, _vp]),
     "qp_frame_ring_acquire": (_i32, [_vp, _i64, _vp, _c.POINTER(_vp), _c.POINTER(_sz)]),
+    "qp_frame_ring_acquire_for": (_i32, [_vp, _i64, _vp, _i64, _c.POINTER(_vp), _c.POINTER(_sz)]),
     "qp_frame_ring_mark_read": (_i32, [_vp, _i64, _vp]),
     "qp_frame_ring_release": (_i32, [_vp, _i64, _vp]),
     "qp_frame_ring_stop": (_i32, [_vp]),
@@ -460,11 +461,9 @@ class QuickPrefillOps:
         """-> (index of the hipBLASLt heuristic candidate THIS context runs for the problem, or -1 if it has not met it;
         whether the process holds a stopwatch decision for it on this device).  bias: None | a bf16/fp32 bias tensor."""
         kind = 0 if bias is None else (2 if bias.dtype == torch.float32 else 1)
-        tuned = _i32(0)
-        rc = self.lib.qp_linear_plan_choice(self.ctx, m, n, k, act, kind, ctypes.byref(tuned))
-        if rc < -1:
-            self._check(rc)
-        return rc, bool(tuned.value)
+        choice, tuned = _i32(-1), _i32(0)
+        self._check(self.lib.qp_linear_plan_choice(self.ctx, m, n, k, act, kind, ctypes.byref(choice), ctypes.byref(tuned)))
+        return choice.value, bool(tuned.value)
 
     def dev_switch(self, name: str, value: int):
         """Developer A/B switch of the launch paths (include/quickprefill.h: qp_dev_switch) — process-wide; the library does not read the

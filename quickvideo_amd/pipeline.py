@@ -74,6 +74,7 @@ class Timings:
     gpu_prefill_busy: float = 0.0      # sum over groups of prefill(g) on the main stream
     gpu_stall_frames: float = 0.0      # main stream idle between groups because group g's frames had not been uploaded yet: TRUE frame wait
     gpu_stall_vit: float = 0.0         # main stream idle because ViT(g) was not finished although its frames were there (ViT not hidden)
+    gpu_stall_unknown: float = 0.0     # idle in front of a group whose upload time is not known (no stamp): booked to neither of the two
     vit_span: float = 0.0              # sum of ViT(g) start->end on its own stream WHILE the prefill shares the CUs (contended)
     vit_uncontended: float = 0.0       # ViT of one group replayed alone after the run, x groups: what the tower costs by itself
                                        # (only with PrefillPipeline.measure_vit_alone; 0 otherwise)
@@ -266,11 +267,19 @@ class _NativeProducer:
     def start(self):
         layout = getattr(self.reader, "raw_layout", None)
         layout = layout() if callable(layout) else None
-        if layout is not None and getattr(self.reader, "_idx", None) is not None and os.environ.get("QP_NATIVE_FILE_SOURCE", "1") != "0":
-            path, off, _ = layout
+        pending = getattr(self.reader, "pending_indices", None)
+        pending = pending() if callable(pending) else None
+        ok = layout is not None and pending is not None and os.environ.get("QP_NATIVE_FILE_SOURCE", "1") != "0"
+        if ok:
+            path, off, frame_bytes = layout
+            stored = getattr(self.reader, "stored_hw", None)
+            # the library pread()s ring.frame_bytes per frame: only when that IS the file's frame (the plan's H x W equals the stored
+            # size); anything else goes through the reader, whose own check raises the ValueError the user should see
+            ok = int(frame_bytes) == self.ring.frame_bytes and (not callable(stored) or tuple(stored()) == tuple(self.ring.frame_shape[1:]))
+        if ok:
             self.native_file = True
-            self.ring.start_file(path, off, self.reader._idx[self.reader._cursor:], self.fpg,
-                                 io_threads=max(1, int(getattr(self.reader, "num_threads", 8))))
+            self.ring.start_file(path, off, pending, self.fpg, io_threads=max(1, int(getattr(self.reader, "num_threads", 8))))
+            self.reader.advance(len(pending))                          # the ring now owns the rest of the selection
         else:
             self.ring.start_reader(self.reader, self.n_groups)
 
@@ -830,16 +839,19 @@ class PrefillPipeline:
         [end of prefill(g-1), start of prefill(g)], is split at the moment group g's frames finished uploading: before it the GPU
         could not have started ViT(g) (frame wait, the producer's fault); after it the ViT simply was not finished (the tower's)."""
         # an event of this process, or (native ring) the copy's finish time in ms after `origin` as the library measured it
-        at = lambda e: (e if e == e else 0.0) * 1e-3 if isinstance(e, float) else origin.elapsed_time(e) * 1e-3   # noqa: E731
+        at = lambda e: e * 1e-3 if isinstance(e, float) else origin.elapsed_time(e) * 1e-3   # noqa: E731  (NaN = the library has no stamp)
         prev_end = 0.0
         tm.group_gaps = []
         for h2d, v0, v1, p0, p1 in trace:
             t_h2d, t_v0, t_v1, t_p0, t_p1 = at(h2d), at(v0), at(v1), at(p0), at(p1)
             stall = max(0.0, t_p0 - prev_end)
             tm.group_gaps.append(stall)
-            frames_part = min(stall, max(0.0, t_h2d - prev_end))
-            tm.gpu_stall_frames += frames_part
-            tm.gpu_stall_vit += stall - frames_part
+            if t_h2d != t_h2d:                            # upload time unknown: do not blame the tower for what may be a frame wait
+                tm.gpu_stall_unknown += stall
+            else:
+                frames_part = min(stall, max(0.0, t_h2d - prev_end))
+                tm.gpu_stall_frames += frames_part
+                tm.gpu_stall_vit += stall - frames_part
             tm.gpu_prefill_busy += t_p1 - t_p0
             tm.vit_span += t_v1 - t_v0
             prev_end = t_p1

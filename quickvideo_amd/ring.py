@@ -14,7 +14,7 @@ from typing import List, Optional
 import numpy as np
 import torch
 
-from .native import FRAME_SOURCE_FN, QP_OK, QuickPrefillError, host_memcpy, load_library
+from .native import FRAME_SOURCE_FN, QP_ERR_TIMEOUT, QP_OK, QuickPrefillError, host_memcpy, load_library
 
 _LIB = None
 
@@ -30,6 +30,8 @@ def _lib():
 class FrameRing:
     """depth pinned host slots + depth device slots (the caller's tensors), one native producer thread per video.
     `ctx` = the qp_ctx handle of the device's QuickPrefillOps (None with dev_slots None: host-only ring, no GPU needed)."""
+
+    POLL_MS = 100          # host wait per qp_frame_ring_acquire_for call
 
     def __init__(self, host_slots: List[torch.Tensor], dev_slots: Optional[List[torch.Tensor]] = None, ctx=None, copy_stream=None):
         self.lib = _lib()
@@ -97,8 +99,14 @@ class FrameRing:
     def acquire(self, g: int, consumer_stream=None) -> torch.Tensor:
         """Frames of group g: a view of the device slot (the consumer stream waits for the copy on the device), or of the host slot."""
         ptr, nbytes = ctypes.c_void_p(), ctypes.c_size_t()
-        rc = self.lib.qp_frame_ring_acquire(self.h, g, consumer_stream.cuda_stream if consumer_stream is not None else None,
-                                            ctypes.byref(ptr), ctypes.byref(nbytes))
+        cs = consumer_stream.cuda_stream if consumer_stream is not None else None
+        # bounded waits in a loop: between two of them the interpreter runs its signal handlers, so Ctrl-C (or a consumer-side error
+        # raised from another thread) ends a generate() whose frame source hangs — the reference's consumer polls its queue every
+        # 10 ms for the same reason (qwen25_lvu_interleaved.py:853-871).  The wait itself is a condition variable: no latency added.
+        while True:
+            rc = self.lib.qp_frame_ring_acquire_for(self.h, g, cs, self.POLL_MS, ctypes.byref(ptr), ctypes.byref(nbytes))
+            if rc != QP_ERR_TIMEOUT:
+                break
         if rc != QP_OK:
             if self.exc is not None:
                 raise self.exc

@@ -52,7 +52,12 @@ static int run_host(void) {
     if (qp_frame_ring_start(r, source, &s, s.groups) == 0) { fprintf(stderr, "second start accepted\n"); return 1; }
     for (g = 0; g < s.groups; ++g) {
       void* p; size_t bytes;
-      CHECK(qp_frame_ring_acquire(r, g, NULL, &p, &bytes));
+      if (g & 1) { CHECK(qp_frame_ring_acquire(r, g, NULL, &p, &bytes)); }
+      else {                                               /* the bounded form, as an interruptible host would call it */
+        int rc;
+        while ((rc = qp_frame_ring_acquire_for(r, g, NULL, 5, &p, &bytes)) == QP_ERR_TIMEOUT) {}
+        CHECK(rc);
+      }
       if (p != host[g % DEPTH] || bytes != (size_t)(g == 10 ? 2 : FPG) * FRAME || check_bytes((unsigned char*)p, g, bytes)) return 1;
       if (g == 4) usleep(50000);                           /* a slow consumer: the source must stop at the ring's depth */
       s.released = g + 1;

@@ -182,6 +182,87 @@ def test_file_source_reads_a_npy_video_without_the_interpreter(tmp_path):
     ring.close()
 
 
+def test_bounded_acquire_times_out_and_leaves_the_ring_intact():
+    """qp_frame_ring_acquire_for: a hung source costs the consumer one bounded wait at a time (the reference polls its queue every
+    10 ms so Ctrl-C works, qwen25_lvu_interleaved.py:853-871) — QP_ERR_TIMEOUT is not an error: no message, the group arrives later."""
+    import ctypes
+    from quickvideo_amd.native import QP_ERR_TIMEOUT, QP_OK
+    gate = threading.Event()
+
+    class Slow:
+        height, width, frame_iter = H, W, 4
+
+        def __init__(self):
+            self.inner = _reader()
+
+        def __next__(self):
+            gate.wait(30)
+            return next(self.inner)
+
+    ring = FrameRing(_slots())
+    ring.start_reader(Slow(), 6)
+    ptr, nbytes = ctypes.c_void_p(), ctypes.c_size_t()
+    before = ring.lib.qp_last_error()
+    t0 = time.perf_counter()
+    assert ring.lib.qp_frame_ring_acquire_for(ring.h, 0, None, 60, ctypes.byref(ptr), ctypes.byref(nbytes)) == QP_ERR_TIMEOUT
+    assert 0.05 <= time.perf_counter() - t0 < 5.0 and ring.lib.qp_last_error() == before
+    ring.POLL_MS = 20
+    threading.Timer(0.2, gate.set).start()
+    got = ring.acquire(0)                                   # the Python face loops over bounded waits
+    assert torch.equal(got, next(_reader()))
+    assert ring.lib.qp_frame_ring_acquire_for(ring.h, 0, None, -1, ctypes.byref(ptr), ctypes.byref(nbytes)) == QP_OK   # < 0: wait for good
+    ring.release(0)
+    ring.close()
+
+
+def test_native_file_source_is_taken_only_for_the_file_as_it_lies(tmp_path):
+    """the library pread()s ring.frame_bytes per frame, so the built-in file source may only run when that IS the stored
+    frame; a plan whose frame size differs goes through the reader (whose own check raises), a partly consumed selection hands over
+    only what is left, and the reader's cursor is advanced."""
+    from quickvideo_amd import pipeline
+    arr = np.random.RandomState(0).randint(0, 256, (12, 3, H, W), dtype=np.uint8)
+    np.save(tmp_path / "v.npy", arr)
+
+    class FakeRing:
+        def __init__(self, shape):
+            self.frame_shape, self.frame_bytes, self.calls = shape, int(np.prod(shape)), []
+
+        def start_file(self, path, off, idx, fpg, io_threads=8):
+            self.calls.append(("file", [int(i) for i in idx]))
+
+        def start_reader(self, reader, n_groups):
+            self.calls.append(("reader", n_groups))
+
+    def producer(reader, shape):
+        p = object.__new__(pipeline._NativeProducer)
+        p.reader, p.n_groups, p.fpg, p.native_file, p.ring = reader, 3, 4, False, FakeRing(shape)
+        p.start()
+        return p
+
+    r = open_video(str(tmp_path / "v.npy"))
+    r.frame_iter = 4
+    r.process(range(12))
+    next(r)                                                                   # one group already consumed by the caller
+    p = producer(r, (3, H, W))
+    assert p.native_file and p.ring.calls == [("file", list(range(4, 12)))] and len(r.pending_indices()) == 0
+    r = open_video(str(tmp_path / "v.npy"))
+    r.process(range(12))
+    p = producer(r, (3, H, W // 2))                                           # the plan's frame is not the stored one
+    assert not p.native_file and p.ring.calls == [("reader", 3)]
+    r = open_video(str(tmp_path / "v.npy"))
+    r.height, r.width = H, W // 2                                             # preset size the reader itself refuses
+    r.process(range(12))
+    assert r.raw_layout() is None
+    with pytest.raises(ValueError, match="no resizer"):
+        next(r)
+
+    class Sub(type(r)):
+        def _frames(self, idx, out=None):
+            return super()._frames(idx, out)
+
+    assert Sub(str(tmp_path / "v.npy")).raw_layout() is None                   # a subclass that makes its frames its own way
+
+
 def test_pt_video_has_no_raw_layout(tmp_path):
     torch.save(torch.zeros(4, 3, H, W, dtype=torch.uint8), tmp_path / "v.pt")
     assert open_video(str(tmp_path / "v.pt")).raw_layout() is None
@@ -273,6 +354,7 @@ def test_generate_gives_the_same_tokens_whichever_producer_feeds_it(tmp_path, mo
         outs[name] = obj.generate("What is shown?", video, max_new_tokens=4)
         t = obj._pipeline.last_timings
         assert t.groups == 6 and t.producer_busy > 0 and t.gpu_prefill_busy > 0 and len(t.group_gaps) == 6, (name, t)
+        assert t.gpu_stall_unknown == 0.0, (name, t)                          # every group's upload time is known (per-group events)
     assert outs["file"] == outs["callback"] == outs["python"] and outs["file"][0].count("<tok_") == 4
     kinds = [(type(p).__name__, getattr(p, "native_file", None)) for p in made]
     assert kinds == [("_NativeProducer", True), ("_NativeProducer", False), ("_Producer", None)], kinds

@@ -1,5 +1,6 @@
 """GPU end-to-end parity: the engine on the HIP library vs (a) the reference's composite golden run (GV5),
 (b) the CPU oracle on the same seeded inputs, at tiny and at real (7B) layer dimensions."""
+import ctypes
 import json
 import os
 
@@ -524,6 +525,32 @@ def test_tuned_gemm_choice_is_shared_by_every_context_of_the_process():
         torch.cuda.synchronize()
         assert torch.equal(o_a.view(torch.int16), o_b.view(torch.int16)) and torch.equal(o_a.view(torch.int16), o_early.view(torch.int16)), (m, n, k, choice)
         differ_from_default += int(choice != 0 and not torch.equal(default_bits, o_a.view(torch.int16)))
+        # a context that plans under ANOTHER workspace limit gets another candidate list; the record is the algorithm itself,
+        # so it either finds that very algorithm in its list (whatever its index there) and computes the same bits, or it does not hold it
+        # and says so (tuned == 1, not 2) — then its own qp_linear_tune re-times, replaces the record, and the others converge on it
+        c = QuickPrefillOps(dev)
+        c._lt_ws[c._stream()] = torch.empty(1 << 20, dtype=torch.uint8, device=dev)
+        o_c = torch.empty_like(o_early)
+        c.linear_act(x, ws[0], None, o_c, c.ACT_NONE)
+        kind = ctypes.c_int32(0)
+        idx = ctypes.c_int32(-1)
+        assert c.lib.qp_linear_plan_choice(c.ctx, m, n, k, 0, 0, ctypes.byref(idx), ctypes.byref(kind)) == 0 and idx.value >= 0
+        torch.cuda.synchronize()
+        if kind.value == 2:
+            assert torch.equal(o_c.view(torch.int16), o_a.view(torch.int16)), (m, n, k, "same algorithm, different bits")
+        else:
+            assert kind.value == 1
+            c.linear_tune(x, ws, None, o_c)                                       # not in its list: re-timed, record replaced
+            c.linear_act(x, ws[0], None, o_c, c.ACT_NONE)
+            a.linear_act(x, ws[0], None, o_a, a.ACT_NONE)                         # a converges if its (larger) list holds c's pick
+            assert c.lib.qp_linear_plan_choice(c.ctx, m, n, k, 0, 0, ctypes.byref(idx), ctypes.byref(kind)) == 0 and kind.value == 2
+            assert a.lib.qp_linear_plan_choice(a.ctx, m, n, k, 0, 0, ctypes.byref(idx), ctypes.byref(kind)) == 0
+            torch.cuda.synchronize()
+            if kind.value == 2:
+                assert torch.equal(o_c.view(torch.int16), o_a.view(torch.int16)), (m, n, k)
+        # the status no longer shares the return value with the index: bad arguments are an error, not "not planned yet"
+        assert c.lib.qp_linear_plan_choice(c.ctx, m, n, k, 7, 0, ctypes.byref(idx), ctypes.byref(kind)) == -1 and idx.value == -1
+        assert b"act=7" in c.lib.qp_last_error()
     print(f"shapes whose tuned candidate rounds differently from candidate 0: {differ_from_default} of 4")
 
 
