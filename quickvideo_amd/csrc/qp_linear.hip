@@ -106,6 +106,14 @@ int handle_for(LtState& st, hipStream_t s, hipblasLtHandle_t* out) {
   return QP_OK;
 }
 
+void destroy_plan(Plan& p) {
+  if (p.desc) (void)hipblasLtMatmulDescDestroy(p.desc);
+  if (p.a) (void)hipblasLtMatrixLayoutDestroy(p.a);
+  if (p.b) (void)hipblasLtMatrixLayoutDestroy(p.b);
+  if (p.d) (void)hipblasLtMatrixLayoutDestroy(p.d);
+  p.desc = nullptr; p.a = p.b = p.d = nullptr;
+}
+
 int make_plan(int device, hipblasLtHandle_t handle, Plan& p, int64_t m, int64_t n, int64_t k, int act, int bias_kind, size_t max_ws) {
   const bool has_bias = bias_kind != 0;
   LT_CHECK(hipblasLtMatmulDescCreate(&p.desc, HIPBLAS_COMPUTE_32F, HIP_R_32F));
@@ -138,9 +146,22 @@ int make_plan(int device, hipblasLtHandle_t handle, Plan& p, int64_t m, int64_t 
     return qp_fail(QP_ERR_UNSUPPORTED, "qp_linear_act: hipBLASLt has no algorithm for m=%lld n=%lld k=%lld act=%d (status %d)", (long long)m,
                    (long long)n, (long long)k, act, (int)st);
   p.cands.assign(res, res + found);
-  int pick = 0;
+  // the first candidate that fits the caller's workspace: this hipBLASLt build returns stream-K candidates that want 64 MB even when the
+  // preference says 1 MB (found by the test of ADVICE r5's fix), so MAX_WORKSPACE_BYTES is a hint here, not a filter
+  int pick = -1;
+  for (int i = 0; i < found && pick < 0; ++i)
+    if (res[i].workspaceSize <= max_ws) pick = i;
+  if (pick < 0) {
+    size_t need = res[0].workspaceSize;
+    for (int i = 1; i < found; ++i) need = std::min(need, (size_t)res[i].workspaceSize);
+    return qp_fail(QP_ERR_WORKSPACE, "qp_linear_act: workspace %zu < %zu bytes (the smallest any of hipBLASLt's %d candidates for m=%lld n=%lld k=%lld needs)",
+                   max_ws, need, found, (long long)m, (long long)n, (long long)k);
+  }
   Choice rec;                                                   // tuned earlier in this process (any context of this device): same algorithm
-  if (recorded_choice(device, m, n, k, act, bias_kind, &rec)) pick = std::max(0, find_choice(p.cands, rec, max_ws));
+  if (recorded_choice(device, m, n, k, act, bias_kind, &rec)) {
+    const int i = find_choice(p.cands, rec, max_ws);
+    if (i >= 0) pick = i;
+  }
 #ifdef QP_EXPERIMENTS                                          // developer probe: QP_LT_ALGO_INDEX = i-th heuristic candidate
   if (const char* e = env_lt_algo_index()) { pick = atoi(e); if (pick >= found) pick = found - 1; if (pick < 0) pick = 0; }
 #endif
@@ -157,13 +178,7 @@ int make_plan(int device, hipblasLtHandle_t handle, Plan& p, int64_t m, int64_t 
 void qp_lt_destroy(void* lt_state) {
   LtState* st = static_cast<LtState*>(lt_state);
   if (!st) return;
-  for (auto& kv : st->plans) {
-    Plan& p = kv.second;
-    if (p.desc) (void)hipblasLtMatmulDescDestroy(p.desc);
-    if (p.a) (void)hipblasLtMatrixLayoutDestroy(p.a);
-    if (p.b) (void)hipblasLtMatrixLayoutDestroy(p.b);
-    if (p.d) (void)hipblasLtMatrixLayoutDestroy(p.d);
-  }
+  for (auto& kv : st->plans) destroy_plan(kv.second);
   for (auto& kv : st->handles) (void)hipblasLtDestroy(kv.second);
   delete st;
 }
@@ -180,7 +195,7 @@ int qp_launch_linear_act(qp_ctx* ctx, const void* x, const void* w, const void* 
   if (it == st.plans.end()) {
     Plan p;
     int rc = make_plan(ctx->device, handle, p, m, n, k, act, bias_kind, workspace_bytes);
-    if (rc) return rc;
+    if (rc) { destroy_plan(p); return rc; }
     it = st.plans.emplace(key, p).first;
   }
   Plan& p = it->second;
@@ -192,7 +207,15 @@ int qp_launch_linear_act(qp_ctx* ctx, const void* x, const void* w, const void* 
       if (i >= 0) { p.algo = p.cands[i].algo; p.ws = p.cands[i].workspaceSize; p.pick = i; }
     }
   }
-  if (p.ws > workspace_bytes) return qp_fail(QP_ERR_WORKSPACE, "qp_linear_act: workspace %zu < %zu bytes", workspace_bytes, p.ws);
+  if (p.ws > workspace_bytes) {
+    // planned under a larger workspace than this call offers: the first candidate that fits (a different algorithm = possibly different
+    // rounding; callers who want one set of bits keep one workspace size, as QuickPrefillOps does)
+    int fit = -1;
+    for (int i = 0; i < (int)p.cands.size() && fit < 0; ++i)
+      if (p.cands[i].workspaceSize <= workspace_bytes) fit = i;
+    if (fit < 0) return qp_fail(QP_ERR_WORKSPACE, "qp_linear_act: workspace %zu < %zu bytes", workspace_bytes, p.ws);
+    p.algo = p.cands[fit].algo; p.ws = p.cands[fit].workspaceSize; p.pick = fit;
+  }
   if (bias) LT_CHECK(hipblasLtMatmulDescSetAttribute(p.desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)));
   const float beta = 0.f;
   LT_CHECK(hipblasLtMatmul(handle, p.desc, &alpha, w, p.a, x, p.b, &beta, out, p.d, out, p.d, &p.algo, workspace, workspace_bytes, s));
@@ -229,7 +252,7 @@ int qp_launch_linear_tune(qp_ctx* ctx, const void* x, const void* const* ws_list
   if (it == st.plans.end()) {
     Plan p;
     int rc = make_plan(ctx->device, handle, p, m, n, k, act, bias_kind, workspace_bytes);
-    if (rc) return rc;
+    if (rc) { destroy_plan(p); return rc; }
     it = st.plans.emplace(key, p).first;
   }
   Plan& p = it->second;
