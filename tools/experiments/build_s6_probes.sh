@@ -14,3 +14,4 @@ build() { tag=$1; shift
 build nofma -DQP_S6_NOFMA
 build nosum -DQP_S6_NOSUM
 build nofma_nosum -DQP_S6_NOFMA -DQP_S6_NOSUM
+build dot2sum -DQP_S6_DOT2SUM
