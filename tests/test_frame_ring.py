@@ -263,6 +263,23 @@ def test_native_file_source_is_taken_only_for_the_file_as_it_lies(tmp_path):
     assert Sub(str(tmp_path / "v.npy")).raw_layout() is None                   # a subclass that makes its frames its own way
 
 
+def test_stall_attribution_keeps_unknown_upload_times_apart():
+    """pipeline._device_breakdown: the idle time in front of a group is split at the moment its frames finished uploading — frame wait
+    before, ViT wait after.  A group whose upload time the library could not stamp (NaN) is booked to NEITHER (it used to read
+    as 0.0 = "uploaded long ago", i.e. the whole stall went to the tower)."""
+    from quickvideo_amd.pipeline import PrefillPipeline, Timings
+    tm = Timings()
+    #        h2d_done  vit0   vit1   prefill0 prefill1   (ms after origin; floats = the native ring's stamps)
+    trace = [(5.0,     6.0,   9.0,   10.0,    20.0),      # group 0: 10 ms in front of it, frames there at 5 -> 5 frames + 5 ViT
+             (31.0,    32.0,  33.0,  34.0,    40.0),      # group 1: prefill(0) ended at 20, frames at 31 -> 11 frames + 3 ViT
+             (float("nan"), 41.0, 47.0, 48.0, 50.0)]      # group 2: 8 ms idle, upload time unknown -> unattributed
+    PrefillPipeline._device_breakdown(tm, None, trace)
+    assert tm.group_gaps == pytest.approx([0.010, 0.014, 0.008])
+    assert tm.gpu_stall_frames == pytest.approx(0.016) and tm.gpu_stall_vit == pytest.approx(0.008)
+    assert tm.gpu_stall_unknown == pytest.approx(0.008)
+    assert tm.gpu_prefill_busy == pytest.approx(0.018) and tm.vit_span == pytest.approx(0.010)
+
+
 def test_pt_video_has_no_raw_layout(tmp_path):
     torch.save(torch.zeros(4, 3, H, W, dtype=torch.uint8), tmp_path / "v.pt")
     assert open_video(str(tmp_path / "v.pt")).raw_layout() is None
