@@ -325,6 +325,23 @@ class VisionTower:
         lens = seqlens[seqlens > 0] * merge * merge
         return win.to(device), lens.to(device)
 
+    @staticmethod
+    def _qwen25_mlp_padded(b):
+        """(gate | up weight [2 Ip, d], bias [2 Ip], down weight [d, Ip]) of a Qwen2.5-VL vision block with the intermediate width zero-
+        padded to a multiple of 128; built once per block and kept beside the checkpoint's tensors."""
+        cached = getattr(b, "_mlp_padded", None)
+        if cached is None:
+            it, d = b.gate_w.shape
+            ip = (it + 127) // 128 * 128
+            gu_w = torch.zeros(2 * ip, d, dtype=b.gate_w.dtype, device=b.gate_w.device)
+            gu_b = torch.zeros(2 * ip, dtype=b.gate_b.dtype, device=b.gate_b.device)
+            gu_w[:it], gu_w[ip:ip + it] = b.gate_w, b.up_w
+            gu_b[:it], gu_b[ip:ip + it] = b.gate_b, b.up_b
+            down_wp = torch.zeros(b.down_w.shape[0], ip, dtype=b.down_w.dtype, device=b.down_w.device)
+            down_wp[:, :it] = b.down_w
+            cached = b._mlp_padded = (gu_w, gu_b, down_wp)
+        return cached
+
     def _forward_qwen25(self, pixel_rows: torch.Tensor, grid_thw: Tuple[int, int, int]) -> torch.Tensor:
         s, w = self.spec, self.w
         t, h, wd = grid_thw
@@ -360,6 +377,7 @@ class VisionTower:
         wmap = torch.where(wvalid, wmap, torch.zeros_like(wmap))
         rms_t = lambda z, g: (z.float() * torch.rsqrt(z.float().pow(2).mean(-1, keepdim=True) + 1e-6)).to(z.dtype) * g
         fused = ops is not None and d % 8 == 0
+        fused_mlp = fused and hasattr(ops, "swiglu") and x.is_cuda and os.environ.get("QP_VIT25_FUSED_MLP", "1") == "1"   # A/B: tools/bench_vit.py
         pend = None                                   # residual branch not yet added to x (fused into the next RMSNorm launch)
         ybuf = torch.empty(n, d, dtype=x.dtype, device=x.device) if fused else None
         if fused:
@@ -407,6 +425,17 @@ class VisionTower:
                     a = a.reshape(n, H * hd)
             pend = F.linear(a, b.proj_w, b.proj_b)
             y = rms(b.n2)
+            if fused_mlp:
+                # gate | up as ONE GEMM into [n, 2 Ip] and silu(gate) * up as ONE pass (qp_swiglu: torch's bf16 rounding points), instead of
+                # two GEMMs + silu + mul (three passes over [n, I]).  I = 3420 is not a multiple of 8 (16-byte vectors) nor of any GEMM
+                # tile: the weights are zero-padded ONCE to Ip = 3456 = 27 x 128 — padded gate / up columns are silu(0) * 0 = 0 and meet
+                # zero columns of the padded down projection, so the result is that of the unpadded MLP.
+                gu_w, gu_b, down_wp = self._qwen25_mlp_padded(b)
+                gu = F.linear(y, gu_w, gu_b)
+                act = torch.empty(n, gu_w.shape[0] // 2, dtype=x.dtype, device=x.device)
+                ops.swiglu(gu, act)
+                pend = F.linear(act, down_wp, b.down_b)
+                continue
             y = F.silu(F.linear(y, b.gate_w, b.gate_b)) * F.linear(y, b.up_w, b.up_b)
             pend = F.linear(y, b.down_w, b.down_b)
         y = rms(w.ln_q_w).view(-1, d * unit)

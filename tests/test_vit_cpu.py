@@ -3,6 +3,7 @@ tower with the same weights, and the GPU-side patchify against the HF processor'
 import numpy as np
 import pytest
 import torch
+import torch.nn.functional as F
 
 from quickvideo_amd.vit import VisionSpec, VisionTower, VisionWeights, patchify_frames, vision_pos_ids, CLIP_MEAN, CLIP_STD
 
@@ -100,3 +101,22 @@ def test_towers_match_hf_fixture_at_real_width(name, golden_dir):
     got = VisionTower(w).forward(pix, tuple(meta["grid"])).numpy()
     assert got.shape == ref.shape
     assert np.abs(got - ref).max() <= 2e-3 * meta["out_absmax"], np.abs(got - ref).max()
+
+
+def test_qwen25_padded_mlp_is_the_unpadded_mlp():
+    """vit.VisionTower._qwen25_mlp_padded: the intermediate width of the Qwen2.5-VL vision MLP (3420: no multiple of 8, so no 16-byte
+    vectors, and of no GEMM tile) zero-padded to a multiple of 128.  Padded gate / up columns are silu(0) * 0 = 0 and meet zero columns of
+    the padded down projection: in exact arithmetic — and in fp32 here — the padded MLP IS the unpadded one."""
+    from quickvideo_amd.vit import VisionBlockWeights25, VisionTower
+    g = torch.Generator().manual_seed(3)
+    d, it, n = 64, 172, 37
+    r = lambda *s: torch.randn(*s, generator=g, dtype=torch.float64) * 0.3
+    b = VisionBlockWeights25(None, None, None, None, None, None, r(it, d), r(it), r(it, d), r(it), r(d, it), r(d))
+    y = r(n, d)
+    want = F.linear(F.silu(F.linear(y, b.gate_w, b.gate_b)) * F.linear(y, b.up_w, b.up_b), b.down_w, b.down_b)
+    gu_w, gu_b, down_wp = VisionTower._qwen25_mlp_padded(b)
+    ip = gu_w.shape[0] // 2
+    assert ip == 256 and down_wp.shape == (d, ip) and VisionTower._qwen25_mlp_padded(b)[0] is gu_w      # built once
+    gu = F.linear(y, gu_w, gu_b)
+    got = F.linear(F.silu(gu[:, :ip]) * gu[:, ip:], down_wp, b.down_b)
+    assert torch.equal(gu[:, it:ip], torch.zeros(n, ip - it, dtype=torch.float64)) and torch.allclose(got, want, rtol=0, atol=1e-12)
