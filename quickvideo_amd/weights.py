@@ -39,6 +39,27 @@ def tp_head_partition(hq: int, hkv: int, tp_rank: int, tp_size: int):
     return idx, kvh, 1
 
 
+def padded_inter(li: int) -> int:
+    """Width a rank's MLP column shard is stored at.  A shard width that is no multiple of 64 (72B: 29568 / 8 = 3696, / 4 = 7392) makes
+    the down projection's K ragged: measured on hipBLASLt (tools/probe/probe_gemm_alignment.py, profiles/r6j_*): K = 3696 -> 3712 is 24-26 %
+    faster at M = 960 / 2240.  Such shards are zero-padded to the next multiple of 128 (so gate | up has N a multiple of 256): the padded
+    gate / up rows give silu(0) * 0 = 0 and meet zero columns of the down shard — the same numbers, bit for bit in exact arithmetic."""
+    return li if li % 64 == 0 else (li + 127) // 128 * 128
+
+
+def pad_mlp_shard(w_gate_up: torch.Tensor, w_down: torch.Tensor):
+    """([2 li, d], [d, li]) -> ([2 lip, d], [d, lip]) with lip = padded_inter(li): gate rows, zeros, up rows, zeros | zero columns."""
+    li = w_down.shape[1]
+    lip = padded_inter(li)
+    if lip == li:
+        return w_gate_up, w_down
+    gu = torch.zeros(2 * lip, w_gate_up.shape[1], dtype=w_gate_up.dtype, device=w_gate_up.device)
+    gu[:li], gu[lip:lip + li] = w_gate_up[:li], w_gate_up[li:]
+    dn = torch.zeros(w_down.shape[0], lip, dtype=w_down.dtype, device=w_down.device)
+    dn[:, :li] = w_down
+    return gu, dn
+
+
 @dataclass
 class LayerWeights:
     ln1: torch.Tensor        # [d]
@@ -76,6 +97,7 @@ class DecoderWeights:
 
     @property
     def local_inter(self) -> int:
+        """Columns of this rank's MLP shard AS STORED (zero-padded to a GEMM-friendly width when I / tp is ragged: padded_inter)."""
         return self.layers[0].w_down.shape[1]
 
     @staticmethod
@@ -113,10 +135,12 @@ class DecoderWeights:
             w_qkv = torch.cat([q_rows(qw), kw[kv_lo * D:(kv_lo + lkv) * D], vw[kv_lo * D:(kv_lo + lkv) * D]], 0)
             b_qkv = torch.cat([q_rows(qb), kb[kv_lo * D:(kv_lo + lkv) * D], vb[kv_lo * D:(kv_lo + lkv) * D]], 0)
             gw, uw, dw = g(p + "mlp.gate_proj.weight"), g(p + "mlp.up_proj.weight"), g(p + "mlp.down_proj.weight")
+            w_gu, w_dn = to(torch.cat([gw[i_lo:i_lo + li], uw[i_lo:i_lo + li]], 0)), to(dw[:, i_lo:i_lo + li])
+            if tp_size > 1:
+                w_gu, w_dn = pad_mlp_shard(w_gu, w_dn)
             layers.append(LayerWeights(
                 ln1=to(g(p + "input_layernorm.weight")), w_qkv=to(w_qkv), b_qkv=to(b_qkv),
-                w_o=to(q_cols(ow)), ln2=to(g(p + "post_attention_layernorm.weight")),
-                w_gate_up=to(torch.cat([gw[i_lo:i_lo + li], uw[i_lo:i_lo + li]], 0)), w_down=to(dw[:, i_lo:i_lo + li])))
+                w_o=to(q_cols(ow)), ln2=to(g(p + "post_attention_layernorm.weight")), w_gate_up=w_gu, w_down=w_dn))
         embed = to(g("embed_tokens.weight"))
         lm = embed if spec.tie_embeddings and "lm_head.weight" not in sd else to(g("lm_head.weight"))
         return DecoderWeights(spec, embed, layers, to(g("norm.weight")), lm, tp_rank, tp_size, l0, spec.n_layers)
@@ -162,6 +186,7 @@ class DecoderWeights:
                 w_o = q_cols(w_o).contiguous()
                 w_gu = torch.cat([w_gu[i_lo:i_lo + li], w_gu[I + i_lo:I + i_lo + li]], 0).contiguous()
                 w_dn = w_dn[:, i_lo:i_lo + li].contiguous()
+                w_gu, w_dn = pad_mlp_shard(w_gu, w_dn)
             layers.append(LayerWeights(ln1=torch.ones(d, device=device, dtype=dtype), w_qkv=w_qkv, b_qkv=b_qkv, w_o=w_o,
                                        ln2=torch.ones(d, device=device, dtype=dtype), w_gate_up=w_gu, w_down=w_dn))
         return DecoderWeights(spec, embed, layers, norm, lm_head, tp_rank, tp_size, l0, total)

@@ -218,7 +218,7 @@ def test_tp2_ranks_on_one_gpu_reproduce_single_process_kept_lists():
     mp.spawn(_tp_gloo_worker, args=(world, _free_port(), ret), nprocs=world, join=True)
     for r in range(world):
         assert f"error{r}" not in ret, ret.get(f"error{r}")
-        assert ret[f"heads{r}"] == (8, 1, 3696)
+        assert ret[f"heads{r}"] == (8, 1, 3712)                  # 3696 columns stored zero-padded to 29 x 128 (weights.padded_inter, round 6)
     ref, k0 = ret["kept"], ret["k0"]
     for a, b in zip(ret["kept0"], ret["kept1"]):
         assert np.array_equal(a, b), "ranks disagree on the kept tokens"                      # identical on every rank, every layer
