@@ -394,9 +394,16 @@ class VisionTower:
                 x, pend = x + pend, None
             return rms_t(x, g)
 
+        # the tower's GEMMs through the library's hipBLASLt path with the candidate that is fastest for the shape (qp_linear_tune over the same
+        # projection of all blocks, cold weights): torch's F.linear takes the first candidate, which at a group of the 1-hour video is 3-10 %
+        # slower on these K = 1280 shapes (tools/probe/probe_vit25_gemm_tuning.py).  QP_VIT_LT=0: torch (A/B).
+        blocks = w.blocks
+        use_lt = fused_mlp and hasattr(ops, "linear_tune") and os.environ.get("QP_VIT_LT", "1") == "1"
+        if use_lt:
+            padded = [self._qwen25_mlp_padded(bb) for bb in blocks]
         for li, b in enumerate(w.blocks):
             y = rms(b.n1)
-            qkv = F.linear(y, b.qkv_w, b.qkv_b)
+            qkv = self._lt("qkv25", y, b.qkv_w, b.qkv_b, peers=[bb.qkv_w for bb in blocks]) if use_lt else F.linear(y, b.qkv_w, b.qkv_b)
             full = li in s.fullatt_blocks
             if ops is not None:
                 ops.vit_rope(qkv, cos_h, sin_h, H, hd)
@@ -423,8 +430,15 @@ class VisionTower:
                     a = torch.empty(n, H, hd, dtype=x.dtype, device=x.device)
                     a[wmap[wvalid]] = o.transpose(1, 2)[wvalid]
                     a = a.reshape(n, H * hd)
-            pend = F.linear(a, b.proj_w, b.proj_b)
+            pend = self._lt("proj25", a, b.proj_w, b.proj_b, peers=[bb.proj_w for bb in blocks]) if use_lt else F.linear(a, b.proj_w, b.proj_b)
             y = rms(b.n2)
+            if use_lt:
+                gu_w, gu_b, down_wp = padded[li]
+                gu = self._lt("gu25", y, gu_w, gu_b, peers=[pp[0] for pp in padded])
+                act = torch.empty(n, gu_w.shape[0] // 2, dtype=x.dtype, device=x.device)
+                ops.swiglu(gu, act)
+                pend = self._lt("down25", act, down_wp, b.down_b, peers=[pp[2] for pp in padded])
+                continue
             if fused_mlp:
                 # gate | up as ONE GEMM into [n, 2 Ip] and silu(gate) * up as ONE pass (qp_swiglu: torch's bf16 rounding points), instead of
                 # two GEMMs + silu + mul (three passes over [n, I]).  I = 3420 is not a multiple of 8 (16-byte vectors) nor of any GEMM
