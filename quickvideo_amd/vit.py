@@ -394,11 +394,12 @@ class VisionTower:
                 x, pend = x + pend, None
             return rms_t(x, g)
 
-        # the tower's GEMMs through the library's hipBLASLt path with the candidate that is fastest for the shape (qp_linear_tune over the same
-        # projection of all blocks, cold weights): torch's F.linear takes the first candidate, which at a group of the 1-hour video is 3-10 %
-        # slower on these K = 1280 shapes (tools/probe/probe_vit25_gemm_tuning.py).  QP_VIT_LT=0: torch (A/B).
+        # QP_VIT25_LT=1 (opt-in, A/B): the tower's GEMMs through the library's hipBLASLt path with the candidate qp_linear_tune measured fastest
+        # (over the same projection of all blocks, cold weights) instead of torch's F.linear (hipBLASLt's first candidate).  Measured
+        # (profiles/r6n_qwen25_tower_tuned_gemms_ab.txt): a group of the 1-hour video 15.4-15.5 -> 15.1 ms (-2 %), a 560x1008 group 34.1-34.5 ->
+        # 35.6 ms (+3.5 %: at 23 040 rows the stopwatch's picks lose to the default) — not a default.
         blocks = w.blocks
-        use_lt = fused_mlp and hasattr(ops, "linear_tune") and os.environ.get("QP_VIT_LT", "1") == "1"
+        use_lt = fused_mlp and hasattr(ops, "linear_tune") and os.environ.get("QP_VIT25_LT", "0") == "1"
         if use_lt:
             padded = [self._qwen25_mlp_padded(bb) for bb in blocks]
         for li, b in enumerate(w.blocks):
