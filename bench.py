@@ -847,7 +847,12 @@ def pipeline_leg(name, eng, device, modes=("overlapped", "sequential"), warm_vid
     from quickvideo_amd.lvu import _VIT
     mname, frames, fh, fw, gs, rho, prefix, tail = CONFIGS[name]
     if model is None:
-        vis = VisionWeights.synthetic(_VIT[mname], device, seed=0)
+        vspec = _VIT[mname]
+        if os.environ.get("QP_BENCH_VIT_ARCH") == "2.5":        # secondary record: the reference's own family — the Qwen2.5-VL tower (window
+            import dataclasses                                  # attention, RMSNorm, gated MLP) in front of the same decoder
+            from quickvideo_amd.vit import QWEN25_VL_VIT_7B
+            vspec = dataclasses.replace(QWEN25_VL_VIT_7B, out_hidden=vspec.out_hidden)
+        vis = VisionWeights.synthetic(vspec, device, seed=0)
         m = QwenVLNative(eng.w, vis, device, name=mname)
         m.engine = eng                                           # same engine (KV arena, tuned GEMM plans) as the headline pass
         pipe = PrefillPipeline(m, eng.cfg, SyntheticProcessor(eng.spec), ops=eng.ops)
@@ -908,6 +913,7 @@ def pipeline_leg(name, eng, device, modes=("overlapped", "sequential"), warm_vid
             continue
         res[mode] = _leg_record(pipe.last_timings, overlap, threads)
         res[mode]["side_streams"] = pipe.stream_report
+        res[mode]["vision_tower"] = m.vision.spec.arch
         res[mode]["producer"]["real_work_thread_seconds"] = round(getattr(rd, "work_seconds", 0.0), 2)
         if burner:
             res[mode]["host_stress"] = {"burner_processes": burner.native, "python_threads_holding_the_gil": burner.python_threads,
