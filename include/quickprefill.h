@@ -55,7 +55,7 @@ int qp_create(qp_ctx** out, int device);
 int qp_dev_switch(const char* name, int value);
 void qp_destroy(qp_ctx* ctx);
 const char* qp_last_error(void);
-const char* qp_version(void);          /* "quickprefill-mi355x 0.7 (gfx950)": 0.3 prune_mode became a per-call argument; 0.4 qp_prefill_segment; 0.5 qp_linear_plan_choice; 0.6 qp_frame_ring_*; 0.7 qp_linear_plan_choice returns a status, qp_frame_ring_acquire_for */
+const char* qp_version(void);          /* "quickprefill-mi355x 0.7 (gfx950)": 0.3 prune_mode became a per-call argument; 0.4 qp_prefill_segment; 0.5 qp_linear_plan_choice; 0.6 qp_frame_ring_*; 0.7 qp_linear_plan_choice returns a status, qp_frame_ring_acquire_for, qp_patchify */
 int qp_device_cus(const qp_ctx* ctx);
 
 /* Host helper of the overlap producer (no device work): memcpy `bytes` from src to dst (e.g. decoded uint8 frames into a pinned
@@ -319,6 +319,15 @@ int qp_linear_tune(qp_ctx* ctx, const void* x, const void* const* weights, int n
  * pick), -1 if the context has not seen it; *tuned (optional) = 0 no stopwatch decision on record for the device, 1 on record, 2 on
  * record and this context's plan runs exactly that algorithm.  bias_kind: 0 none, 1 bf16, 2 fp32.  Host-side query, no device work. */
 int qp_linear_plan_choice(qp_ctx* ctx, int64_t m, int64_t n, int64_t k, int act, int bias_kind, int* choice, int* tuned);
+/* Front end, first step (the reference: HF image processor on the CPU under the GIL, lvu/models/qwen25_lvu_interleaved.py:252-271, 318-340; then
+ * H2D of 4 bytes per value, qwen25_lvu.py:691): uint8 frames [n_frames, 3, height, width] on the device -> pixel rows
+ * [n_frames / temporal_patch * (height / patch) * (width / patch)][row_elems] bf16 in the HF Qwen2VLImageProcessor order
+ * (t, h/merge, w/merge, merge, merge | C, temporal_patch, patch, patch), rescaled + normalised, in one pass.  lut_bf16: 3 x 256 bf16 on the
+ * device, lut[c][v] = the normalised value of byte v in channel c — computed by the CALLER with the expression of its own reference path, so
+ * the result is bit-identical to it by construction.  row_elems >= 3 * temporal_patch * patch^2 (a multiple of 8); the columns behind the
+ * patch are written as zeros (a tile-aligned K for the patch-embedding GEMM: 1176 -> 1280). */
+int qp_patchify(qp_ctx* ctx, const void* frames_u8, int n_frames, int height, int width, int patch, int temporal_patch, int merge,
+                const void* lut_bf16, void* out, int row_elems, void* stream);
 /* out = y * sigmoid(1.702 y) with torch's bf16 rounding steps (hidden_act = quick_gelu). */
 int qp_quick_gelu(qp_ctx* ctx, const void* x, void* out, int64_t n_elems, void* stream);
 

@@ -557,6 +557,19 @@ int qp_vit_attn_varlen(qp_ctx* ctx, const void* qkv, const int32_t* cu_seqlens, 
   return qp_launch_vit_attn(ctx, qkv, n_seq, max_seq_len, heads, scale, out, cu_seqlens, (hipStream_t)stream);
 }
 
+int qp_patchify(qp_ctx* ctx, const void* frames_u8, int n_frames, int height, int width, int patch, int temporal_patch, int merge,
+                const void* lut_bf16, void* out, int row_elems, void* stream) {
+  QP_REQUIRE(ctx && frames_u8 && lut_bf16 && out, QP_ERR_INVALID, "qp_patchify: NULL argument");
+  QP_REQUIRE(patch > 0 && temporal_patch > 0 && merge > 0 && n_frames > 0 && n_frames % temporal_patch == 0 && height > 0 && width > 0 &&
+                 height % (patch * merge) == 0 && width % (patch * merge) == 0,
+             QP_ERR_INVALID, "qp_patchify: %d frames of %d x %d are not aligned to the patch grid (patch %d, temporal %d, merge %d)", n_frames, height,
+             width, patch, temporal_patch, merge);
+  QP_REQUIRE(row_elems >= 3 * temporal_patch * patch * patch && row_elems % 8 == 0 && aligned16(out), QP_ERR_INVALID,
+             "qp_patchify: row_elems=%d (at least %d, a multiple of 8; out 16-byte aligned)", row_elems, 3 * temporal_patch * patch * patch);
+  QP_REQUIRE((int64_t)n_frames * 3 * height * width < (1ll << 40), QP_ERR_UNSUPPORTED, "qp_patchify: frame block too large");
+  return qp_launch_patchify(frames_u8, lut_bf16, out, n_frames, height, width, patch, temporal_patch, merge, row_elems, (hipStream_t)stream);
+}
+
 int qp_quick_gelu(qp_ctx* ctx, const void* x, void* out, int64_t n_elems, void* stream) {
   QP_REQUIRE(ctx && x && out, QP_ERR_INVALID, "qp_quick_gelu: NULL argument");
   QP_REQUIRE(n_elems >= 0 && n_elems % 8 == 0 && aligned16(x) && aligned16(out), QP_ERR_INVALID, "qp_quick_gelu: size/alignment");

@@ -119,6 +119,7 @@ int qp_launch_vit_attn(const qp_ctx* ctx, const void* qkv, int64_t n_seq, int64_
                        const int* cu_seqlens, hipStream_t s);
 int qp_launch_vit_rope(void* qkv, const float* cos_t, const float* sin_t, int64_t n, int heads, int head_dim, hipStream_t s);
 int qp_launch_quick_gelu(const void* x, void* out, int64_t n_elems, hipStream_t s);
+int qp_launch_patchify(const void* frames, const void* lut, void* out, int n_frames, int H, int W, int ps, int tp, int mg, int row_elems, hipStream_t s);
 int qp_launch_add_layernorm(void* x, const void* delta, const void* w, const void* b, void* out, int64_t n, int hidden, float eps,
                             hipStream_t s);
 int qp_launch_gemv(const qp_ctx* ctx, const void* w, const void* x, const void* norm_w, float eps, const void* bias, void* out,

@@ -195,6 +195,56 @@ int qp_launch_quick_gelu(const void* x, void* out, int64_t n_elems, hipStream_t 
   return qp_check_launch("quick_gelu");
 }
 
+// Front end, first step: uint8 frames [F, 3, H, W] -> pixel rows [gt*gh*gw][row_elems] bf16 in the HF Qwen2VLImageProcessor order
+// (t, h/mg, w/mg, mg, mg | C, tp, ps, ps) [3P], rescaled + CLIP-normalised, in ONE pass.  The reference does this on the CPU under the GIL (HF
+// processor, qwen25_lvu_interleaved.py:252-271, 318-340) and uploads 4 bytes per value; rounds 1-5 did it on the GPU with five torch passes.
+// The arithmetic is a 3 x 256-entry table: lut[c][v] = bf16((v * (1/255) - mean[c]) / std[c]) is computed ONCE by the caller with the very
+// expression the torch path uses, so the kernel is a pure gather — bit-identical by construction.  Columns [C*tp*ps*ps, row_elems) are
+// written as zeros: the patch-embedding GEMM then runs on a tile-aligned K (1176 -> 1280: 46 -> 28 us per group of the 1-hour video).
+__global__ __launch_bounds__(256) void patchify_kernel(const unsigned char* __restrict__ frames, const unsigned short* __restrict__ lut,
+                                                       unsigned short* __restrict__ out, int H, int W, int gh, int gw, int ps, int tp, int mg,
+                                                       int cols, int row_elems, int64_t n_rows) {
+  __shared__ unsigned short s_lut[768];
+  for (int i = threadIdx.x; i < 768; i += 256) s_lut[i] = lut[i];
+  __syncthreads();
+  const int groups = row_elems / 8;                                 // 8 output values (16 bytes) per thread
+  const int pp = ps * ps, cpp = tp * pp;
+  const int uw = gw / mg, uh = gh / mg, mm = mg * mg;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_rows * groups; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / groups;
+    const int c0 = (int)(i % groups) * 8;
+    const int unit = (int)(r / mm), sub = (int)(r % mm);
+    const int wb = unit % uw, t2 = unit / uw, hb = t2 % uh, t = t2 / uh;
+    const int h = hb * mg + sub / mg, w = wb * mg + sub % mg;
+    unsigned short v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int col = c0 + e;
+      if (col < cols) {
+        const int c = col / cpp, rem = col % cpp, tt = rem / pp, rem2 = rem % pp, py = rem2 / ps, px = rem2 % ps;
+        const int64_t src = (((int64_t)(t * tp + tt) * 3 + c) * H + (h * ps + py)) * W + (w * ps + px);
+        v[e] = s_lut[c * 256 + frames[src]];
+      } else {
+        v[e] = 0;
+      }
+    }
+    uint4 o;
+    o.x = v[0] | ((unsigned)v[1] << 16); o.y = v[2] | ((unsigned)v[3] << 16); o.z = v[4] | ((unsigned)v[5] << 16); o.w = v[6] | ((unsigned)v[7] << 16);
+    reinterpret_cast<uint4*>(out)[i] = o;
+  }
+}
+
+int qp_launch_patchify(const void* frames, const void* lut, void* out, int n_frames, int H, int W, int ps, int tp, int mg, int row_elems, hipStream_t s) {
+  const int gt = n_frames / tp, gh = H / ps, gw = W / ps, cols = 3 * tp * ps * ps;
+  const int64_t n_rows = (int64_t)gt * gh * gw, work = n_rows * (row_elems / 8);
+  int64_t blocks = (work + 255) / 256;
+  if (blocks > 65536) blocks = 65536;
+  if (blocks < 1) blocks = 1;
+  patchify_kernel<<<(int)blocks, 256, 0, s>>>((const unsigned char*)frames, (const unsigned short*)lut, (unsigned short*)out, H, W, gh, gw, ps, tp, mg,
+                                              cols, row_elems, n_rows);
+  return qp_check_launch("patchify");
+}
+
 // x = bf16(x + delta) (when delta != NULL, written back);  out = bf16((x - mean) * rstd * w + b)  — the residual add of a ViT
 // block fused with the LayerNorm that follows it (transformers Qwen2VLVisionBlock [3P]: x = x + attn(norm1(x)); x = x + mlp(norm2(x))).
 // One WAVE per row, the row stays in registers (hidden <= 4096): two-pass mean / variance in fp32 like torch's layer_norm.

@@ -99,6 +99,7 @@ SIGNATURES = {
     "qp_vit_attn": (_i32, [_vp, _vp, _i64, _i64, _i32, _i32, _f32, _vp, _vp]),
     "qp_vit_attn_varlen": (_i32, [_vp, _vp, _vp, _i64, _i64, _i32, _i32, _f32, _vp, _vp]),
     "qp_quick_gelu": (_i32, [_vp, _vp, _vp, _i64, _vp]),
+    "qp_patchify": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp]),
     "qp_linear_tune": (_i32, [_vp, _vp, _c.POINTER(_vp), _i32, _vp, _i32, _f32, _vp, _i64, _i64, _i64, _i32, _vp, _sz, _vp]),
     "qp_linear_act": (_i32, [_vp, _vp, _vp, _vp, _i32, _f32, _vp, _i64, _i64, _i64, _i32, _vp, _sz, _vp]),
     "qp_linear_plan_choice": (_i32, [_vp, _i64, _i64, _i64, _i32, _i32, _c.POINTER(_i32), _c.POINTER(_i32)]),
@@ -469,6 +470,13 @@ class QuickPrefillOps:
         """Developer A/B switch of the launch paths (include/quickprefill.h: qp_dev_switch) — process-wide; the library does not read the
         environment at launch time."""
         self._check(self.lib.qp_dev_switch(name.encode(), int(value)))
+
+    def patchify(self, frames_u8, patch, temporal_patch, merge, lut, out):
+        """uint8 frames [F, 3, H, W] -> out [gt*gh*gw, row_elems] bf16 (HF patch order; columns behind the patch zeroed); lut: [3, 256] bf16."""
+        f, c, h, w = frames_u8.shape
+        assert c == 3 and frames_u8.dtype == torch.uint8 and frames_u8.is_contiguous() and out.is_contiguous() and lut.is_contiguous()
+        self._check(self.lib.qp_patchify(self.ctx, frames_u8.data_ptr(), f, h, w, patch, temporal_patch, merge, lut.data_ptr(), out.data_ptr(),
+                                         out.shape[1], self._stream()))
 
     def quick_gelu(self, x, out):
         self._check(self.lib.qp_quick_gelu(self.ctx, x.data_ptr(), out.data_ptr(), x.numel(), self._stream()))

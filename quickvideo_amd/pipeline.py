@@ -506,7 +506,7 @@ class PrefillPipeline:
             read_done.record(torch.cuda.current_stream(dev))                    # rank 0: the ring's device slot has been read
         local = torch.zeros(chunk * S, self.model.spec.hidden, dtype=dt, device=dev)
         if mine:
-            rows, grid = patchify_frames(recv[: mine * tp], vs, dt)
+            rows, grid = self.tower.patchify(recv[: mine * tp])
             local[: mine * S].copy_(self.tower.forward(rows, grid))
         allf = torch.empty(par.world * chunk * S, self.model.spec.hidden, dtype=dt, device=dev)
         dist.all_gather_into_tensor(allf, local, group=grp)
@@ -630,7 +630,7 @@ class PrefillPipeline:
                     if par.on:                                    # scatter by frame pair -> ViT on this rank's share -> all-gather
                         feats, read_done = self._vit_parallel(frames, plan.frames[g], P["H"], P["W"])
                     else:
-                        rows, grid = patchify_frames(frames, self.model.vision.spec, self.model.text.embed.dtype)
+                        rows, grid = self.tower.patchify(frames)
                         read_done = torch.cuda.Event()
                         read_done.record(self.vit_stream)         # last read of the ring's device slot
                         prod.mark_read(g)                         # (native ring: its own event, recorded at the same point)
@@ -639,7 +639,7 @@ class PrefillPipeline:
                 return feats, (s_ev, e_ev, ev), read_done, frames
             if par.on:
                 return self._vit_parallel(frames, plan.frames[g], P["H"], P["W"])[0], None, None, frames
-            rows, grid = patchify_frames(frames, self.model.vision.spec, self.model.text.embed.dtype)
+            rows, grid = self.tower.patchify(frames)
             return self.tower.forward(rows, grid), None, None, frames
 
         t_pre = time.perf_counter()
@@ -864,7 +864,7 @@ class PrefillPipeline:
             for i in range(3):
                 if i == 1:
                     s.record(self.vit_stream)
-                rows, grid = patchify_frames(frames, self.model.vision.spec, self.model.text.embed.dtype)
+                rows, grid = self.tower.patchify(frames)
                 self.tower.forward(rows, grid)
             e.record(self.vit_stream)
         e.synchronize()

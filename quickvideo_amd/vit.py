@@ -199,6 +199,48 @@ class VisionTower:
         self.ops.linear_act(x, w, bias, out, act, alpha)
         return out
 
+    # ------------------------------------------------------------------ front end, first step: frames -> pixel rows
+    def _patch_lut(self, device) -> torch.Tensor:
+        """[3, 256] bf16: what patchify_frames makes of byte v in channel c — the SAME torch expression on the 256 byte values (so the HIP
+        gather below is bit-identical to the torch path by construction)."""
+        luts = self.__dict__.setdefault("_luts", {})
+        key = str(device)
+        if key not in luts:
+            mean, std = _clip_constants(device)
+            v = torch.arange(256, device=device).to(torch.uint8).view(1, 1, 1, 256).expand(1, 3, 1, 256)
+            luts[key] = ((v.to(torch.float32) * (1.0 / 255.0) - mean) / std).to(torch.bfloat16).reshape(3, 256).contiguous()
+        return luts[key]
+
+    def _patch_w(self, k: int) -> torch.Tensor:
+        """The patch-embedding weight for pixel rows of k columns: the checkpoint's [embed, 1176], or — rows from the HIP patchify, padded
+        with zero columns to a GEMM-friendly K — the same weight with zero columns appended (built once)."""
+        w = self.w.patch_w
+        if k == w.shape[1]:
+            return w
+        cache = self.__dict__.setdefault("_patch_w_padded", {})
+        if k not in cache:
+            assert k > w.shape[1], (k, tuple(w.shape))
+            wp = torch.zeros(w.shape[0], k, dtype=w.dtype, device=w.device)
+            wp[:, :w.shape[1]] = w
+            cache[k] = wp
+        return cache[k]
+
+    def patchify(self, frames_u8: torch.Tensor) -> Tuple[torch.Tensor, Tuple[int, int, int]]:
+        """patchify_frames for this tower.  On the GPU with the library: ONE kernel (qp_patchify: uint8 -> normalised bf16 rows in the HF patch
+        order through a 3 x 256 table of the torch path's own values; columns padded with zeros to a multiple of 128 for the patch-embedding
+        GEMM) instead of five torch passes; anywhere else the torch function.  QP_VIT_HIP_PATCHIFY=0: torch (A/B)."""
+        s, ops = self.spec, self.ops
+        if (ops is not None and hasattr(ops, "patchify") and frames_u8.is_cuda and frames_u8.dtype == torch.uint8
+                and self.w.patch_w.dtype == torch.bfloat16 and os.environ.get("QP_VIT_HIP_PATCHIFY", "1") == "1"):
+            Fn, C, H, W = frames_u8.shape
+            ps, tp, mg = s.patch_size, s.temporal_patch_size, s.spatial_merge_size
+            assert C == s.in_channels == 3 and Fn % tp == 0 and H % (ps * mg) == 0 and W % (ps * mg) == 0, "frame count / size not aligned to the patch grid"
+            gt, gh, gw = Fn // tp, H // ps, W // ps
+            out = torch.empty(gt * gh * gw, (s.patch_dim + 127) // 128 * 128, dtype=torch.bfloat16, device=frames_u8.device)
+            ops.patchify(frames_u8.contiguous(), ps, tp, mg, self._patch_lut(frames_u8.device), out)
+            return out, (gt, gh, gw)
+        return patchify_frames(frames_u8, s, self.w.patch_w.dtype)
+
     @torch.no_grad()
     def forward(self, pixel_rows: torch.Tensor, grid_thw: Tuple[int, int, int]) -> torch.Tensor:
         if self.spec.arch == "qwen2.5":
@@ -207,7 +249,7 @@ class VisionTower:
         t, h, wd = grid_thw
         n, seq = pixel_rows.shape[0], h * wd
         assert n == t * seq
-        x = F.linear(pixel_rows.to(w.patch_w.dtype), w.patch_w)                         # Conv3d(stride = kernel) == GEMM
+        x = F.linear(pixel_rows.to(w.patch_w.dtype), self._patch_w(pixel_rows.shape[1]))     # Conv3d(stride = kernel) == GEMM
         pos = vision_pos_ids(grid_thw, s.spatial_merge_size, x.device)                  # [n, 2]
         rd = s.head_dim // 2
         inv_freq = 1.0 / (10000.0 ** (torch.arange(0, rd, 2, dtype=torch.float32, device=x.device) / rd))
@@ -347,7 +389,7 @@ class VisionTower:
         t, h, wd = grid_thw
         n, seq, unit = pixel_rows.shape[0], h * wd, s.spatial_merge_size ** 2
         H, hd, d = s.num_heads, s.head_dim, s.embed_dim
-        x = F.linear(pixel_rows.to(w.patch_w.dtype), w.patch_w)
+        x = F.linear(pixel_rows.to(w.patch_w.dtype), self._patch_w(pixel_rows.shape[1]))
         # the window permutation depends only on the grid: built once per (grid, device) — it is host work + an H2D copy
         wk = (tuple(grid_thw), str(x.device))
         cache = self.__dict__.setdefault("_win_cache", {})

@@ -1217,3 +1217,32 @@ def test_torch_device_argsort_gives_the_stable_list_on_the_reference_expression(
             assert np.array_equal(got, data[f"c{ci}_ref_idx_stable"]), (ci, dist, n, k)
     assert checked >= 15 and same_norms >= 10, (checked, same_norms)
     print(f"device argsort == stable argsort on {checked} cases; device norms == fixture's torch-CPU norms on {same_norms} of them")
+
+
+@pytest.mark.parametrize("shape", [(16, 392, 560), (2, 28, 56), (4, 56, 28), (6, 112, 168)])
+def test_hip_patchify_is_bit_identical_to_the_torch_path(ops, shape):
+    """qp_patchify (front end, first step): uint8 frames -> normalised bf16 pixel rows in the HF patch order as ONE gather through
+    a 3 x 256 table of the torch path's own values — every value must equal vit.patchify_frames' bit for bit, the columns behind the patch
+    must be zero, and the tower must give the same features from the padded rows (zero columns meet zero weights)."""
+    from quickvideo_amd.vit import QWEN2_VL_VIT_7B, VisionSpec, VisionTower, VisionWeights, patchify_frames
+    F_, H_, W_ = shape
+    spec = VisionSpec(depth=1, embed_dim=1280, num_heads=16, out_hidden=256)
+    tower = VisionTower(VisionWeights.synthetic(spec, "cuda:0", seed=2), ops=ops)
+    frames = torch.from_numpy(np.random.RandomState(F_ + H_).randint(0, 256, (F_, 3, H_, W_), dtype=np.uint8)).cuda()
+    frames[0, :, 0, :3] = torch.tensor([0, 255, 128], dtype=torch.uint8, device="cuda")
+    want, grid_w = patchify_frames(frames, spec, torch.bfloat16)
+    got, grid = tower.patchify(frames)
+    torch.cuda.synchronize()
+    assert grid == grid_w and got.shape == (want.shape[0], 1280) and want.shape[1] == 1176
+    assert torch.equal(got[:, :1176].contiguous().view(torch.int16), want.view(torch.int16))
+    assert not got[:, 1176:].any()
+    a, b = tower.forward(got, grid).float(), tower.forward(want, grid).float()
+    torch.cuda.synchronize()
+    assert (a - b).abs().max().item() <= 2e-2 * b.abs().max().item()
+    os.environ["QP_VIT_HIP_PATCHIFY"] = "0"
+    try:
+        assert tower.patchify(frames)[0].shape[1] == 1176                     # the A/B switch gives the torch rows
+    finally:
+        del os.environ["QP_VIT_HIP_PATCHIFY"]
+    with pytest.raises(ValueError, match="not aligned to the patch grid"):
+        ops.patchify(frames[:, :, :27].contiguous(), 14, 2, 2, tower._patch_lut(frames.device), got)

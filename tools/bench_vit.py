@@ -10,7 +10,7 @@ H_, W_ = (int(v) for v in os.environ.get("QP_VIT_HW", "560,1008").split(","))   
 NF = int(os.environ.get("QP_VIT_FRAMES", "16"))                                    # QP_VIT_FRAMES=32: two frame groups in ONE tower pass (M doubles)
 frames = torch.randint(0, 256, (NF, 3, H_, W_), dtype=torch.uint8, device=dev)
 def f():
-    rows, grid = patchify_frames(frames, w.spec)
+    rows, grid = tower.patchify(frames)
     return tower.forward(rows, grid)
 for _ in range(2): f()
 torch.cuda.synchronize()
